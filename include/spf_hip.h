@@ -1,0 +1,173 @@
+/*
+ * spf_hip.h — C ABI of the MI355X (gfx950) bootstrap engine.
+ *
+ * Drop-in boundary for the programmable-bootstrap hot path of Sunscreen-tech/spf.  The
+ * reference has no FFI of its own; its seam is the concrete struct
+ * `parasol_runtime::Evaluation` (parasol_runtime/src/crypto/evaluation.rs:144-266), whose
+ * methods take caller-allocated `&mut` outputs, never fail, and are called concurrently from
+ * rayon workers (circuit_processor/mod.rs:201-209).  Every entry point below names the
+ * reference method / function whose body it replaces.  Citations are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns spf_status (0 = OK) and
+ *     leaves a message retrievable with spf_last_error().
+ *   - all arrays are dense, row-major, little-endian, in the reference's own layouts:
+ *       LWE(n)        n mask words then the body                     entities/lwe_ciphertext.rs:24-33
+ *       GLWE(k,N)     k mask polynomials then the body polynomial    entities/glwe_ciphertext.rs:32-41
+ *       GGSW-FFT      [row<k+1][level<l][poly<k+1][bin<N/2]{re,im}   entities/ggsw_ciphertext_fft.rs:23-29
+ *       BSK-FFT       [i<n] GGSW-FFT, natural DFT bin order           entities/bootstrap_key.rs:119-125
+ *       KSK           [i<k*N][level<l_ks][n+1]                        entities/lwe_keyswitch_key.rs:27-36
+ *     Torus elements are uint64_t (Torus<u64>, math/torus.rs:213); complex bins are
+ *     interleaved {double re, double im} (num_complex::Complex<f64>).
+ *   - "_batch" entry points take HOST pointers (what a Rust shim holding `&[u64]` passes) and
+ *     stage through device memory; "_dev" entry points take DEVICE pointers plus a hipStream_t
+ *     (passed as void*) and are asynchronous on that stream.
+ *   - a context is bound to one GPU; one process per GPU.  Calls on one context are
+ *     serialised internally (thread-safe); use one context per stream for concurrency.
+ */
+#ifndef SPF_HIP_H
+#define SPF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int spf_status;
+enum {
+    SPF_OK = 0,
+    SPF_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, size mismatch, unsupported parameter */
+    SPF_ERR_HIP = 2,              /* a HIP runtime call failed (message has the HIP error) */
+    SPF_ERR_NO_KEY = 3,           /* the key this operation needs has not been loaded */
+    SPF_ERR_UNSUPPORTED = 4       /* parameter set outside what the kernels are built for */
+};
+
+/* Mirror of `parasol_runtime::Params` (parasol_runtime/src/params.rs:10-100; DEFAULT_128 at
+ * :107-134) restricted to the fields the bootstrap / keyswitch path reads. */
+typedef struct spf_params {
+    uint32_t lwe_dimension;     /* l0_params.dim            = 637  */
+    uint32_t polynomial_degree; /* l1_params.dim.polynomial_degree = 2048 */
+    uint32_t glwe_size;         /* l1_params.dim.size       = 1    */
+    uint32_t pbs_radix_log;     /* pbs_radix.radix_log      = 16   */
+    uint32_t pbs_radix_count;   /* pbs_radix.count          = 2    */
+    uint32_t cbs_radix_log;     /* cbs_radix.radix_log      = 4    */
+    uint32_t cbs_radix_count;   /* cbs_radix.count          = 4    */
+    uint32_t ks_radix_log;      /* ks_radix.radix_log       = 2    */
+    uint32_t ks_radix_count;    /* ks_radix.count           = 6    */
+} spf_params;
+
+/* DEFAULT_128 (parasol_runtime/src/params.rs:107-134) */
+void spf_default_params(spf_params *out);
+
+typedef struct spf_ctx spf_ctx;
+
+/* Replaces `Evaluation::new` (crypto/evaluation.rs:161-197) minus key ownership: creates the
+ * per-GPU engine (twiddle tables, scratch).  device_id is the HIP ordinal. */
+spf_status spf_create(const spf_params *params, int device_id, spf_ctx **out);
+void spf_destroy(spf_ctx *ctx);
+/* Message of the last failing call on this context (or on creation when ctx == NULL). */
+const char *spf_last_error(const spf_ctx *ctx);
+
+/* ---- keys: `ComputeKey` fields (crypto/keys.rs:306-318) ------------------------------- */
+
+/* `ComputeKey::bs_key` : BootstrapKeyFft<Complex<f64>>.  n_complex must equal
+ * lwe_dimension * (k+1)*l_pbs*(k+1)*N/2.  Host pointer; copied to HBM. */
+spf_status spf_load_bootstrap_key(spf_ctx *ctx, const double *bsk_fft, size_t n_complex);
+/* `ComputeKey::ks_key` : LweKeyswitchKey<u64>.  n_words = k*N * l_ks * (lwe_dimension+1). */
+spf_status spf_load_keyswitch_key(spf_ctx *ctx, const uint64_t *ksk, size_t n_words);
+
+/* Multi-GPU key replication (no reference counterpart): the device-resident
+ * key blobs, so that a caller can RCCL-broadcast rank 0's keys into every other rank's
+ * context.  which: 0 = bootstrap key, 1 = keyswitch key.  Allocates the blob if needed;
+ * after filling it externally call spf_key_blob_commit. */
+spf_status spf_key_blob(spf_ctx *ctx, int which, void **dev_ptr, size_t *bytes);
+spf_status spf_key_blob_commit(spf_ctx *ctx, int which);
+
+/* ---- the hot path, host-pointer batch forms --------------------------------------------- */
+
+/* B x `Evaluation::keyswitch_lwe_l1_lwe_l0` (crypto/evaluation.rs:246-255) =
+ * `keyswitch_lwe_to_lwe` (sunscreen_tfhe/src/ops/keyswitch/lwe_keyswitch.rs:23-62).
+ * lwe1_in: B x (k*N+1), lwe0_out: B x (lwe_dimension+1). */
+spf_status spf_keyswitch_lwe_l1_lwe_l0_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1_in,
+                                             uint64_t *lwe0_out);
+
+/* B x `generalized_programmable_bootstrap`
+ * (sunscreen_tfhe/src/ops/bootstrapping/programmable_bootstrapping.rs:342-410).
+ * lwe0_in : B x (lwe_dimension+1)
+ * lut_glwe: the UnivariateLookupTable's GLWE, (k+1)*N words; lut_stride = 0 shares one LUT
+ *           across the batch, otherwise ciphertext j uses lut_glwe + j*lut_stride.
+ * body_rotate is added to each input body first (`lwe_rotate`,
+ *           ops/homomorphisms/lwe.rs:9-20; 0 for a plain PBS).
+ * glwe_out: B x (k+1)*N. */
+spf_status spf_generalized_pbs_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0_in,
+                                     const uint64_t *lut_glwe, size_t lut_stride, uint32_t log_chi,
+                                     uint32_t log_v, uint64_t body_rotate, uint64_t *glwe_out);
+
+/* B x `programmable_bootstrap_univariate` (programmable_bootstrapping.rs:291-318):
+ * generalized PBS with (log_chi, log_v) = (0, 0) then `sample_extract(., 0)`.
+ * lwe1_out: B x (k*N+1). */
+spf_status spf_pbs_univariate_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0_in,
+                                    const uint64_t *lut_glwe, size_t lut_stride,
+                                    uint64_t *lwe1_out);
+
+/* B x the bootstrap stage of `Evaluation::circuit_bootstrap` (crypto/evaluation.rs:211-226):
+ * `hi_noise_lwe_to_lo_noise_glwe` (ops/bootstrapping/circuit_bootstrapping.rs:387-427) =
+ * rotate by q/4, multifunctional CBS LUT (:430-482), generalized PBS with
+ * log_v = ceil(log2(cbs_radix_count)).  glwe_out: B x (k+1)*N. */
+spf_status spf_circuit_bootstrap_pbs_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0_in,
+                                           uint64_t *glwe_out);
+
+/* B x `KeylessEvaluation::sample_extract_l1` (crypto/evaluation.rs:126-133) =
+ * `sample_extract` (ops/ciphertext/glwe_ciphertext_ops.rs:31-76), same index for the batch. */
+spf_status spf_sample_extract_l1_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in, size_t idx,
+                                       uint64_t *lwe1_out);
+
+/* B x `KeylessEvaluation::cmux` (crypto/evaluation.rs:68-83) = `cmux`
+ * (sunscreen_tfhe/src/ops/fft_ops.rs:149-181) with the GGSW in cbs_radix shape.
+ * sel_ggsw_fft: B x (k+1)*l_cbs*(k+1)*N/2 complex; a (selected when 0), b (when 1), out:
+ * B x (k+1)*N. */
+spf_status spf_cmux_batch(spf_ctx *ctx, size_t B, const double *sel_ggsw_fft, const uint64_t *a,
+                          const uint64_t *b, uint64_t *out);
+
+/* The north-star "gate": keyswitch L1->L0 then the circuit-bootstrap PBS, fused on device
+ * (FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, circuit_processor/mod.rs:329-340,453-463).
+ * lwe1_in: B x (k*N+1); glwe_out: B x (k+1)*N. */
+spf_status spf_gate_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1_in,
+                                    uint64_t *glwe_out);
+
+/* ---- device-pointer forms (inputs/outputs resident in HBM, asynchronous on `stream`) ----- */
+
+spf_status spf_keyswitch_lwe_l1_lwe_l0_dev(spf_ctx *ctx, void *stream, size_t B,
+                                           const uint64_t *d_lwe1_in, uint64_t *d_lwe0_out);
+spf_status spf_generalized_pbs_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_lwe0_in,
+                                   const uint64_t *d_lut_glwe, size_t lut_stride, uint32_t log_chi,
+                                   uint32_t log_v, uint64_t body_rotate, uint64_t *d_glwe_out);
+spf_status spf_pbs_univariate_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_lwe0_in,
+                                  const uint64_t *d_lut_glwe, size_t lut_stride,
+                                  uint64_t *d_lwe1_out);
+spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx *ctx, void *stream, size_t B,
+                                         const uint64_t *d_lwe0_in, uint64_t *d_glwe_out);
+spf_status spf_sample_extract_l1_dev(spf_ctx *ctx, void *stream, size_t B,
+                                     const uint64_t *d_glwe_in, size_t idx, uint64_t *d_lwe1_out);
+spf_status spf_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,
+                        const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------- */
+
+/* Average device time in milliseconds of the `reps` most recent blind-rotation launches made
+ * through this context, measured with hipEvents recorded on the launch stream around each
+ * kernel.  Enable with spf_set_timing(ctx, 1) before launching. */
+spf_status spf_set_timing(spf_ctx *ctx, int enabled);
+spf_status spf_last_kernel_ms(spf_ctx *ctx, const char *kernel /* "pbs" | "keyswitch" */,
+                              double *avg_ms, int *launches);
+
+/* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */
+const char *spf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPF_HIP_H */

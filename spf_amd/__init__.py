@@ -1,0 +1,15 @@
+"""spf_amd — MI355X (gfx950) engine for the programmable-bootstrap path of Sunscreen-tech/spf.
+
+The compute lives in hand-written HIP kernels behind a C ABI (include/spf_hip.h,
+spf_amd/csrc/).  This package is plumbing over that ABI: a ctypes binding and a host-side
+mirror of ``parasol_runtime::Evaluation`` (parasol_runtime/src/crypto/evaluation.rs:144-266).
+There is no CPU fallback: importing works anywhere, but creating an ``Engine`` without the
+compiled library or without a GPU raises.
+"""
+from .params import Params, DEFAULT_128  # noqa: F401
+from ._ffi import Engine, SpfError, lib_path, load_library  # noqa: F401
+from .evaluation import Evaluation, ComputeKey  # noqa: F401
+from .build import build_library  # noqa: F401
+
+__all__ = ["Params", "DEFAULT_128", "Engine", "SpfError", "Evaluation", "ComputeKey",
+           "build_library", "lib_path", "load_library"]

@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/spf_hip.h.
+
+``Engine`` wraps one ``spf_ctx`` (one GPU).  Host-array methods take / return numpy arrays and
+go through the ``*_batch`` entry points; ``*_dev`` methods take raw device pointers (e.g.
+``torch.Tensor.data_ptr()``) and a stream handle and are asynchronous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .params import Params, DEFAULT_128
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SpfError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"spf_hip status {status}: {msg}")
+        self.status = status
+
+
+class _CParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "lwe_dimension", "polynomial_degree", "glwe_size", "pbs_radix_log", "pbs_radix_count",
+        "cbs_radix_log", "cbs_radix_count", "ks_radix_log", "ks_radix_count")]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libspf_hip.so")
+
+
+# every symbol include/spf_hip.h declares: (name, restype, argtypes)
+_P, _SZ, _U32, _U64, _I = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
+SYMBOLS = [
+    ("spf_default_params", None, [C.POINTER(_CParams)]),
+    ("spf_create", _I, [C.POINTER(_CParams), _I, C.POINTER(_P)]),
+    ("spf_destroy", None, [_P]),
+    ("spf_last_error", C.c_char_p, [_P]),
+    ("spf_load_bootstrap_key", _I, [_P, _P, _SZ]),
+    ("spf_load_keyswitch_key", _I, [_P, _P, _SZ]),
+    ("spf_key_blob", _I, [_P, _I, C.POINTER(_P), C.POINTER(_SZ)]),
+    ("spf_key_blob_commit", _I, [_P, _I]),
+    ("spf_keyswitch_lwe_l1_lwe_l0_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_generalized_pbs_batch", _I, [_P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
+    ("spf_pbs_univariate_batch", _I, [_P, _SZ, _P, _P, _SZ, _P]),
+    ("spf_circuit_bootstrap_pbs_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_sample_extract_l1_batch", _I, [_P, _SZ, _P, _SZ, _P]),
+    ("spf_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
+    ("spf_gate_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_keyswitch_lwe_l1_lwe_l0_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_generalized_pbs_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
+    ("spf_pbs_univariate_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
+    ("spf_circuit_bootstrap_pbs_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_sample_extract_l1_dev", _I, [_P, _P, _SZ, _P, _SZ, _P]),
+    ("spf_cmux_dev", _I, [_P, _P, _SZ, _P, _P, _P, _P]),
+    ("spf_set_timing", _I, [_P, _I]),
+    ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
+    ("spf_version", C.c_char_p, []),
+]
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and declare every prototype.  Raises if it has not been built —
+    the product path never falls back to a CPU implementation."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise SpfError(-1, f"{p} is missing: build it with spf_amd.build_library() "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _u64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One GPU's bootstrap engine (`spf_ctx`)."""
+
+    def __init__(self, params: Params = DEFAULT_128, device: int = 0):
+        self._lib = load_library()
+        self.params = params
+        self.device = device
+        cp = _CParams(*[getattr(params, n) for n, _ in _CParams._fields_])
+        h = C.c_void_p()
+        st = self._lib.spf_create(C.byref(cp), device, C.byref(h))
+        if st != 0:
+            raise SpfError(st, (self._lib.spf_last_error(None) or b"").decode())
+        self._h = h
+
+    # -- plumbing
+    def _ck(self, st: int):
+        if st != 0:
+            raise SpfError(st, (self._lib.spf_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.spf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def version(self) -> str:
+        return self._lib.spf_version().decode()
+
+    # -- keys (ComputeKey fields, crypto/keys.rs:306-318)
+    def load_bootstrap_key(self, bsk_fft: np.ndarray):
+        a = np.ascontiguousarray(bsk_fft, dtype=np.complex128).reshape(-1)
+        self._ck(self._lib.spf_load_bootstrap_key(self._h, _ptr(a), a.size))
+
+    def load_keyswitch_key(self, ksk: np.ndarray):
+        a = _u64(ksk).reshape(-1)
+        self._ck(self._lib.spf_load_keyswitch_key(self._h, _ptr(a), a.size))
+
+    def key_blob(self, which: int):
+        """(device pointer, bytes) of the device-resident key; for RCCL broadcast."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.spf_key_blob(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def key_blob_commit(self, which: int):
+        self._ck(self._lib.spf_key_blob_commit(self._h, which))
+
+    # -- host-array batch forms
+    def keyswitch_lwe_l1_lwe_l0(self, lwe1: np.ndarray) -> np.ndarray:
+        x = _u64(lwe1)
+        x = x.reshape(-1, self.params.lwe1_words)
+        out = np.empty((x.shape[0], self.params.lwe0_words), dtype=np.uint64)
+        self._ck(self._lib.spf_keyswitch_lwe_l1_lwe_l0_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def _lut(self, lut, B):
+        lut = _u64(lut)
+        if lut.ndim == 1:
+            if lut.size != self.params.glwe_words:
+                raise ValueError("lut must hold one GLWE")
+            return lut, 0
+        if lut.shape != (B, self.params.glwe_words):
+            raise ValueError("per-ciphertext luts must be B x glwe_words")
+        return lut, self.params.glwe_words
+
+    def generalized_pbs(self, lwe0, lut_glwe, log_chi=0, log_v=0, body_rotate=0) -> np.ndarray:
+        x = _u64(lwe0).reshape(-1, self.params.lwe0_words)
+        lut, stride = self._lut(lut_glwe, x.shape[0])
+        out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        self._ck(self._lib.spf_generalized_pbs_batch(self._h, x.shape[0], _ptr(x), _ptr(lut), stride,
+                                                     log_chi, log_v, body_rotate, _ptr(out)))
+        return out
+
+    def pbs_univariate(self, lwe0, lut_glwe) -> np.ndarray:
+        x = _u64(lwe0).reshape(-1, self.params.lwe0_words)
+        lut, stride = self._lut(lut_glwe, x.shape[0])
+        out = np.empty((x.shape[0], self.params.lwe1_words), dtype=np.uint64)
+        self._ck(self._lib.spf_pbs_univariate_batch(self._h, x.shape[0], _ptr(x), _ptr(lut), stride,
+                                                    _ptr(out)))
+        return out
+
+    def circuit_bootstrap_pbs(self, lwe0) -> np.ndarray:
+        x = _u64(lwe0).reshape(-1, self.params.lwe0_words)
+        out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        self._ck(self._lib.spf_circuit_bootstrap_pbs_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def sample_extract_l1(self, glwe, idx: int) -> np.ndarray:
+        x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        out = np.empty((x.shape[0], self.params.lwe1_words), dtype=np.uint64)
+        self._ck(self._lib.spf_sample_extract_l1_batch(self._h, x.shape[0], _ptr(x), idx, _ptr(out)))
+        return out
+
+    def cmux(self, sel_ggsw_fft, a, b) -> np.ndarray:
+        g = np.ascontiguousarray(sel_ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
+        a = _u64(a).reshape(-1, self.params.glwe_words)
+        b = _u64(b).reshape(-1, self.params.glwe_words)
+        out = np.empty_like(a)
+        self._ck(self._lib.spf_cmux_batch(self._h, a.shape[0], _ptr(g), _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def gate_bootstrap(self, lwe1) -> np.ndarray:
+        x = _u64(lwe1).reshape(-1, self.params.lwe1_words)
+        out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        self._ck(self._lib.spf_gate_bootstrap_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    # -- device-pointer forms (ints are raw device addresses; stream is a hipStream_t handle)
+    def keyswitch_dev(self, stream: int, B: int, d_in: int, d_out: int):
+        self._ck(self._lib.spf_keyswitch_lwe_l1_lwe_l0_dev(self._h, stream, B, d_in, d_out))
+
+    def generalized_pbs_dev(self, stream, B, d_lwe, d_lut, lut_stride, log_chi, log_v, body_rotate, d_out):
+        self._ck(self._lib.spf_generalized_pbs_dev(self._h, stream, B, d_lwe, d_lut, lut_stride,
+                                                   log_chi, log_v, body_rotate, d_out))
+
+    def pbs_univariate_dev(self, stream, B, d_lwe, d_lut, lut_stride, d_out):
+        self._ck(self._lib.spf_pbs_univariate_dev(self._h, stream, B, d_lwe, d_lut, lut_stride, d_out))
+
+    def circuit_bootstrap_pbs_dev(self, stream: int, B: int, d_lwe: int, d_out: int):
+        self._ck(self._lib.spf_circuit_bootstrap_pbs_dev(self._h, stream, B, d_lwe, d_out))
+
+    def sample_extract_l1_dev(self, stream, B, d_glwe, idx, d_out):
+        self._ck(self._lib.spf_sample_extract_l1_dev(self._h, stream, B, d_glwe, idx, d_out))
+
+    # -- measurement
+    def set_timing(self, enabled: bool):
+        self._ck(self._lib.spf_set_timing(self._h, 1 if enabled else 0))
+
+    def last_kernel_ms(self, kernel: str = "pbs"):
+        ms, n = C.c_double(), C.c_int()
+        self._ck(self._lib.spf_last_kernel_ms(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

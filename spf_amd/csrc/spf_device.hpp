@@ -1,0 +1,195 @@
+// spf_device.hpp — device-side arithmetic of the gfx950 bootstrap engine.
+//
+// Everything here is wave64 / CDNA4 code: a 512-point complex FFT lives in ONE wavefront
+// (64 lanes x 8 complex f64 registers), exchanges go through a per-wave LDS tile with an
+// XOR-swizzled, bank-conflict-free image, and no workgroup barrier is ever needed.
+//
+// The arithmetic follows the canonical operation order "DAG-I" (DESIGN.md §FFT): every add,
+// multiply and fma below is performed on the same operands in the same association as the
+// build's definition, so results are reproducible bit for bit.  Compile with
+// -ffp-contract=off: the only fused operations are the explicit __builtin_fma calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spf {
+
+struct c64 {
+    double re, im;
+};
+
+__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c64 csub(c64 a, c64 b) { return {a.re - b.re, a.im - b.im}; }
+
+// Complex product as num-complex defines it (4 mul, 1 sub, 1 add; nothing fused) — what
+// complex_twist / complex_untwist / complex_mad use
+// (sunscreen_tfhe/src/math/simd/scalar.rs:12-35).
+__device__ __forceinline__ c64 cmul_nf(c64 a, c64 b)
+{
+    c64 o;
+    o.re = a.re * b.re - a.im * b.im;
+    o.im = a.re * b.im + a.im * b.re;
+    return o;
+}
+// a * conj(b), same association as cmul_nf(a, {b.re, -b.im})
+__device__ __forceinline__ c64 cmul_nf_conj(c64 a, c64 b)
+{
+    c64 o;
+    o.re = a.re * b.re + a.im * b.im;
+    o.im = a.im * b.re - a.re * b.im;
+    return o;
+}
+
+// FFT-internal twiddle product of DAG-I: one multiply and one fma per component.
+template <int DIR> __device__ __forceinline__ c64 cmul_tw(c64 a, c64 w)
+{
+    c64 o;
+    if (DIR > 0) {
+        double t1 = a.im * w.im;
+        o.re = __builtin_fma(a.re, w.re, -t1);
+        double t2 = a.im * w.re;
+        o.im = __builtin_fma(a.re, w.im, t2);
+    } else { // multiply by conj(w)
+        double t1 = a.im * w.im;
+        o.re = __builtin_fma(a.re, w.re, t1);
+        double t2 = a.im * w.re;
+        o.im = __builtin_fma(-a.re, w.im, t2);
+    }
+    return o;
+}
+
+constexpr double kSqrtHalf = 0.70710678118654752440; // 0x3FE6A09E667F3BCD
+
+// 8-point DFT, decimation in frequency, in place.  DIR=+1: e^{-2 pi i jk/8}, DIR=-1: conjugate.
+template <int DIR> __device__ __forceinline__ void radix8(c64 (&v)[8])
+{
+    c64 s0 = cadd(v[0], v[4]), s1 = cadd(v[1], v[5]), s2 = cadd(v[2], v[6]), s3 = cadd(v[3], v[7]);
+    c64 t0 = csub(v[0], v[4]), t1 = csub(v[1], v[5]), t2 = csub(v[2], v[6]), t3 = csub(v[3], v[7]);
+    c64 t1w, t3w;
+    if (DIR > 0) {
+        double p1 = t1.re + t1.im, m1 = t1.im - t1.re;
+        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
+        double p3 = t3.re + t3.im, m3 = t3.im - t3.re;
+        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
+    } else {
+        double p1 = t1.re + t1.im, m1 = t1.re - t1.im;
+        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
+        double p3 = t3.re + t3.im, m3 = t3.re - t3.im;
+        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
+    }
+    c64 a0 = cadd(s0, s2), a1 = cadd(s1, s3), a2 = csub(s0, s2), d = csub(s1, s3);
+    v[0] = cadd(a0, a1);
+    v[4] = csub(a0, a1);
+    c64 b0, b2;
+    if (DIR > 0) {
+        v[2] = {a2.re + d.im, a2.im - d.re};
+        v[6] = {a2.re - d.im, a2.im + d.re};
+        b0 = {t0.re + t2.im, t0.im - t2.re};
+        b2 = {t0.re - t2.im, t0.im + t2.re};
+    } else {
+        v[2] = {a2.re - d.im, a2.im + d.re};
+        v[6] = {a2.re + d.im, a2.im - d.re};
+        b0 = {t0.re - t2.im, t0.im + t2.re};
+        b2 = {t0.re + t2.im, t0.im - t2.re};
+    }
+    c64 b1 = cadd(t1w, t3w), e = csub(t1w, t3w);
+    v[1] = cadd(b0, b1);
+    v[5] = csub(b0, b1);
+    if (DIR > 0) {
+        v[3] = {b2.re + e.im, b2.im - e.re};
+        v[7] = {b2.re - e.im, b2.im + e.re};
+    } else {
+        v[3] = {b2.re - e.im, b2.im + e.re};
+        v[7] = {b2.re + e.im, b2.im - e.re};
+    }
+}
+
+// ---- LDS image of the twiddle tables (one copy per workgroup), in 16-byte complex entries.
+//   T1[k1-1][lane]   = W512^{lane*k1}, k1 = 1..7          (7*64 entries)
+//   T2[c-1][b]       = W64^{b*c},      c  = 1..7, b < 8   (7*8  entries)
+//   WC[k]            = W1024^{k},      k < 512
+//   TW[par][n']      = e^{+i pi (2n'+par)/2048}, n' < 512 (negacyclic twist, de-interleaved)
+// with W_M = e^{-2 pi i / M}.  The host builds the same image (spf_hip.hip: build_tables).
+constexpr int kT1Off = 0;
+constexpr int kT2Off = kT1Off + 7 * 64;
+constexpr int kWCOff = kT2Off + 7 * 8;
+constexpr int kTWOff = kWCOff + 512;
+constexpr int kTableEntries = kTWOff + 1024; // 2040 entries = 32640 bytes
+constexpr int kTableBytes = kTableEntries * 16;
+constexpr int kWaveBufBytes = 16384; // per-wave staging / exchange tile
+
+// wave-local ordering point between LDS writes and the reads of other lanes' data.  DS
+// operations of one wave execute in issue order; the asm keeps the compiler from moving
+// memory operations across and drains the LDS queue.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// 512-point DFT, DIF 8x8x8, held by one wave: lane l, register j holds element 64*j + l on
+// entry (time order) and on exit (frequency order).  `buf` is this FFT's private 8 KiB LDS
+// tile, `tab` the table image.
+//   n' = 64*n1 + n0, n0 = 8a + b;   k' = k1 + 8c + 64d
+//   pass 1: radix-8 over n1 -> k1, * W512^{n0 k1} (k1 != 0)     lanes (a,b)  regs k1
+//   exchange 1                                                  lanes (b,k1) regs a
+//   pass 2: radix-8 over a -> c,  * W64^{b c}   (c != 0)        lanes (b,k1) regs c
+//   exchange 2                                                  lanes (c,k1) regs b
+//   pass 3: radix-8 over b -> d                                 lanes (c,k1) regs d
+// Exchange images (16-byte slots): slot(x, y, z) = 64 x + 8 z + (y ^ z) with (x,y,z) =
+// (a,b,k1) resp. (b,c,k1): writes hit 8 distinct slots mod 8 per 8-lane group and reads 16
+// distinct slots mod 16 per ds_read_b128 lane group — conflict-free both ways.
+template <int DIR>
+__device__ __forceinline__ void fft512_wave(c64 (&v)[8], char* buf, const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    // pass 1
+    radix8<DIR>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul_tw<DIR>(v[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    // exchange 1: writer lane = 8a + b holds reg k1 -> slot 64a + 8k1 + (b ^ k1)
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = v[k1];
+    wave_lds_fence();
+    // reader lane = 8b + k1 wants reg a <- slot 64a + 8k1 + (b ^ k1)
+    const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
+#pragma unroll
+    for (int a = 0; a < 8; a++) v[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
+    // pass 2
+    radix8<DIR>(v);
+#pragma unroll
+    for (int c = 1; c < 8; c++) v[c] = cmul_tw<DIR>(v[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    wave_lds_fence(); // all lanes' exchange-1 reads retired before the tile is overwritten
+    // exchange 2: writer lane = 8b + k1 holds reg c -> slot 64b + 8k1 + (c ^ k1)
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = v[c];
+    wave_lds_fence();
+    // reader lane = 8c + k1 wants reg b <- slot 64b + 8k1 + (c ^ k1)
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
+    // pass 3
+    radix8<DIR>(v);
+    wave_lds_fence(); // reads retired before the caller reuses the tile
+}
+
+// round half away from zero, then reduce mod 2^64 into the torus exactly as
+// PolynomialFftRef::ifft does (entities/polynomial_fft.rs:82-99 -> simd/scalar.rs:26-35,
+// 75-119 -> `x as i64` saturating, math/torus.rs:177-192).
+__device__ __forceinline__ uint64_t f64_round_to_torus(double x)
+{
+    const double q = 18446744073709551616.0;      // 2^64
+    const double q_div_2 = 9223372036854775808.0; // 2^63
+    double v = __builtin_round(x);
+    double m = __builtin_fma(-__builtin_trunc(v * (1.0 / q)), q, v);
+    // branch-free form of `if m >= q/2 { m -= q } else if m <= -q/2 { m += q }`
+    double adj = (m >= q_div_2) ? -q : ((m <= -q_div_2) ? q : 0.0);
+    m += adj;
+    // m is now in [-2^63, 2^63]; `as i64` saturates the single out-of-range value +2^63
+    bool sat = m >= q_div_2;
+    long long r = (long long)(sat ? 0.0 : m);
+    r = sat ? 0x7FFFFFFFFFFFFFFFll : r;
+    return (uint64_t)r;
+}
+
+} // namespace spf

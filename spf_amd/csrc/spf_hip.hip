@@ -1,0 +1,568 @@
+// spf_hip.hip — host side of the C ABI declared in include/spf_hip.h.
+//
+// Owns the per-GPU context: device copies of the evaluation keys (reference layouts, 288 GB of
+// HBM means every rank simply holds a full replica), the twiddle image, growable staging
+// buffers for the host-pointer entry points, and hipEvent timing for bench.py.
+// No exception leaves this file; every entry point returns spf_status.
+#include "../../include/spf_hip.h"
+#include "spf_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace spf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+} // namespace
+
+struct spf_ctx {
+    spf_params prm{};
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    c64* d_tables = nullptr;
+    c64* d_bsk = nullptr;
+    size_t bsk_bytes = 0;
+    bool bsk_ready = false;
+    uint64_t* d_ksk = nullptr;
+    size_t ksk_bytes = 0;
+    bool ksk_ready = false;
+    uint64_t* d_cbs_lut = nullptr; // fill_multifunctional_cbs_decomposition_lut, constant per params
+    DevBuf in, out, mid, aux;      // staging for the host-pointer entry points
+    hipStream_t stream = nullptr;  // stream of the host-pointer entry points
+    bool timing = false;
+    std::vector<TimedLaunch> t_pbs, t_ks;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+};
+
+namespace {
+
+spf_status fail(spf_ctx* c, spf_status s, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return s;
+}
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, SPF_ERR_HIP,                                                         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+// e^{+2 pi i num/den}: first-octant cosl/sinl, rounded once to double, mirrored by octant so
+// conjugate / quarter-turn partners are exact.  (The build's definition of its twiddles.)
+c64 root_of_unity(uint64_t num, uint64_t den)
+{
+    static const long double TWO_PI = 6.283185307179586476925286766559005768L;
+    uint64_t j = num % den, eighth = den / 8, oct = j / eighth, r = j % eighth;
+    uint64_t rr = (oct & 1) ? (eighth - r) : r;
+    long double th = TWO_PI * (long double)rr / (long double)den;
+    double c = (double)cosl(th), s = (double)sinl(th);
+    if (rr == 0) { c = 1.0; s = 0.0; }
+    switch (oct) {
+    case 0: return {c, s};
+    case 1: return {s, c};
+    case 2: return {-s, c};
+    case 3: return {-c, s};
+    case 4: return {-c, -s};
+    case 5: return {-s, -c};
+    case 6: return {s, -c};
+    default: return {c, -s};
+    }
+}
+
+c64 conj(c64 a) { return {a.re, -a.im}; }
+
+void build_tables(std::vector<c64>& t)
+{
+    t.resize(kTableEntries);
+    for (int k1 = 1; k1 < 8; k1++)
+        for (int lane = 0; lane < 64; lane++)
+            t[kT1Off + (k1 - 1) * 64 + lane] = conj(root_of_unity((uint64_t)(lane * k1), 512));
+    for (int c = 1; c < 8; c++)
+        for (int b = 0; b < 8; b++) t[kT2Off + (c - 1) * 8 + b] = conj(root_of_unity((uint64_t)(b * c), 64));
+    for (int k = 0; k < 512; k++) t[kWCOff + k] = conj(root_of_unity((uint64_t)k, 1024));
+    // negacyclic twist e^{+2 pi i j / (2N)}, j = 2n' + par (math/fft/negacyclic/mod.rs:56-65)
+    for (int par = 0; par < 2; par++)
+        for (int n = 0; n < 512; n++) t[kTWOff + par * 512 + n] = root_of_unity((uint64_t)(2 * n + par), 4096);
+}
+
+uint32_t ceil_log2(uint32_t v)
+{
+    uint32_t l = 0;
+    while ((1u << l) < v) l++;
+    return l;
+}
+
+spf_status ensure(spf_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (b.cap >= bytes) return SPF_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SPF_OK;
+}
+
+size_t lwe0_words(const spf_params& p) { return (size_t)p.lwe_dimension + 1; }
+size_t lwe1_words(const spf_params& p) { return (size_t)p.glwe_size * p.polynomial_degree + 1; }
+size_t glwe_words(const spf_params& p) { return (size_t)(p.glwe_size + 1) * p.polynomial_degree; }
+size_t ggsw_fft_complex(const spf_params& p, uint32_t count)
+{
+    return (size_t)(p.glwe_size + 1) * count * (p.glwe_size + 1) * (p.polynomial_degree / 2);
+}
+
+spf_status get_events(spf_ctx* c, hipEvent_t* a, hipEvent_t* b)
+{
+    HIPCHK(c, hipEventCreate(a));
+    HIPCHK(c, hipEventCreate(b));
+    return SPF_OK;
+}
+
+spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe,
+                               const uint64_t* d_lut, size_t lut_stride, uint32_t log_chi,
+                               uint32_t log_v, uint64_t body_rotate, uint64_t* d_out,
+                               size_t out_stride, bool extract)
+{
+    if (!c->bsk_ready) return fail(c, SPF_ERR_NO_KEY, "bootstrap key not loaded");
+    if (B == 0) return SPF_OK;
+    if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    // modulus switch needs log_modulus - log_v >= 1 and shifts below 64
+    if (log_v >= 12 || log_chi >= 52) return fail(c, SPF_ERR_INVALID_ARGUMENT, "log_v / log_chi out of range");
+    BlindRotateArgs a{};
+    a.lwe_in = d_lwe; a.lut = d_lut; a.lut_stride = lut_stride; a.bsk = c->d_bsk;
+    a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
+    a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
+    a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
+    const size_t lds = kTableBytes + kWavesPerBlock * kWaveBufBytes;
+    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(256);
+    TimedLaunch tl{};
+    if (c->timing) {
+        spf_status st = get_events(c, &tl.start, &tl.stop);
+        if (st != SPF_OK) return st;
+        HIPCHK(c, hipEventRecord(tl.start, s));
+    }
+    hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, lds, s, a);
+    HIPCHK(c, hipGetLastError());
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(tl.stop, s));
+        c->t_pbs.push_back(tl);
+    }
+    return SPF_OK;
+}
+
+spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_in,
+                            uint64_t* d_out)
+{
+    if (!c->ksk_ready) return fail(c, SPF_ERR_NO_KEY, "keyswitch key not loaded");
+    if (B == 0) return SPF_OK;
+    KeyswitchArgs a{};
+    a.in = d_in; a.ksk = c->d_ksk; a.out = d_out;
+    a.n_in = c->prm.glwe_size * c->prm.polynomial_degree; a.n_out = c->prm.lwe_dimension;
+    a.B = (uint32_t)B; a.radix_log = c->prm.ks_radix_log; a.count = c->prm.ks_radix_count;
+    dim3 grid((a.n_out + 1 + 255) / 256, (unsigned)((B + KS_CT - 1) / KS_CT)), block(256);
+    TimedLaunch tl{};
+    if (c->timing) {
+        spf_status st = get_events(c, &tl.start, &tl.stop);
+        if (st != SPF_OK) return st;
+        HIPCHK(c, hipEventRecord(tl.start, s));
+    }
+    hipLaunchKernelGGL(keyswitch_kernel, grid, block, 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(tl.stop, s));
+        c->t_ks.push_back(tl);
+    }
+    return SPF_OK;
+}
+
+bool params_supported(const spf_params& p, std::string& why)
+{
+    if (p.polynomial_degree != kN) { why = "kernels are built for polynomial_degree 2048"; return false; }
+    if (p.glwe_size != 1) { why = "kernels are built for glwe_size 1"; return false; }
+    if (p.pbs_radix_log != 16 || p.pbs_radix_count != 2) { why = "blind rotation is built for pbs_radix 2 x 16 bits"; return false; }
+    if (p.lwe_dimension == 0 || p.lwe_dimension > 4096) { why = "lwe_dimension out of range"; return false; }
+    if (p.ks_radix_log == 0 || p.ks_radix_log * p.ks_radix_count > 32) { why = "ks_radix must satisfy 0 < l*logB <= 32"; return false; }
+    if (p.cbs_radix_count == 0 || p.cbs_radix_count >= 8 || p.cbs_radix_log == 0) { why = "cbs_radix.count must be in 1..7"; return false; }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+void spf_default_params(spf_params* o)
+{
+    if (!o) return;
+    *o = spf_params{637, 2048, 1, 16, 2, 4, 4, 2, 6};
+}
+
+const char* spf_version(void) { return "spf_hip 0.1 (gfx950, wave-per-ciphertext blind rotation)"; }
+
+const char* spf_last_error(const spf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
+{
+    if (!params || !out) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    std::string why;
+    if (!params_supported(*params, why)) return fail(nullptr, SPF_ERR_UNSUPPORTED, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SPF_ERR_HIP, "no HIP device visible: the HIP path is the only path, there is no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "device_id out of range");
+    spf_ctx* c = new (std::nothrow) spf_ctx();
+    if (!c) return fail(nullptr, SPF_ERR_HIP, "out of host memory");
+    c->prm = *params;
+    c->device = device_id;
+    auto bail = [&](spf_status s) { g_create_error = c->err; spf_destroy(c); return s; };
+#define CK(expr)                                                                                  \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+            return bail(SPF_ERR_HIP);                                                             \
+        }                                                                                         \
+    } while (0)
+    CK(hipSetDevice(device_id));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    std::vector<c64> t;
+    build_tables(t);
+    CK(hipMalloc((void**)&c->d_tables, kTableBytes));
+    CK(hipMemcpy(c->d_tables, t.data(), kTableBytes, hipMemcpyHostToDevice));
+    // fill_multifunctional_cbs_decomposition_lut (circuit_bootstrapping.rs:430-482)
+    {
+        std::vector<uint64_t> lut(glwe_words(*params), 0);
+        uint64_t levels[16] = {0};
+        for (uint32_t i = 0; i < 16; i++) {
+            uint32_t lvl = i + 1;
+            if (lvl * params->cbs_radix_log + 1 < 64) {
+                uint32_t bits = params->cbs_radix_log * lvl + 1;
+                uint64_t minus_one = ((uint64_t)1 << bits) - 1;
+                levels[i] = minus_one << (64 - bits);
+            }
+        }
+        uint32_t v = 1u << ceil_log2(params->cbs_radix_count);
+        uint64_t* b = lut.data() + (size_t)params->glwe_size * params->polynomial_degree;
+        for (uint32_t i = 0; i < params->polynomial_degree; i++) {
+            uint32_t fn = i % v;
+            b[i] = fn < params->cbs_radix_count ? levels[fn] : 0;
+        }
+        CK(hipMalloc((void**)&c->d_cbs_lut, lut.size() * 8));
+        CK(hipMemcpy(c->d_cbs_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice));
+    }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                           kTableBytes + kWavesPerBlock * kWaveBufBytes));
+#undef CK
+    *out = c;
+    return SPF_OK;
+}
+
+void spf_destroy(spf_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& t : c->t_pbs) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto& t : c->t_ks) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_ksk, (void*)c->d_cbs_lut,
+                    c->in.p, c->out.p, c->mid.p, c->aux.p})
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
+{
+    if (!c || !dev_ptr || !bytes) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (which == 0) {
+        size_t need = (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count) * sizeof(c64);
+        if (!c->d_bsk) { HIPCHK(c, hipMalloc((void**)&c->d_bsk, need)); c->bsk_bytes = need; }
+        *dev_ptr = c->d_bsk; *bytes = c->bsk_bytes;
+    } else if (which == 1) {
+        size_t need = (size_t)c->prm.glwe_size * c->prm.polynomial_degree * c->prm.ks_radix_count * lwe0_words(c->prm) * 8;
+        if (!c->d_ksk) { HIPCHK(c, hipMalloc((void**)&c->d_ksk, need)); c->ksk_bytes = need; }
+        *dev_ptr = c->d_ksk; *bytes = c->ksk_bytes;
+    } else {
+        return fail(c, SPF_ERR_INVALID_ARGUMENT, "which must be 0 (bootstrap key) or 1 (keyswitch key)");
+    }
+    return SPF_OK;
+}
+
+spf_status spf_key_blob_commit(spf_ctx* c, int which)
+{
+    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (which == 0 && c->d_bsk) c->bsk_ready = true;
+    else if (which == 1 && c->d_ksk) c->ksk_ready = true;
+    else return fail(c, SPF_ERR_INVALID_ARGUMENT, "blob not allocated");
+    return SPF_OK;
+}
+
+spf_status spf_load_bootstrap_key(spf_ctx* c, const double* bsk_fft, size_t n_complex)
+{
+    if (!c || !bsk_fft) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    size_t want = (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count);
+    if (n_complex != want)
+        return fail(c, SPF_ERR_INVALID_ARGUMENT, "bootstrap key length " + std::to_string(n_complex) + " != " + std::to_string(want));
+    void* p; size_t bytes;
+    spf_status s = spf_key_blob(c, 0, &p, &bytes);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpy(p, bsk_fft, bytes, hipMemcpyHostToDevice));
+    c->bsk_ready = true;
+    return SPF_OK;
+}
+
+spf_status spf_load_keyswitch_key(spf_ctx* c, const uint64_t* ksk, size_t n_words)
+{
+    if (!c || !ksk) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    size_t want = (size_t)c->prm.glwe_size * c->prm.polynomial_degree * c->prm.ks_radix_count * lwe0_words(c->prm);
+    if (n_words != want)
+        return fail(c, SPF_ERR_INVALID_ARGUMENT, "keyswitch key length " + std::to_string(n_words) + " != " + std::to_string(want));
+    void* p; size_t bytes;
+    spf_status s = spf_key_blob(c, 1, &p, &bytes);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpy(p, ksk, bytes, hipMemcpyHostToDevice));
+    c->ksk_ready = true;
+    return SPF_OK;
+}
+
+// ---------------------------------------------------------------- device-pointer forms
+
+spf_status spf_keyswitch_lwe_l1_lwe_l0_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_in, uint64_t* d_out)
+{
+    if (!c || (B && (!d_in || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_keyswitch(c, (hipStream_t)stream, B, d_in, d_out);
+}
+
+spf_status spf_generalized_pbs_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, const uint64_t* d_lut,
+                                   size_t lut_stride, uint32_t log_chi, uint32_t log_v, uint64_t body_rotate,
+                                   uint64_t* d_out)
+{
+    if (!c || (B && (!d_lwe || !d_lut || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, d_lut, lut_stride, log_chi, log_v, body_rotate, d_out,
+                               glwe_words(c->prm), false);
+}
+
+spf_status spf_pbs_univariate_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, const uint64_t* d_lut,
+                                  size_t lut_stride, uint64_t* d_out)
+{
+    if (!c || (B && (!d_lwe || !d_lut || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, d_lut, lut_stride, 0, 0, 0, d_out, lwe1_words(c->prm), true);
+}
+
+spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, uint64_t* d_out)
+{
+    if (!c || (B && (!d_lwe || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    // hi_noise_lwe_to_lo_noise_glwe (circuit_bootstrapping.rs:387-427)
+    return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count),
+                               (uint64_t)1 << 62, d_out, glwe_words(c->prm), false);
+}
+
+spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, size_t idx, uint64_t* d_out)
+{
+    if (!c || (B && (!d_glwe || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (idx >= c->prm.polynomial_degree) return fail(c, SPF_ERR_INVALID_ARGUMENT, "sample_extract index >= polynomial_degree");
+    if (B == 0) return SPF_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    dim3 grid((kN + 1 + 255) / 256, (unsigned)B), block(256);
+    hipLaunchKernelGGL(sample_extract_kernel, grid, block, 0, (hipStream_t)stream, d_glwe, d_out, (uint32_t)B, (uint32_t)idx);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
+spf_status spf_cmux_dev(spf_ctx* c, void*, size_t, const double*, const uint64_t*, const uint64_t*, uint64_t*)
+{
+    return fail(c, SPF_ERR_UNSUPPORTED, "cmux (cbs_radix GGSW) is not built yet");
+}
+
+// ---------------------------------------------------------------- host-pointer forms
+
+#define STAGE_IN(buf, host, bytes)                                                                \
+    do {                                                                                          \
+        spf_status s_ = ensure(c, buf, bytes);                                                    \
+        if (s_ != SPF_OK) return s_;                                                              \
+        HIPCHK(c, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, c->stream));          \
+    } while (0)
+
+spf_status spf_keyswitch_lwe_l1_lwe_l0_batch(spf_ctx* c, size_t B, const uint64_t* in, uint64_t* out)
+{
+    if (!c || (B && (!in || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    STAGE_IN(c->in, in, B * lwe1_words(c->prm) * 8);
+    spf_status s = ensure(c, c->out, B * lwe0_words(c->prm) * 8);
+    if (s != SPF_OK) return s;
+    s = launch_keyswitch(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * lwe0_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+static spf_status pbs_host(spf_ctx* c, size_t B, const uint64_t* lwe, const uint64_t* lut, size_t lut_stride,
+                           uint32_t log_chi, uint32_t log_v, uint64_t rot, uint64_t* out, bool extract)
+{
+    if (!c || (B && (!lwe || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    STAGE_IN(c->in, lwe, B * lwe0_words(c->prm) * 8);
+    const uint64_t* d_lut = c->d_cbs_lut;
+    if (lut) {
+        size_t luts = lut_stride ? B : 1;
+        if (lut_stride && lut_stride < glwe_words(c->prm)) return fail(c, SPF_ERR_INVALID_ARGUMENT, "lut_stride smaller than a GLWE");
+        size_t words = lut_stride ? (luts - 1) * lut_stride + glwe_words(c->prm) : glwe_words(c->prm);
+        STAGE_IN(c->aux, lut, words * 8);
+        d_lut = (const uint64_t*)c->aux.p;
+    }
+    size_t ow = extract ? lwe1_words(c->prm) : glwe_words(c->prm);
+    spf_status s = ensure(c, c->out, B * ow * 8);
+    if (s != SPF_OK) return s;
+    s = launch_blind_rotate(c, c->stream, B, (const uint64_t*)c->in.p, d_lut, lut ? lut_stride : 0, log_chi, log_v, rot,
+                            (uint64_t*)c->out.p, ow, extract);
+    if (s != SPF_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * ow * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_generalized_pbs_batch(spf_ctx* c, size_t B, const uint64_t* lwe, const uint64_t* lut, size_t lut_stride,
+                                     uint32_t log_chi, uint32_t log_v, uint64_t body_rotate, uint64_t* out)
+{
+    if (B && !lut) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null lut");
+    return pbs_host(c, B, lwe, lut, lut_stride, log_chi, log_v, body_rotate, out, false);
+}
+
+spf_status spf_pbs_univariate_batch(spf_ctx* c, size_t B, const uint64_t* lwe, const uint64_t* lut, size_t lut_stride,
+                                    uint64_t* out)
+{
+    if (B && !lut) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null lut");
+    return pbs_host(c, B, lwe, lut, lut_stride, 0, 0, 0, out, true);
+}
+
+spf_status spf_circuit_bootstrap_pbs_batch(spf_ctx* c, size_t B, const uint64_t* lwe, uint64_t* out)
+{
+    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    return pbs_host(c, B, lwe, nullptr, 0, 0, ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62, out, false);
+}
+
+spf_status spf_sample_extract_l1_batch(spf_ctx* c, size_t B, const uint64_t* glwe, size_t idx, uint64_t* out)
+{
+    if (!c || (B && (!glwe || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (idx >= c->prm.polynomial_degree) return fail(c, SPF_ERR_INVALID_ARGUMENT, "sample_extract index >= polynomial_degree");
+    if (B == 0) return SPF_OK;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->in, glwe, B * glwe_words(c->prm) * 8);
+        spf_status s = ensure(c, c->out, B * lwe1_words(c->prm) * 8);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_sample_extract_l1_dev(c, c->stream, B, (const uint64_t*)c->in.p, idx, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * lwe1_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_cmux_batch(spf_ctx* c, size_t, const double*, const uint64_t*, const uint64_t*, uint64_t*)
+{
+    return fail(c, SPF_ERR_UNSUPPORTED, "cmux (cbs_radix GGSW) is not built yet");
+}
+
+spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, uint64_t* glwe_out)
+{
+    if (!c || (B && (!lwe1 || !glwe_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    STAGE_IN(c->in, lwe1, B * lwe1_words(c->prm) * 8);
+    spf_status s = ensure(c, c->mid, B * lwe0_words(c->prm) * 8);
+    if (s != SPF_OK) return s;
+    s = ensure(c, c->out, B * glwe_words(c->prm) * 8);
+    if (s != SPF_OK) return s;
+    s = launch_keyswitch(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->mid.p);
+    if (s != SPF_OK) return s;
+    s = launch_blind_rotate(c, c->stream, B, (const uint64_t*)c->mid.p, c->d_cbs_lut, 0, 0,
+                            ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62, (uint64_t*)c->out.p,
+                            glwe_words(c->prm), false);
+    if (s != SPF_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(glwe_out, c->out.p, B * glwe_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+// ---------------------------------------------------------------- measurement hooks
+
+spf_status spf_set_timing(spf_ctx* c, int enabled)
+{
+    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->timing = enabled != 0;
+    return SPF_OK;
+}
+
+spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, int* launches)
+{
+    if (!c || !kernel || !avg_ms || !launches) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<TimedLaunch>* v = nullptr;
+    if (!strcmp(kernel, "pbs")) v = &c->t_pbs;
+    else if (!strcmp(kernel, "keyswitch")) v = &c->t_ks;
+    else return fail(c, SPF_ERR_INVALID_ARGUMENT, "kernel must be \"pbs\" or \"keyswitch\"");
+    double total = 0.0;
+    int n = 0;
+    for (auto& t : *v) {
+        HIPCHK(c, hipEventSynchronize(t.stop));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, t.start, t.stop));
+        total += ms; n++;
+        (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop);
+    }
+    v->clear();
+    *avg_ms = n ? total / n : 0.0;
+    *launches = n;
+    return SPF_OK;
+}
+
+} // extern "C"

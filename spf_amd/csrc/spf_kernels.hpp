@@ -1,0 +1,321 @@
+// spf_kernels.hpp — gfx950 kernels of the bootstrap path.
+//
+// blind_rotate_kernel: ONE WAVEFRONT PER CIPHERTEXT.  The wave keeps the GLWE accumulator
+// (2 x 2048 u64) and the frequency-domain external-product accumulator (2 x 1024 c64) in its
+// registers for all n CMUX steps; LDS is used only as a 16 KiB per-wave tile for the negacyclic
+// rotation gather and the in-wave FFT exchanges.  There is no workgroup barrier inside the
+// loop: the four waves of a workgroup (four ciphertexts) only share the 32 KiB twiddle image.
+// The bootstrapping key is read in the reference's own layout (natural DFT bin order):
+// lane l touches bins l + 64 r, so every key load is a fully coalesced 1 KiB wave access, and
+// all workgroups walk the key in the same order, so it is served from L2 / Infinity Cache.
+//
+// Reference path reproduced (sunscreen_tfhe/src):
+//   ops/bootstrapping/programmable_bootstrapping.rs:342-410  generalized_programmable_bootstrap
+//   ops/fft_ops.rs:149-181 cmux, :23-56 glwe_ggsw_mad, :67-98 decomposed_polynomial_glev_mad
+//   math/radix.rs:157-162 round, math/simd/scalar.rs:52-71 vector_next_decomp
+//   entities/polynomial.rs:171-236 monomial rotation, :257-274 fft
+//   entities/polynomial_fft.rs:82-99 ifft, math/simd/scalar.rs:12-35,75-119
+#pragma once
+#include "spf_device.hpp"
+
+namespace spf {
+
+constexpr int kN = 2048;      // polynomial degree the kernels are built for
+constexpr int kHalf = 1024;   // complex bins per polynomial
+constexpr int kWavesPerBlock = 4;
+
+struct BlindRotateArgs {
+    const uint64_t* lwe_in;   // B x (n+1)
+    const uint64_t* lut;      // (k+1)*N words, or B of them
+    size_t lut_stride;        // 0 = shared
+    const c64* bsk;           // [n][2][L][2][1024]
+    const c64* tables;        // kTableEntries
+    uint64_t* out;            // B x out_stride
+    size_t out_stride;
+    uint32_t n;               // LWE dimension
+    uint32_t B;
+    uint32_t log_chi, log_v;
+    uint64_t body_rotate;
+    uint32_t sample_extract;  // 0: write GLWE (2N words), 1: write LWE (N+1 words), index 0
+};
+
+// modulus_switch (ops/ciphertext/lwe_ciphertext_ops.rs:130-142) to 2N = 4096
+__device__ __forceinline__ uint32_t mod_switch_2n(uint64_t x, uint32_t log_chi, uint32_t log_v)
+{
+    const uint32_t log_modulus = 12;
+    x = x << log_chi;
+    uint32_t shift = 64 - (log_modulus - log_v);
+    uint64_t round = (x >> (shift - 1)) & 1;
+    x = x >> shift;
+    return (uint32_t)(((x + round) & ((1u << log_modulus) - 1)) << log_v);
+}
+
+// Lane-private element e in [0,32) of a polynomial <-> coefficient index.
+//   e = half*16 + n1*2 + par ;  coefficient c = half*1024 + 128*n1 + 2*lane + par
+// i.e. complex sample (2*(64*n1+lane) + par) = (coef c, coef c + 1024), the layout the
+// parity-split FFT-512 pair of DAG-I wants (lane = n' mod 64, register = n' div 64).
+__device__ __forceinline__ int coef_of(int e, int lane)
+{
+    return (e >> 4) * 1024 + ((e >> 1) & 7) * 128 + 2 * lane + (e & 1);
+}
+
+// de-interleaved staging position of coefficient c inside the 16 KiB tile (u64 index)
+__device__ __forceinline__ int stage_pos(int c) { return ((c & 1) << 10) | (c >> 1); }
+
+template <int L, int LOGB> // gadget: L digits of LOGB bits, L*LOGB <= 32
+__global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
+{
+    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    char* wbuf = smem + kTableBytes + wave * kWaveBufBytes;
+
+    // twiddle image -> LDS (the only workgroup-wide step)
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint32_t ct = blockIdx.x * kWavesPerBlock + wave;
+    if (ct >= a.B) return;
+
+    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
+    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
+    uint64_t* stage = reinterpret_cast<uint64_t*>(wbuf);
+
+    // ---- acc = LUT * X^{-b~}  (programmable_bootstrapping.rs:385-390)
+    uint64_t acc[2][32];
+    {
+        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 32; e++) {
+                uint32_t idx = (uint32_t)coef_of(e, lane) + bt; // < 3N
+                uint64_t v = lut[p * kN + (idx & (kN - 1))];
+                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+            }
+    }
+
+    for (uint32_t step = 0; step < a.n; step++) {
+        const uint32_t at = mod_switch_2n(lwe[step], a.log_chi, a.log_v);
+        const c64* bsk_i = a.bsk + (size_t)step * (2 * L * 2 * kHalf);
+
+        // ---- diff = acc * X^{a~} - acc, rounded and decomposed; digits packed LOGB bits each
+        uint32_t dig[2][32];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int e = 0; e < 32; e++) stage[stage_pos(coef_of(e, lane))] = acc[p][e];
+            wave_lds_fence();
+#pragma unroll
+            for (int e = 0; e < 32; e++) {
+                uint32_t idx = (uint32_t)coef_of(e, lane) + 2 * kN - at; // in (0, 3N)
+                uint64_t v = stage[stage_pos((int)(idx & (kN - 1)))];
+                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+                uint64_t diff = rot - acc[p][e];
+                // round (radix.rs:157-162): keep the top L*LOGB bits, add the bit below
+                constexpr int shift = 64 - L * LOGB;
+                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+                // vector_next_decomp (scalar.rs:52-71), all L digits; only the low L*LOGB
+                // bits of the rounded value can reach a digit
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    uint32_t d = s & ((1u << LOGB) - 1);
+                    s >>= LOGB;
+                    s += d >> (LOGB - 1);
+                    packed |= d << (j * LOGB); // digit value = sign-extended d
+                }
+                dig[p][e] = packed;
+            }
+            wave_lds_fence();
+        }
+
+        // ---- external product in the frequency domain (fft_ops.rs:23-124)
+        c64 prod[2][16];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) prod[q][r] = {0.0, 0.0};
+
+#pragma unroll 1
+        for (int m = 0; m < 2 * L; m++) {
+            const int p = m / L;        // GLWE polynomial: a then b (fft_ops.rs:43-55)
+            const int j = m - p * L;    // digit, least significant first
+            // GLEV rows are consumed in reverse (fft_ops.rs:92): digit j <-> level L-1-j
+            const c64* row = bsk_i + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf;
+            const int sh = j * LOGB;
+
+            c64 E[8], O[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    uint32_t wre = p ? dig[1][n1 * 2 + par] : dig[0][n1 * 2 + par];
+                    uint32_t wim = p ? dig[1][16 + n1 * 2 + par] : dig[0][16 + n1 * 2 + par];
+                    int dre = ((int)(wre << (32 - LOGB - sh))) >> (32 - LOGB);
+                    int dim = ((int)(wim << (32 - LOGB - sh))) >> (32 - LOGB);
+                    // PolynomialRef::fft: i64 -> f64, then complex_twist (scalar.rs:19-23)
+                    c64 z = cmul_nf({(double)dre, (double)dim}, tab[kTWOff + par * 512 + 64 * n1 + lane]);
+                    if (par == 0) E[n1] = z; else O[n1] = z;
+                }
+            }
+            fft512_wave<+1>(E, wbuf, tab, lane);
+            fft512_wave<+1>(O, wbuf + 8192, tab, lane);
+            c64 X[16];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                c64 t = cmul_tw<+1>(O[d], tab[kWCOff + lane + 64 * d]);
+                X[d] = cadd(E[d], t);
+                X[d + 8] = csub(E[d], t);
+            }
+            // glwe_polynomial_mad (fft_ops.rs:107-124): prod[q] += row[q] * X, non-fused
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    c64 b = row[q * kHalf + lane + 64 * r];
+                    c64 pr = cmul_nf(b, X[r]);
+                    prod[q][r].re += pr.re;
+                    prod[q][r].im += pr.im;
+                }
+        }
+
+        // ---- back to the torus and acc = prod + acc (fft_ops.rs:176-180)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            c64 E[8], O[8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                E[d] = cadd(prod[q][d], prod[q][d + 8]);
+                c64 dd = csub(prod[q][d], prod[q][d + 8]);
+                O[d] = cmul_tw<-1>(dd, tab[kWCOff + lane + 64 * d]);
+            }
+            fft512_wave<-1>(E, wbuf, tab, lane);
+            fft512_wave<-1>(O, wbuf + 8192, tab, lane);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++)
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    c64 y = par ? O[n1] : E[n1];
+                    // complex_untwist (scalar.rs:26-35): (x * n_inv) * twist_inv, round()
+                    c64 xs = {y.re * (1.0 / 1024.0), y.im * (1.0 / 1024.0)};
+                    c64 t = cmul_nf_conj(xs, tab[kTWOff + par * 512 + 64 * n1 + lane]);
+                    acc[q][n1 * 2 + par] += f64_round_to_torus(t.re);
+                    acc[q][16 + n1 * 2 + par] += f64_round_to_torus(t.im);
+                }
+        }
+    }
+
+    // ---- output
+    if (!a.sample_extract) {
+        uint64_t* out = a.out + (size_t)ct * a.out_stride;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 32; e += 2) {
+                ulonglong2 v2 = {acc[p][e], acc[p][e + 1]};
+                *reinterpret_cast<ulonglong2*>(out + p * kN + coef_of(e, lane)) = v2;
+            }
+    } else {
+        // sample_extract(., 0) (ops/ciphertext/glwe_ciphertext_ops.rs:31-76):
+        // a_lwe[0] = a[0]; a_lwe[j] = -a[N-j] (j >= 1); b_lwe = b[0]
+        uint64_t* out = a.out + (size_t)ct * a.out_stride;
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            int c = coef_of(e, lane);
+            if (c == 0) {
+                out[0] = acc[0][e];
+                out[kN] = acc[1][e];
+            } else {
+                out[kN - c] = (uint64_t)0 - acc[0][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LWE keyswitch L1 -> L0 (ops/keyswitch/lwe_keyswitch.rs:23-62; lev_ciphertext_ops.rs:18-42;
+// lwe_ciphertext_ops.rs:48-66), batched: out[ct] = (0,..,0,b) - sum_i sum_j d_{i,j} KSK[i][l-1-j].
+// A workgroup owns a tile of KS_CT ciphertexts x 256 output columns; each thread owns one
+// column and keeps KS_CT 64-bit accumulators in registers, so every key word fetched (coalesced
+// across the 256 columns) is used KS_CT times.  Digits are wave-uniform, computed on the
+// scalar unit from the input mask word.
+constexpr int KS_CT = 32;
+
+struct KeyswitchArgs {
+    const uint64_t* in;  // B x (n_in+1)
+    const uint64_t* ksk; // [n_in][count][n_out+1]
+    uint64_t* out;       // B x (n_out+1)
+    uint32_t n_in, n_out, B;
+    uint32_t radix_log, count;
+};
+
+__global__ __launch_bounds__(256) void keyswitch_kernel(KeyswitchArgs a)
+{
+    const uint32_t w = a.n_out + 1;
+    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ct0 = blockIdx.y * KS_CT;
+    const bool live = col < w;
+    const uint32_t colc = live ? col : 0;
+    uint64_t sum[KS_CT];
+#pragma unroll
+    for (int t = 0; t < KS_CT; t++) sum[t] = 0;
+
+    const uint32_t shift = 64 - a.radix_log * a.count;
+    const uint32_t mask = (1u << a.radix_log) - 1;
+    for (uint32_t i = 0; i < a.n_in; i++) {
+        const uint64_t* lev = a.ksk + (size_t)i * a.count * w + colc;
+        uint32_t st[KS_CT];
+#pragma unroll
+        for (int t = 0; t < KS_CT; t++) {
+            uint32_t ct = ct0 + t < a.B ? ct0 + t : a.B - 1;
+            uint64_t x = a.in[(size_t)ct * (a.n_in + 1) + i];
+            st[t] = (uint32_t)(x >> shift) + (uint32_t)((x >> (shift - 1)) & 1);
+        }
+        for (uint32_t j = 0; j < a.count; j++) {
+            uint64_t kv = lev[(size_t)(a.count - 1 - j) * w];
+#pragma unroll
+            for (int t = 0; t < KS_CT; t++) {
+                uint32_t d = st[t] & mask;
+                st[t] >>= a.radix_log;
+                uint32_t carry = d >> (a.radix_log - 1);
+                st[t] += carry;
+                int64_t digit = (int64_t)d - ((int64_t)carry << a.radix_log);
+                sum[t] += kv * (uint64_t)digit;
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < KS_CT; t++) {
+        uint32_t ct = ct0 + t;
+        if (ct < a.B) {
+            uint64_t base = (col == a.n_out) ? a.in[(size_t)ct * (a.n_in + 1) + a.n_in] : 0;
+            a.out[(size_t)ct * w + col] = base - sum[t];
+        }
+    }
+}
+
+// sample_extract (ops/ciphertext/glwe_ciphertext_ops.rs:31-76), k = 1, batched
+__global__ void sample_extract_kernel(const uint64_t* glwe, uint64_t* lwe, uint32_t B, uint32_t h)
+{
+    const uint32_t ct = blockIdx.y;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= B || j > kN) return;
+    const uint64_t* g = glwe + (size_t)ct * 2 * kN;
+    uint64_t* o = lwe + (size_t)ct * (kN + 1);
+    if (j == kN) o[kN] = g[kN + h];
+    else if (j <= h) o[j] = g[h - j];
+    else o[j] = (uint64_t)0 - g[h + kN - j];
+}
+
+// lwe_rotate (ops/homomorphisms/lwe.rs:9-20) is folded into blind_rotate_kernel's body_rotate.
+
+} // namespace spf

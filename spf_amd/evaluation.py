@@ -1,0 +1,73 @@
+"""Host-side mirror of ``parasol_runtime::Evaluation`` / ``KeylessEvaluation``
+(parasol_runtime/src/crypto/evaluation.rs:26-266) for the bootstrap path.
+
+Method names, argument order and meaning follow the reference: the caller allocates ``output``
+and the method writes into it (the reference takes ``&mut`` outputs and returns nothing).
+Inputs may be single ciphertexts (1-D arrays, as the reference's typed newtypes) or batches
+(2-D, leading dimension = batch): the engine underneath is batch-native.  All compute happens in
+the HIP library; nothing here touches ciphertext words.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._ffi import Engine
+from .params import Params, DEFAULT_128
+
+
+@dataclass
+class ComputeKey:
+    """``parasol_runtime::ComputeKey`` (crypto/keys.rs:306-318): the fields this path uses."""
+
+    bs_key: np.ndarray   # BootstrapKeyFft<Complex<f64>>, complex128, reference layout
+    ks_key: np.ndarray   # LweKeyswitchKey<u64>
+
+
+class Evaluation:
+    def __init__(self, compute_key: ComputeKey, params: Params = DEFAULT_128, device: int = 0):
+        # Evaluation::new (evaluation.rs:161-197) minus the two CBS runs that precompute
+        # l1ggsw_zero/one, which need the trace / scheme-switch tail.
+        self.params = params
+        self.engine = Engine(params, device)
+        self.engine.load_bootstrap_key(compute_key.bs_key)
+        if compute_key.ks_key is not None and np.size(compute_key.ks_key):
+            self.engine.load_keyswitch_key(compute_key.ks_key)
+
+    @staticmethod
+    def _store(output: np.ndarray, result: np.ndarray):
+        if output.dtype != np.uint64:
+            raise TypeError("output must be uint64")
+        output[...] = result.reshape(output.shape)
+
+    # KeylessEvaluation::sample_extract_l1 (evaluation.rs:126-133)
+    def sample_extract_l1(self, output: np.ndarray, input: np.ndarray, idx: int):
+        self._store(output, self.engine.sample_extract_l1(input, idx))
+
+    # Evaluation::keyswitch_lwe_l1_lwe_l0 (evaluation.rs:246-255)
+    def keyswitch_lwe_l1_lwe_l0(self, output: np.ndarray, input: np.ndarray):
+        self._store(output, self.engine.keyswitch_lwe_l1_lwe_l0(input))
+
+    # the bootstrap stage of Evaluation::circuit_bootstrap (evaluation.rs:211-226):
+    # hi_noise_lwe_to_lo_noise_glwe (circuit_bootstrapping.rs:387-427).  Output: L1 GLWE whose
+    # first cbs_radix.count coefficients hold the gadget levels of the input bit.
+    def circuit_bootstrap_pbs(self, output: np.ndarray, input: np.ndarray):
+        self._store(output, self.engine.circuit_bootstrap_pbs(input))
+
+    # sunscreen_tfhe::ops::bootstrapping::programmable_bootstrap_univariate
+    # (programmable_bootstrapping.rs:291-318)
+    def programmable_bootstrap_univariate(self, output: np.ndarray, input: np.ndarray, lut: np.ndarray):
+        self._store(output, self.engine.pbs_univariate(input, lut))
+
+    # generalized_programmable_bootstrap (programmable_bootstrapping.rs:342-410)
+    def generalized_programmable_bootstrap(self, output, input, lut, log_chi: int, log_v: int):
+        self._store(output, self.engine.generalized_pbs(input, lut, log_chi, log_v, 0))
+
+    # KeylessEvaluation::cmux (evaluation.rs:68-83)
+    def cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
+        self._store(output, self.engine.cmux(sel, a, b))
+
+    # FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap fused (circuit_processor/mod.rs:329-340,453-463)
+    def gate_bootstrap(self, output: np.ndarray, input_l1: np.ndarray):
+        self._store(output, self.engine.gate_bootstrap(input_l1))

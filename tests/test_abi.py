@@ -1,0 +1,67 @@
+"""CPU-side checks of the boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/spf_hip.h declares, and refuses to run without a GPU (no silent fallback)."""
+import os
+import re
+
+import pytest
+
+import spf_amd
+from spf_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    spf_amd.build_library()
+    return spf_amd.load_library()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "spf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _ffi.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_default_params_match_reference(lib):
+    p = _ffi._CParams()
+    lib.spf_default_params(p)
+    got = {n: getattr(p, n) for n, _ in _ffi._CParams._fields_}
+    assert got == dict(lwe_dimension=637, polynomial_degree=2048, glwe_size=1, pbs_radix_log=16,
+                       pbs_radix_count=2, cbs_radix_log=4, cbs_radix_count=4, ks_radix_log=2,
+                       ks_radix_count=6)  # parasol_runtime/src/params.rs:107-134
+    assert spf_amd.DEFAULT_128.bsk_complex * 16 == 83_492_864
+    assert spf_amd.DEFAULT_128.ksk_words * 8 == 62_717_952
+
+
+def test_unsupported_params_rejected(lib):
+    import ctypes as C
+    p = _ffi._CParams()
+    lib.spf_default_params(p)
+    p.polynomial_degree = 1024
+    h = C.c_void_p()
+    st = lib.spf_create(p, 0, h)
+    assert st == 4 and not h.value
+    assert b"2048" in lib.spf_last_error(None)
+
+
+def test_no_gpu_means_loud_failure():
+    from tests.util import gpu_available
+    if gpu_available():
+        pytest.skip("GPU present")
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.Engine()
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under spf_amd/ may reference it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "spf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "spf_oracle" not in src, f

@@ -1,0 +1,174 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit, on the
+same seeded inputs.  Integer/byte domain => the bar is exact equality of every output word."""
+import numpy as np
+import pytest
+
+import oracle as O
+import spf_amd
+from tests.util import M64, keyset, random_glwe, random_lwe_batch, to_engine_params
+
+pytestmark = pytest.mark.gpu
+
+SMALL_N = 20
+
+
+@pytest.fixture(scope="module")
+def small():
+    ks = keyset(0x5EED0001, SMALL_N)
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    return ks, eng
+
+
+def test_version_names_gfx950(small):
+    assert "gfx950" in small[1].version
+
+
+@pytest.mark.parametrize("B", [1, 4, 9])
+def test_circuit_bootstrap_pbs_parity(small, B):
+    ks, eng = small
+    lwe = random_lwe_batch(100 + B, B, SMALL_N)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    exp = np.stack([O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params) for i in range(B)])
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("log_chi,log_v,rot", [(0, 0, 0), (0, 2, 1 << 62), (1, 1, 12345), (3, 0, M64)])
+def test_generalized_pbs_parity_per_ct_lut(small, log_chi, log_v, rot):
+    ks, eng = small
+    B = 6
+    lwe = random_lwe_batch(7 + log_v, B, SMALL_N)
+    luts = random_glwe(9, B, ks.params.glwe_len)
+    got = eng.generalized_pbs(lwe, luts, log_chi, log_v, rot)
+    for i in range(B):
+        rotated = lwe[i].copy()
+        rotated[-1] = (int(rotated[-1]) + rot) & M64
+        exp = O.generalized_pbs(rotated, luts[i], ks.bsk_fft, ks.params, log_chi, log_v)
+        assert np.array_equal(got[i], exp), i
+
+
+def test_pbs_univariate_parity_and_decrypt(small):
+    ks, eng = small
+    P = ks.params
+    lut = O.trivial_lut_glwe(O.generate_lut(P.N, [lambda x: (x + 1) % 2], 1), P)
+    msgs = [0, 1, 1, 0, 1]
+    lwe = np.stack([O.encrypt_lwe(O.Rng(300 + i), ks.lwe_sk, O.encode(m, 2), P.lwe_std)
+                    for i, m in enumerate(msgs)])
+    got = eng.pbs_univariate(lwe, lut)
+    for i, m in enumerate(msgs):
+        assert np.array_equal(got[i], O.pbs_univariate(lwe[i], lut, ks.bsk_fft, P))
+        assert O.decode(O.decrypt_lwe_raw(got[i], ks.glwe_sk), 1) == (m + 1) % 2
+
+
+def test_identity_steps_and_extreme_words(small):
+    # a~_i = 0 makes a CMUX step an exact identity; all-ones / top-bit words stress the wraps
+    ks, eng = small
+    B = 4
+    lwe = np.zeros((B, SMALL_N + 1), dtype=np.uint64)
+    lwe[1, :] = M64
+    lwe[2, ::2] = 1 << 63
+    lwe[3, :] = random_lwe_batch(5, 1, SMALL_N)[0]
+    lwe[3, 3:9] = 0
+    got = eng.circuit_bootstrap_pbs(lwe)
+    for i in range(B):
+        assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
+
+
+def test_saturating_cast_quirk_is_reproduced():
+    # vector_mod_pow2_q_f64 + `as i64` map an ifft value of exactly -2^63 to 0x7FFF...F
+    # (simd/scalar.rs:85-118, math/torus.rs:177-192).  Force it: LUT body = 2^62 everywhere,
+    # a~ = N (negation) -> diff = 0x8000.. -> top digit -2^15; key polynomial = constant 2^48.
+    P = O.DEFAULT_128.replace(lwe_n=1)
+    h = P.N // 2
+    bsk = np.zeros((1, 2, 2, 2, h), dtype=np.complex128)   # [i][row][level][poly][bin]
+    const = np.zeros(P.N, dtype=np.uint64)
+    const[0] = 1 << 48
+    bsk[0, 1, 0, 1, :] = O.poly_fft(const)                 # row b, level 0 (<-> top digit), poly b
+    lut = np.zeros(P.glwe_len, dtype=np.uint64)
+    lut[P.N:] = 1 << 62
+    lwe = np.array([[1 << 63, 0]], dtype=np.uint64)
+    exp = O.generalized_pbs(lwe[0], lut, bsk, P)
+    body_delta = (exp[P.N:].astype(object) - (1 << 62)) % (1 << 64)
+    assert sum(1 for v in body_delta if v == (1 << 63) - 1) > 0, "test vector no longer hits the quirk"
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(bsk)
+    got = eng.generalized_pbs(lwe, lut)
+    assert np.array_equal(got[0], exp)
+
+
+@pytest.mark.parametrize("B", [1, 5, 33])
+def test_keyswitch_parity(small, B):
+    ks, eng = small
+    P = ks.params
+    lwe1 = random_lwe_batch(40 + B, B, P.N * P.k)
+    got = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+    for i in range(B):
+        exp = O.keyswitch_lwe(lwe1[i], ks.ksk, P.N * P.k, P.lwe_n, P.ks_radix_log, P.ks_count)
+        assert np.array_equal(got[i], exp), i
+
+
+@pytest.mark.parametrize("idx", [0, 1, 1023, 2047])
+def test_sample_extract_parity(small, idx):
+    ks, eng = small
+    glwe = random_glwe(idx, 3, ks.params.glwe_len)
+    got = eng.sample_extract_l1(glwe, idx)
+    for i in range(3):
+        assert np.array_equal(got[i], O.sample_extract(glwe[i], idx, ks.params.N, ks.params.k))
+
+
+def test_gate_bootstrap_parity_and_decrypt(small):
+    # keyswitch L1->L0 then the circuit-bootstrap PBS, on valid encryptions
+    ks, eng = small
+    P = ks.params
+    bits = [0, 1, 1, 0, 1, 0, 0]
+    lwe1 = np.stack([O.encrypt_lwe(O.Rng(500 + i), ks.glwe_sk, O.encode(b, 1), P.glwe_std)
+                     for i, b in enumerate(bits)])
+    got = eng.gate_bootstrap(lwe1)
+    for i, b in enumerate(bits):
+        l0 = O.keyswitch_lwe(lwe1[i], ks.ksk, P.N * P.k, P.lwe_n, P.ks_radix_log, P.ks_count)
+        assert np.array_equal(got[i], O.cbs_pbs(l0, ks.bsk_fft, P)), i
+        m = O.decrypt_glwe_raw(got[i], ks.glwe_sk, P.N, P.k)
+        for lvl in range(P.cbs_count):
+            mag = 1 << (64 - (P.cbs_radix_log * (lvl + 1) + 1))
+            want = mag if b else (-mag) & M64
+            err = (int(m[lvl]) - want + (1 << 63)) % (1 << 64) - (1 << 63)
+            assert abs(err) < mag // 4
+
+
+def test_empty_batch_and_bad_arguments(small):
+    ks, eng = small
+    assert eng.circuit_bootstrap_pbs(np.zeros((0, SMALL_N + 1), dtype=np.uint64)).shape == (0, ks.params.glwe_len)
+    with pytest.raises(spf_amd.SpfError):
+        eng.sample_extract_l1(np.zeros((1, ks.params.glwe_len), dtype=np.uint64), 2048)  # faults.rs: illegal index
+    eng2 = spf_amd.Engine(to_engine_params(ks.params))
+    with pytest.raises(spf_amd.SpfError):   # key not loaded
+        eng2.circuit_bootstrap_pbs(np.zeros((1, SMALL_N + 1), dtype=np.uint64))
+
+
+def test_evaluation_mirror_writes_outputs(small):
+    ks, _ = small
+    P = ks.params
+    ev = spf_amd.Evaluation(spf_amd.ComputeKey(ks.bsk_fft, ks.ksk), to_engine_params(P))
+    lwe = random_lwe_batch(77, 1, SMALL_N)[0]
+    out = np.zeros(P.glwe_len, dtype=np.uint64)
+    ev.circuit_bootstrap_pbs(out, lwe)
+    assert np.array_equal(out, O.cbs_pbs(lwe, ks.bsk_fft, P))
+    l1 = np.zeros(P.N + 1, dtype=np.uint64)
+    ev.sample_extract_l1(l1, out, 0)
+    assert np.array_equal(l1, O.sample_extract(out, 0, P.N, P.k))
+    l0 = np.zeros(P.lwe_n + 1, dtype=np.uint64)
+    ev.keyswitch_lwe_l1_lwe_l0(l0, l1)
+    assert np.array_equal(l0, O.keyswitch_lwe(l1, ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count))
+
+
+def test_full_parameter_set_parity():
+    # DEFAULT_128 (n = 637): a handful of ciphertexts, every output word equal
+    ks = keyset(0x5EED0001, 637, with_ksk=False)
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    bits = [0, 1, 1, 0, 1, 0]
+    lwe = O.encrypt_bits_l0(0x5EED0100, ks, bits)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    for i, b in enumerate(bits):
+        assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
