@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — programmable bootstraps per second at DEFAULT_128 on N MI355X GPUs.
+
+One "step" = one pass of the hot path (the circuit-bootstrap PBS: modulus switch, LUT rotate,
+637 CMUX steps; sunscreen_tfhe programmable_bootstrapping.rs:342-410 via
+circuit_bootstrapping.rs:387-427) over one batch of `--batch` synthetic ciphertexts per GPU,
+inputs and keys already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
+("Batch of 4096 independent programmable bootstraps, default params, 1xMI355X").
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  Bootstraps are
+independent, so the batch is sharded with no data-path collective (weak scaling: --batch per
+GPU); the only collective is the one-time RCCL broadcast of the evaluation keys from rank 0.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PBS = 263.5e6          # 637 x 413 696 f64 flop
+FP64_PEAK_TFLOPS = 78.6         # MI355X dense FP64 (vector == matrix): 256 CU x 128 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
+
+
+class _DevArray:
+    """zero-copy torch view of a raw device pointer (CUDA array interface)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="ciphertexts per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import spf_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = spf_amd.DEFAULT_128
+    spf_amd.build_library()
+    eng = spf_amd.Engine(P, device=local_rank)
+
+    # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob
+    t_keys0 = time.time()
+    blobs = []
+    for which in (0, 1):
+        ptr, nbytes = eng.key_blob(which)
+        blobs.append(torch.as_tensor(_DevArray(ptr, nbytes), device=dev))
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED0001)
+        # BSK-FFT magnitudes of a real key: DFT of 1024 uniform 64-bit words ~ N(0, (2^63)^2*1024/3)
+        bsk = torch.randn(P.bsk_complex * 2, generator=g, device=dev, dtype=torch.float64) * (2.0 ** 67)
+        blobs[0].copy_(bsk.view(torch.uint8))
+        ksk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (P.ksk_words,), generator=g, device=dev, dtype=torch.int64)
+        blobs[1].copy_(ksk.view(torch.uint8))
+        del bsk, ksk
+    torch.cuda.synchronize()
+    t_bcast0 = time.time()
+    if world > 1:
+        for b in blobs:
+            dist.broadcast(b, src=0)
+        torch.cuda.synchronize()
+    t_bcast = time.time() - t_bcast0
+    eng.key_blob_commit(0)
+    eng.key_blob_commit(1)
+
+    # ---- synthetic ciphertext batch (uniform torus words; throughput is value-independent)
+    B = args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0100 + rank)
+    lwe0 = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.lwe0_words), generator=g, device=dev, dtype=torch.int64)
+    glwe_out = torch.empty((B, P.glwe_words), device=dev, dtype=torch.int64)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.circuit_bootstrap_pbs_dev(stream, B, lwe0.data_ptr(), glwe_out.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = eng.last_kernel_ms("pbs")
+    eng.set_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    gate = None
+    if args.with_keyswitch:
+        lwe1 = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.lwe1_words), generator=g, device=dev, dtype=torch.int64)
+        mid = torch.empty((B, P.lwe0_words), device=dev, dtype=torch.int64)
+
+        def gate_step():
+            eng.keyswitch_dev(stream, B, lwe1.data_ptr(), mid.data_ptr())
+            eng.circuit_bootstrap_pbs_dev(stream, B, mid.data_ptr(), glwe_out.data_ptr())
+
+        gate_step()
+        barrier()
+        eng.set_timing(True)
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            gate_step()
+        barrier()
+        tg = time.perf_counter() - tg
+        ks_ms, _ = eng.last_kernel_ms("keyswitch")
+        eng.last_kernel_ms("pbs")
+        eng.set_timing(False)
+        gate = {"gates_per_s": world * B * args.steps / tg, "keyswitch_kernel_ms": ks_ms}
+        # leave glwe_out holding the plain-PBS result for the parity sample below
+        step()
+        torch.cuda.synchronize()
+
+    total_units = world * B * args.steps
+    value = total_units / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (blind_rotate_kernel), per launch
+    per_launch_s = kernel_ms * 1e-3 if launches else float("nan")
+    achieved_tflops = FLOP_PER_PBS * B / per_launch_s / 1e12
+    alg_bytes = P.bsk_complex * 16 + B * (P.lwe0_words * 8 + P.glwe_words * 8)
+    roofline = {
+        "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel": "blind_rotate_kernel<2,16>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
+        "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
+        "note": "f64 work runs on the VALU (v_fma_f64); MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and "
+                "MFMA alike, so the MFMA-f64 peak is the compute roof",
+        "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": round(alg_bytes / per_launch_s / 1e9, 2),
+                "peak_GBs": HBM_PEAK_GBS},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the sunscreen_tfhe algorithm), rank 0 at N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle as O
+        cores = os.cpu_count() or 1
+        threads = max(1, min(cores, 64))
+        OP = O.DEFAULT_128
+        bsk_host = blobs[0].cpu().numpy().view(np.complex128)
+        # calibrate on one bootstrap, then size the sample for ~cpu_seconds of wall time
+        lwe_host = lwe0[: threads * 64].cpu().numpy().view(np.uint64)
+        t1, _ = O.bench_cbs_pbs(lwe_host[:1], bsk_host, OP, 1)
+        per_thread = max(1, int(args.cpu_seconds / max(t1, 1e-3)))
+        count = min(lwe_host.shape[0], threads * per_thread)
+        secs, out = O.bench_cbs_pbs(lwe_host[:count], bsk_host, OP, threads)
+        gpu_sample = glwe_out[:count].cpu().numpy().view(np.uint64)
+        cpu = {"value": round(count / secs, 3), "unit": "PBS/s", "cores": threads, "kind": "port",
+               "sample": f"{count} of the {B} bench ciphertexts, one bootstrap per thread on {threads} host threads "
+                         f"(oracle/spf_oracle.c, gcc -O3 -march=native, {secs:.1f} s)",
+               "single_thread_ms_per_pbs": round(t1 * 1e3, 1),
+               "gpu_outputs_bit_equal_on_sample": bool(np.array_equal(out, gpu_sample))}
+
+    if rank == 0:
+        line = {
+            "metric": "programmable bootstraps/sec (CMUX gates/sec) at default 128-bit params",
+            "value": round(value, 2), "unit": "PBS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch of {B} independent circuit-bootstrap PBS per GPU, DEFAULT_128 "
+                                   "(n=637, N=2048, k=1, pbs_radix 2x16), keys resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"batch-sharded x{world}, keys replicated by RCCL broadcast"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "key_broadcast_s": round(t_bcast, 4) if world > 1 else None,
+            "setup_s": round(t_bcast0 - t_keys0, 2),
+        }
+        if gate:
+            line["gate"] = gate
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
