@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profile bench.py on the GPU box: kernel trace + PMC passes (each its own run).
+# usage: bash scripts_profile.sh <tag> [batch]
+set -o pipefail
+TAG=${1:-r01}
+BATCH=${2:-4096}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
+echo "pmc1 rc=$?"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
+echo "pmc2 rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
+echo "pmc3 rc=$?"
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
+echo "pmc4 rc=$?"
+find $OUT -name "*.csv" | head -40

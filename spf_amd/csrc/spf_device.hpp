@@ -125,10 +125,15 @@ __device__ __forceinline__ void wave_lds_fence()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
+// compiler-only ordering point (no instruction): LDS reads that precede it in program order
+// stay ahead of the LDS writes that follow it.  The hardware needs nothing here: a wave's DS
+// instructions execute in order and all 64 lanes retire an instruction together.
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 
-// 512-point DFT, DIF 8x8x8, held by one wave: lane l, register j holds element 64*j + l on
-// entry (time order) and on exit (frequency order).  `buf` is this FFT's private 8 KiB LDS
-// tile, `tab` the table image.
+// Two independent 512-point DFTs (the even / odd sample halves of one 1024-point transform),
+// DIF 8x8x8, held by one wave and advanced in lockstep so that one transform's LDS round trip
+// hides under the other's butterflies.  For each: lane l, register j holds element 64*j + l on
+// entry (time order) and on exit (frequency order).  bufE / bufO are private 8 KiB LDS tiles.
 //   n' = 64*n1 + n0, n0 = 8a + b;   k' = k1 + 8c + 64d
 //   pass 1: radix-8 over n1 -> k1, * W512^{n0 k1} (k1 != 0)     lanes (a,b)  regs k1
 //   exchange 1                                                  lanes (b,k1) regs a
@@ -137,40 +142,67 @@ __device__ __forceinline__ void wave_lds_fence()
 //   pass 3: radix-8 over b -> d                                 lanes (c,k1) regs d
 // Exchange images (16-byte slots): slot(x, y, z) = 64 x + 8 z + (y ^ z) with (x,y,z) =
 // (a,b,k1) resp. (b,c,k1): writes hit 8 distinct slots mod 8 per 8-lane group and reads 16
-// distinct slots mod 16 per ds_read_b128 lane group — conflict-free both ways.
+// distinct slots mod 16 per ds_read_b128 lane group — conflict-free both ways (measured:
+// SQ_LDS_BANK_CONFLICT = 0).
 template <int DIR>
-__device__ __forceinline__ void fft512_wave(c64 (&v)[8], char* buf, const c64* tab, int lane)
+__device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE, char* bufO,
+                                            const c64* tab, int lane)
 {
     const int hi3 = lane >> 3, lo3 = lane & 7;
-    // pass 1
-    radix8<DIR>(v);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul_tw<DIR>(v[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
-    // exchange 1: writer lane = 8a + b holds reg k1 -> slot 64a + 8k1 + (b ^ k1)
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++)
-        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = v[k1];
-    wave_lds_fence();
-    // reader lane = 8b + k1 wants reg a <- slot 64a + 8k1 + (b ^ k1)
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
+    // pass 1 + exchange-1 writes: writer lane = 8a + b holds reg k1 -> slot 64a + 8k1 + (b ^ k1)
+    {
+        c64 tw[7];
 #pragma unroll
-    for (int a = 0; a < 8; a++) v[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
-    // pass 2
-    radix8<DIR>(v);
+        for (int k1 = 1; k1 < 8; k1++) tw[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
+        radix8<DIR>(E);
 #pragma unroll
-    for (int c = 1; c < 8; c++) v[c] = cmul_tw<DIR>(v[c], tab[kT2Off + (c - 1) * 8 + hi3]);
-    wave_lds_fence(); // all lanes' exchange-1 reads retired before the tile is overwritten
-    // exchange 2: writer lane = 8b + k1 holds reg c -> slot 64b + 8k1 + (c ^ k1)
+        for (int k1 = 1; k1 < 8; k1++) E[k1] = cmul_tw<DIR>(E[k1], tw[k1 - 1]);
 #pragma unroll
-    for (int c = 0; c < 8; c++)
-        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = v[c];
+        for (int k1 = 0; k1 < 8; k1++)
+            *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = E[k1];
+        radix8<DIR>(O);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; k1++) O[k1] = cmul_tw<DIR>(O[k1], tw[k1 - 1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++)
+            *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = O[k1];
+    }
     wave_lds_fence();
-    // reader lane = 8c + k1 wants reg b <- slot 64b + 8k1 + (c ^ k1)
+    // exchange-1 reads: reader lane = 8b + k1 wants reg a <- slot 64a + 8k1 + (b ^ k1)
 #pragma unroll
-    for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
+    for (int a = 0; a < 8; a++) E[a] = *reinterpret_cast<const c64*>(bufE + 1024 * a + rd);
+#pragma unroll
+    for (int a = 0; a < 8; a++) O[a] = *reinterpret_cast<const c64*>(bufO + 1024 * a + rd);
+    // pass 2 + exchange-2 writes: writer lane = 8b + k1 holds reg c -> slot 64b + 8k1 + (c ^ k1)
+    {
+        c64 tw[7];
+#pragma unroll
+        for (int c = 1; c < 8; c++) tw[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
+        compiler_fence();
+        radix8<DIR>(E);
+#pragma unroll
+        for (int c = 1; c < 8; c++) E[c] = cmul_tw<DIR>(E[c], tw[c - 1]);
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
+        radix8<DIR>(O);
+#pragma unroll
+        for (int c = 1; c < 8; c++) O[c] = cmul_tw<DIR>(O[c], tw[c - 1]);
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
+    }
+    wave_lds_fence();
+    // exchange-2 reads: reader lane = 8c + k1 wants reg b <- slot 64b + 8k1 + (c ^ k1)
+#pragma unroll
+    for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
+#pragma unroll
+    for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
     // pass 3
-    radix8<DIR>(v);
-    wave_lds_fence(); // reads retired before the caller reuses the tile
+    radix8<DIR>(E);
+    radix8<DIR>(O);
+    compiler_fence(); // the tile's next writer stays behind these reads
 }
 
 // round half away from zero, then reduce mod 2^64 into the torus exactly as

@@ -156,7 +156,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
-    const size_t lds = kTableBytes + kWavesPerBlock * kWaveBufBytes;
+    const size_t lds = kBlindRotateLds;
     dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(256);
     TimedLaunch tl{};
     if (c->timing) {
@@ -274,8 +274,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
         CK(hipMemcpy(c->d_cbs_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice));
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                           kTableBytes + kWavesPerBlock * kWaveBufBytes));
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
 #undef CK
     *out = c;
     return SPF_OK;

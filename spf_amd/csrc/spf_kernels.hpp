@@ -62,6 +62,27 @@ __device__ __forceinline__ int coef_of(int e, int lane)
 // de-interleaved staging position of coefficient c inside the 16 KiB tile (u64 index)
 __device__ __forceinline__ int stage_pos(int c) { return ((c & 1) << 10) | (c >> 1); }
 
+// LDS map of blind_rotate_kernel (163 712 of the CU's 163 840 bytes, one workgroup per CU):
+//   [0, 32640)            twiddle image (spf_device.hpp)
+//   [32640, +4 x 16384)   per-wave tile: rotation staging / FFT exchanges
+//   [98176, +2 x 32768)   bootstrapping-key ring: the 32 KiB GLWE-FFT row pair the whole
+//                         workgroup multiplies by next, filled by LDS-DMA (global_load_lds)
+constexpr int kBskSlotBytes = 2 * kHalf * 16; // one (row, level): both output polynomials
+constexpr int kBlindRotateLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 2 * kBskSlotBytes;
+
+// issue this thread's share of the DMA that brings one 32 KiB key slot into LDS: 8 x 16 bytes
+// per lane, each wave-instruction lands 1 KiB contiguously (wave-uniform base + lane*16).
+__device__ __forceinline__ void bsk_slot_dma(const c64* src, char* slot, int tid)
+{
+    const int wave_base = tid & ~63;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + k * 256 + tid),
+            (__attribute__((address_space(3))) void*)(slot + (k * 256 + wave_base) * 16), 16, 0, 0);
+    }
+}
+
 template <int L, int LOGB> // gadget: L digits of LOGB bits, L*LOGB <= 32
 __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
 {
@@ -72,21 +93,35 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     char* wbuf = smem + kTableBytes + wave * kWaveBufBytes;
+    char* bskring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
 
-    // twiddle image -> LDS (the only workgroup-wide step)
+    // twiddle image -> LDS
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
     }
-    __syncthreads();
 
-    const uint32_t ct = blockIdx.x * kWavesPerBlock + wave;
-    if (ct >= a.B) return;
+    // The four waves of a workgroup walk the key in lockstep (one barrier per digit), so a wave
+    // without a ciphertext of its own (ragged last workgroup) shadows the last one and skips
+    // the final store.
+    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + wave;
+    const bool owns_output = ct_raw < a.B;
+    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
 
     const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
     const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
     uint64_t* stage = reinterpret_cast<uint64_t*>(wbuf);
+
+    // key slot for global digit index g = step*2L + m lives at
+    //   bsk[step][p][L-1-j][.][.]  with p = m / L, j = m % L  (GLEV rows consumed in reverse,
+    //   fft_ops.rs:92: digit j, least significant first, pairs with level L-1-j)
+    const uint32_t total_g = a.n * (2 * L);
+    auto slot_src = [&](uint32_t g) -> const c64* {
+        uint32_t step = g / (2 * L), m = g % (2 * L), p = m / L, j = m % L;
+        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf);
+    };
+    bsk_slot_dma(slot_src(0), bskring, tid);
 
     // ---- acc = LUT * X^{-b~}  (programmable_bootstrapping.rs:385-390)
     uint64_t acc[2][32];
@@ -101,10 +136,13 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                 acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
             }
     }
+    __syncthreads(); // twiddle image complete
 
+    uint64_t a_next = lwe[0];
+    uint32_t g = 0;
     for (uint32_t step = 0; step < a.n; step++) {
-        const uint32_t at = mod_switch_2n(lwe[step], a.log_chi, a.log_v);
-        const c64* bsk_i = a.bsk + (size_t)step * (2 * L * 2 * kHalf);
+        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
+        a_next = lwe[step + 1]; // the body word on the last step: harmless, in bounds
 
         // ---- diff = acc * X^{a~} - acc, rounded and decomposed; digits packed LOGB bits each
         uint32_t dig[2][32];
@@ -134,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                 }
                 dig[p][e] = packed;
             }
-            wave_lds_fence();
+            compiler_fence();
         }
 
         // ---- external product in the frequency domain (fft_ops.rs:23-124)
@@ -145,11 +183,9 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
             for (int r = 0; r < 16; r++) prod[q][r] = {0.0, 0.0};
 
 #pragma unroll 1
-        for (int m = 0; m < 2 * L; m++) {
+        for (int m = 0; m < 2 * L; m++, g++) {
             const int p = m / L;        // GLWE polynomial: a then b (fft_ops.rs:43-55)
             const int j = m - p * L;    // digit, least significant first
-            // GLEV rows are consumed in reverse (fft_ops.rs:92): digit j <-> level L-1-j
-            const c64* row = bsk_i + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf;
             const int sh = j * LOGB;
 
             c64 E[8], O[8];
@@ -166,8 +202,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                     if (par == 0) E[n1] = z; else O[n1] = z;
                 }
             }
-            fft512_wave<+1>(E, wbuf, tab, lane);
-            fft512_wave<+1>(O, wbuf + 8192, tab, lane);
+            fft512_pair<+1>(E, O, wbuf, wbuf + 8192, tab, lane);
             c64 X[16];
 #pragma unroll
             for (int d = 0; d < 8; d++) {
@@ -175,6 +210,14 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                 X[d] = cadd(E[d], t);
                 X[d + 8] = csub(E[d], t);
             }
+            // key slot g has been in flight since the previous digit; make it visible to the
+            // whole workgroup, then start the DMA of slot g+1 into the other half of the ring
+            // (every wave is past its reads of that half: they precede this barrier).
+            // (an LDS-DMA is tracked by vmcnt; hipcc does not drain it at a barrier by itself)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (g + 1 < total_g) bsk_slot_dma(slot_src(g + 1), bskring + ((g + 1) & 1) * kBskSlotBytes, tid);
+            const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes);
             // glwe_polynomial_mad (fft_ops.rs:107-124): prod[q] += row[q] * X, non-fused
 #pragma unroll
             for (int q = 0; q < 2; q++)
@@ -197,8 +240,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                 c64 dd = csub(prod[q][d], prod[q][d + 8]);
                 O[d] = cmul_tw<-1>(dd, tab[kWCOff + lane + 64 * d]);
             }
-            fft512_wave<-1>(E, wbuf, tab, lane);
-            fft512_wave<-1>(O, wbuf + 8192, tab, lane);
+            fft512_pair<-1>(E, O, wbuf, wbuf + 8192, tab, lane);
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++)
 #pragma unroll
@@ -214,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
     }
 
     // ---- output
+    if (!owns_output) return;
     if (!a.sample_extract) {
         uint64_t* out = a.out + (size_t)ct * a.out_stride;
 #pragma unroll
