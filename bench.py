@@ -54,6 +54,7 @@ def main() -> int:
     import torch.distributed as dist
 
     import spf_amd
+    from spf_amd.sharding import broadcast_keys, max_over_ranks
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,8 +94,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t_bcast0 = time.time()
     if world > 1:
-        for b in blobs:
-            dist.broadcast(b, src=0)
+        broadcast_keys(blobs, dist, src=0)   # RCCL over xGMI, once
         torch.cuda.synchronize()
     t_bcast = time.time() - t_bcast0
     eng.key_blob_commit(0)
@@ -128,9 +128,7 @@ def main() -> int:
     kernel_ms, launches = eng.last_kernel_ms("pbs")
     eng.set_timing(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(dt, dist, device=dev)
 
     gate = None
     if args.with_keyswitch:

@@ -1,0 +1,104 @@
+// spf_evaluation.hpp — C++ host-side mirror of `parasol_runtime::Evaluation`
+// (parasol_runtime/src/crypto/evaluation.rs:144-266) over the C ABI in spf_hip.h.
+//
+// Same method names, argument order and ownership as the reference: the caller allocates the
+// output and passes it first (`&mut` there, pointer/span here); methods never return data.
+// Where the reference panics (size assertions, `assert_is_valid`) this throws
+// spf::Error — a C++-level convenience; nothing is thrown across the C ABI itself.
+// Every method also has a batch form (leading size_t B): the engine is batch-native and a
+// single ciphertext is simply B = 1.
+#pragma once
+#include "spf_hip.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace spf {
+
+struct Error : std::runtime_error {
+    spf_status status;
+    Error(spf_status s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+// `ComputeKey` (crypto/keys.rs:306-318): borrowed host arrays in the reference layouts.
+struct ComputeKey {
+    const double* bs_key;   // BootstrapKeyFft<Complex<f64>>, interleaved re/im
+    size_t bs_key_complex;
+    const uint64_t* ks_key; // LweKeyswitchKey<u64>
+    size_t ks_key_words;
+};
+
+class Evaluation {
+  public:
+    // Evaluation::new (evaluation.rs:161-197)
+    Evaluation(const ComputeKey& key, const spf_params& params, int device = 0) : params_(params)
+    {
+        check(spf_create(&params, device, &ctx_), nullptr);
+        check(spf_load_bootstrap_key(ctx_, key.bs_key, key.bs_key_complex), ctx_);
+        if (key.ks_key) check(spf_load_keyswitch_key(ctx_, key.ks_key, key.ks_key_words), ctx_);
+    }
+    // Evaluation::with_default_params (evaluation.rs:200-204)
+    static Evaluation with_default_params(const ComputeKey& key, int device = 0)
+    {
+        spf_params p;
+        spf_default_params(&p);
+        return Evaluation(key, p, device);
+    }
+    Evaluation(Evaluation&& o) noexcept : ctx_(o.ctx_), params_(o.params_) { o.ctx_ = nullptr; }
+    Evaluation(const Evaluation&) = delete;
+    Evaluation& operator=(const Evaluation&) = delete;
+    ~Evaluation() { spf_destroy(ctx_); }
+
+    const spf_params& params() const { return params_; }
+    spf_ctx* raw() const { return ctx_; }
+
+    // KeylessEvaluation::sample_extract_l1(&mut L1LweCiphertext, &L1GlweCiphertext, idx) (:126)
+    void sample_extract_l1(uint64_t* output, const uint64_t* input, size_t idx, size_t B = 1)
+    {
+        check(spf_sample_extract_l1_batch(ctx_, B, input, idx, output), ctx_);
+    }
+    // Evaluation::keyswitch_lwe_l1_lwe_l0(&mut L0LweCiphertext, &L1LweCiphertext) (:246)
+    void keyswitch_lwe_l1_lwe_l0(uint64_t* output, const uint64_t* input, size_t B = 1)
+    {
+        check(spf_keyswitch_lwe_l1_lwe_l0_batch(ctx_, B, input, output), ctx_);
+    }
+    // bootstrap stage of Evaluation::circuit_bootstrap (:211) = hi_noise_lwe_to_lo_noise_glwe
+    void circuit_bootstrap_pbs(uint64_t* output_glwe, const uint64_t* input_l0, size_t B = 1)
+    {
+        check(spf_circuit_bootstrap_pbs_batch(ctx_, B, input_l0, output_glwe), ctx_);
+    }
+    // sunscreen_tfhe::ops::bootstrapping::programmable_bootstrap_univariate
+    void programmable_bootstrap_univariate(uint64_t* output_l1, const uint64_t* input_l0,
+                                           const uint64_t* lut_glwe, size_t B = 1, size_t lut_stride = 0)
+    {
+        check(spf_pbs_univariate_batch(ctx_, B, input_l0, lut_glwe, lut_stride, output_l1), ctx_);
+    }
+    // sunscreen_tfhe::ops::bootstrapping::generalized_programmable_bootstrap
+    void generalized_programmable_bootstrap(uint64_t* output_glwe, const uint64_t* input_l0,
+                                            const uint64_t* lut_glwe, uint32_t log_chi, uint32_t log_v,
+                                            size_t B = 1, size_t lut_stride = 0)
+    {
+        check(spf_generalized_pbs_batch(ctx_, B, input_l0, lut_glwe, lut_stride, log_chi, log_v, 0, output_glwe), ctx_);
+    }
+    // KeylessEvaluation::cmux(&mut L1GlweCiphertext, &L1GgswCiphertext, a, b) (:68)
+    void cmux(uint64_t* output, const double* sel_ggsw_fft, const uint64_t* a, const uint64_t* b, size_t B = 1)
+    {
+        check(spf_cmux_batch(ctx_, B, sel_ggsw_fft, a, b, output), ctx_);
+    }
+    // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, fused on device
+    void gate_bootstrap(uint64_t* output_glwe, const uint64_t* input_l1, size_t B = 1)
+    {
+        check(spf_gate_bootstrap_batch(ctx_, B, input_l1, output_glwe), ctx_);
+    }
+
+  private:
+    static void check(spf_status s, const spf_ctx* c)
+    {
+        if (s != SPF_OK) throw Error(s, spf_last_error(c));
+    }
+    spf_ctx* ctx_ = nullptr;
+    spf_params params_;
+};
+
+} // namespace spf
