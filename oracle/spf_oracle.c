@@ -565,13 +565,37 @@ void spfo_poly_ifft(const spfo_c64 *in, size_t N, uint64_t *poly)
     free(f);
 }
 
-/* scalar.rs:12-16 */
+/* complex_mad: c += a * b.  The reference dispatches on the host CPU
+ * (math/simd/x86_64/mod.rs:59-75):
+ *   mode 1 (default) — AVX-512 hosts: inline asm with four FMAs per element
+ *       (math/simd/x86_64/avx512.rs:54-57):
+ *         re(c) = fma(re(a), re(b), re(c));  im(c) = fma(re(a), im(b), im(c));
+ *         re(c) = fma(-im(a), im(b), re(c)); im(c) = fma(im(a), re(b), im(c));
+ *       This is what the reference executes on any AVX-512 server CPU (including the hosts of
+ *       the MI355X boxes), so it is the canonical order of this build.
+ *   mode 0 — scalar / AVX2 hosts: `*c += a * b` with num-complex Mul, nothing fused
+ *       (math/simd/scalar.rs:12-16, x86_64/avx2.rs:10-16). */
+static int g_mad_mode = 1;
+void spfo_set_mad_mode(int mode) { g_mad_mode = mode ? 1 : 0; }
+int spfo_get_mad_mode(void) { return g_mad_mode; }
+
 void spfo_complex_mad(spfo_c64 *c, const spfo_c64 *a, const spfo_c64 *b, size_t len)
 {
-    for (size_t i = 0; i < len; i++) {
-        spfo_c64 p = cmul_nf(a[i], b[i]);
-        c[i].re += p.re;
-        c[i].im += p.im;
+    if (g_mad_mode) {
+        for (size_t i = 0; i < len; i++) {
+            double re = fma(a[i].re, b[i].re, c[i].re);
+            double im = fma(a[i].re, b[i].im, c[i].im);
+            re = fma(-a[i].im, b[i].im, re);
+            im = fma(a[i].im, b[i].re, im);
+            c[i].re = re;
+            c[i].im = im;
+        }
+    } else {
+        for (size_t i = 0; i < len; i++) {
+            spfo_c64 p = cmul_nf(a[i], b[i]);
+            c[i].re += p.re;
+            c[i].im += p.im;
+        }
     }
 }
 

@@ -100,7 +100,10 @@ void spfo_poly_fft(const uint64_t *poly, size_t N, spfo_c64 *out);
 void spfo_poly_ifft(const spfo_c64 *in, size_t N, uint64_t *poly);
 /* scalar.rs:75-119 on one value with log2_q = 64, then `as i64` (saturating) -> u64 */
 uint64_t spfo_f64_to_torus(double v);
-/* scalar.rs:12-16 */
+/* complex_mad, c += a*b.  mode 1 (default): the reference's AVX-512 path, four FMAs
+ * (simd/x86_64/avx512.rs:54-57); mode 0: its scalar/AVX2 path, non-fused (simd/scalar.rs:12-16). */
+void spfo_set_mad_mode(int mode);
+int spfo_get_mad_mode(void);
 void spfo_complex_mad(spfo_c64 *c, const spfo_c64 *a, const spfo_c64 *b, size_t len);
 
 /* the canonical complex FFT-1024 alone (for table / DAG tests); dir = +1 forward, -1 inverse */

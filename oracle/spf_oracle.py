@@ -82,6 +82,8 @@ def _declare(lib):
     f("spfo_poly_ifft", None, P, sz, P)
     f("spfo_f64_to_torus", u64, dbl)
     f("spfo_complex_mad", None, P, P, P, sz)
+    f("spfo_set_mad_mode", None, C.c_int)
+    f("spfo_get_mad_mode", C.c_int)
     f("spfo_fft1024", None, P, P, C.c_int)
     f("spfo_root_of_unity", _C64, u64, u64)
     f("spfo_negacyclic_mul_exact", None, P, P, P, sz)
@@ -285,6 +287,16 @@ def poly_ifft(X) -> np.ndarray:
 
 def f64_to_torus(v: float) -> int:
     return int(_load().spfo_f64_to_torus(float(v)))
+
+
+def set_mad_mode(mode: int):
+    """1 = the reference's AVX-512 complex_mad (four FMAs; default, canonical for this build),
+    0 = its scalar/AVX2 complex_mad (non-fused)."""
+    _load().spfo_set_mad_mode(int(mode))
+
+
+def get_mad_mode() -> int:
+    return int(_load().spfo_get_mad_mode())
 
 
 def complex_mad(c, a, b) -> np.ndarray:

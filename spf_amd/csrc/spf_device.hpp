@@ -224,4 +224,22 @@ __device__ __forceinline__ uint64_t f64_round_to_torus(double x)
     return (uint64_t)r;
 }
 
+// Same result as f64_round_to_torus for an input that is already an integer with |v| >= 2^52
+// (so round() is the identity): the low 64 bits of v in two's complement via two exact
+// floor/fma splits, then the saturating-cast quirk (v mod 2^64 == -2^63 reached from below
+// zero becomes +2^63 and saturates to 0x7FFF...F).
+__device__ __forceinline__ uint64_t f64_bigint_to_torus(double v)
+{
+    const double two32 = 4294967296.0, inv32 = 1.0 / 4294967296.0;
+    double hi = __builtin_floor(v * inv32);
+    double lo = __builtin_fma(hi, -two32, v);   // in [0, 2^32), exact
+    double hi2 = __builtin_floor(hi * inv32);
+    double hil = __builtin_fma(hi2, -two32, hi); // in [0, 2^32), exact
+    uint32_t ulo = (uint32_t)lo, uhi = (uint32_t)hil;
+    bool quirk = (v < 0.0) && (ulo == 0u) && (uhi == 0x80000000u);
+    uhi = quirk ? 0x7FFFFFFFu : uhi;
+    ulo = quirk ? 0xFFFFFFFFu : ulo;
+    return ((uint64_t)uhi << 32) | ulo;
+}
+
 } // namespace spf

@@ -144,10 +144,18 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1]; // the body word on the last step: harmless, in bounds
 
-        // ---- diff = acc * X^{a~} - acc, rounded and decomposed; digits packed LOGB bits each
-        uint32_t dig[2][32];
+        // ---- external product in the frequency domain (fft_ops.rs:23-124)
+        c64 prod[2][16];
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) prod[q][r] = {0.0, 0.0};
+
+#pragma unroll
+        for (int p = 0; p < 2; p++) { // GLWE polynomial: a then b (fft_ops.rs:43-55)
+            // ---- diff_p = (acc * X^{a~} - acc)_p, rounded and decomposed; the L digits of a
+            // coefficient are packed LOGB bits each into one register
+            uint32_t dig[32];
 #pragma unroll
             for (int e = 0; e < 32; e++) stage[stage_pos(coef_of(e, lane))] = acc[p][e];
             wave_lds_fence();
@@ -170,64 +178,56 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                     s += d >> (LOGB - 1);
                     packed |= d << (j * LOGB); // digit value = sign-extended d
                 }
-                dig[p][e] = packed;
+                dig[e] = packed;
             }
             compiler_fence();
-        }
-
-        // ---- external product in the frequency domain (fft_ops.rs:23-124)
-        c64 prod[2][16];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) prod[q][r] = {0.0, 0.0};
 
 #pragma unroll 1
-        for (int m = 0; m < 2 * L; m++, g++) {
-            const int p = m / L;        // GLWE polynomial: a then b (fft_ops.rs:43-55)
-            const int j = m - p * L;    // digit, least significant first
-            const int sh = j * LOGB;
-
-            c64 E[8], O[8];
+            for (int j = 0; j < L; j++, g++) { // digit, least significant first
+                const int sh = j * LOGB;
+                c64 E[8], O[8];
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
+                for (int n1 = 0; n1 < 8; n1++) {
 #pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    uint32_t wre = p ? dig[1][n1 * 2 + par] : dig[0][n1 * 2 + par];
-                    uint32_t wim = p ? dig[1][16 + n1 * 2 + par] : dig[0][16 + n1 * 2 + par];
-                    int dre = ((int)(wre << (32 - LOGB - sh))) >> (32 - LOGB);
-                    int dim = ((int)(wim << (32 - LOGB - sh))) >> (32 - LOGB);
-                    // PolynomialRef::fft: i64 -> f64, then complex_twist (scalar.rs:19-23)
-                    c64 z = cmul_nf({(double)dre, (double)dim}, tab[kTWOff + par * 512 + 64 * n1 + lane]);
-                    if (par == 0) E[n1] = z; else O[n1] = z;
+                    for (int par = 0; par < 2; par++) {
+                        int dre = ((int)(dig[n1 * 2 + par] << (32 - LOGB - sh))) >> (32 - LOGB);
+                        int dim = ((int)(dig[16 + n1 * 2 + par] << (32 - LOGB - sh))) >> (32 - LOGB);
+                        // PolynomialRef::fft: i64 -> f64, then complex_twist (scalar.rs:19-23)
+                        c64 z = cmul_nf({(double)dre, (double)dim}, tab[kTWOff + par * 512 + 64 * n1 + lane]);
+                        if (par == 0) E[n1] = z; else O[n1] = z;
+                    }
                 }
-            }
-            fft512_pair<+1>(E, O, wbuf, wbuf + 8192, tab, lane);
-            c64 X[16];
+                fft512_pair<+1>(E, O, wbuf, wbuf + 8192, tab, lane);
+                c64 X[16];
 #pragma unroll
-            for (int d = 0; d < 8; d++) {
-                c64 t = cmul_tw<+1>(O[d], tab[kWCOff + lane + 64 * d]);
-                X[d] = cadd(E[d], t);
-                X[d + 8] = csub(E[d], t);
-            }
-            // key slot g has been in flight since the previous digit; make it visible to the
-            // whole workgroup, then start the DMA of slot g+1 into the other half of the ring
-            // (every wave is past its reads of that half: they precede this barrier).
-            // (an LDS-DMA is tracked by vmcnt; hipcc does not drain it at a barrier by itself)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (g + 1 < total_g) bsk_slot_dma(slot_src(g + 1), bskring + ((g + 1) & 1) * kBskSlotBytes, tid);
-            const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes);
-            // glwe_polynomial_mad (fft_ops.rs:107-124): prod[q] += row[q] * X, non-fused
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    c64 b = row[q * kHalf + lane + 64 * r];
-                    c64 pr = cmul_nf(b, X[r]);
-                    prod[q][r].re += pr.re;
-                    prod[q][r].im += pr.im;
+                for (int d = 0; d < 8; d++) {
+                    c64 t = cmul_tw<+1>(O[d], tab[kWCOff + lane + 64 * d]);
+                    X[d] = cadd(E[d], t);
+                    X[d + 8] = csub(E[d], t);
                 }
+                // key slot g has been in flight since the previous digit; make it visible to the
+                // whole workgroup, then start the DMA of slot g+1 into the other half of the ring
+                // (every wave is past its reads of that half: they precede this barrier).
+                // (an LDS-DMA is tracked by vmcnt; hipcc does not drain it at a barrier by itself)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (g + 1 < total_g) bsk_slot_dma(slot_src(g + 1), bskring + ((g + 1) & 1) * kBskSlotBytes, tid);
+                const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes);
+                // glwe_polynomial_mad (fft_ops.rs:107-124) -> complex_mad, c += a * b with
+                // a = key, b = digit transform, in the order of the reference's AVX-512 path
+                // (math/simd/x86_64/avx512.rs:54-57): re += a.re*b.re; im += a.re*b.im;
+                // re -= a.im*b.im; im += a.im*b.re — four FMAs.
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        c64 k = row[q * kHalf + lane + 64 * r];
+                        double re = __builtin_fma(k.re, X[r].re, prod[q][r].re);
+                        double im = __builtin_fma(k.re, X[r].im, prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, X[r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, X[r].re, im);
+                    }
+            }
         }
 
         // ---- back to the torus and acc = prod + acc (fft_ops.rs:176-180)
@@ -241,17 +241,32 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
                 O[d] = cmul_tw<-1>(dd, tab[kWCOff + lane + 64 * d]);
             }
             fft512_pair<-1>(E, O, wbuf, wbuf + 8192, tab, lane);
+            // complex_untwist (scalar.rs:26-35): (x * n_inv) * twist_inv
+            double tv[32];
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++)
 #pragma unroll
                 for (int par = 0; par < 2; par++) {
                     c64 y = par ? O[n1] : E[n1];
-                    // complex_untwist (scalar.rs:26-35): (x * n_inv) * twist_inv, round()
                     c64 xs = {y.re * (1.0 / 1024.0), y.im * (1.0 / 1024.0)};
                     c64 t = cmul_nf_conj(xs, tab[kTWOff + par * 512 + 64 * n1 + lane]);
-                    acc[q][n1 * 2 + par] += f64_round_to_torus(t.re);
-                    acc[q][16 + n1 * 2 + par] += f64_round_to_torus(t.im);
+                    tv[n1 * 2 + par] = t.re;
+                    tv[16 + n1 * 2 + par] = t.im;
                 }
+            // round(), mod 2^64, `as i64` (scalar.rs:32-33,75-119; torus.rs:177-192).  Products of
+            // real keys are ~2^80: every value is already an integer (|v| >= 2^52), for which a
+            // short exact conversion exists; the wave takes it only if ALL its values qualify,
+            // otherwise the literal sequence.  Both give identical words where both apply.
+            double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+            for (int e = 1; e < 32; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+            if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+                for (int e = 0; e < 32; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 32; e++) acc[q][e] += f64_round_to_torus(tv[e]);
+            }
         }
     }
 

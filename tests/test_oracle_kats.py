@@ -133,11 +133,31 @@ def test_complex_mad_matches_definition():
     mk = lambda: (rng.integers(0, 1 << 64, 16, dtype=np.uint64).astype(np.float64)
                   + 1j * rng.integers(0, 1 << 64, 16, dtype=np.uint64).astype(np.float64))
     a, b, c = mk(), mk(), mk()
+    assert O.get_mad_mode() == 1     # the build's canonical order = the reference's AVX-512 path
+    try:
+        # mode 0: scalar / AVX2 path, `*c += a * b`, nothing fused (simd/scalar.rs:12-16)
+        O.set_mad_mode(0)
+        got = O.complex_mad(c, a, b)
+        exp = np.array([complex(c[i].real + (a[i].real * b[i].real - a[i].imag * b[i].imag),
+                                c[i].imag + (a[i].real * b[i].imag + a[i].imag * b[i].real))
+                        for i in range(16)])
+        assert np.array_equal(got, exp)
+    finally:
+        O.set_mad_mode(1)
+    # mode 1: AVX-512 path, four FMAs in this order (simd/x86_64/avx512.rs:54-57).  Exact
+    # rational arithmetic gives the correctly-rounded fma the asm performs.
+    from fractions import Fraction as F
+
+    def fma(x, y, z):
+        return float(F(x) * F(y) + F(z))   # float(Fraction) rounds to nearest-even
+
     got = O.complex_mad(c, a, b)
-    exp = np.array([complex(c[i].real + (a[i].real * b[i].real - a[i].imag * b[i].imag),
-                            c[i].imag + (a[i].real * b[i].imag + a[i].imag * b[i].real))
-                    for i in range(16)])
-    assert np.array_equal(got, exp)
+    for i in range(16):
+        re = fma(a[i].real, b[i].real, c[i].real)
+        im = fma(a[i].real, b[i].imag, c[i].imag)
+        re = fma(-a[i].imag, b[i].imag, re)
+        im = fma(a[i].imag, b[i].real, im)
+        assert (got[i].real, got[i].imag) == (re, im)
 
 
 # ------------------------------------------------------------------ second opinions on the FFT
