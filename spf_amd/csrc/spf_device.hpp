@@ -130,6 +130,37 @@ __device__ __forceinline__ void wave_lds_fence()
 // instructions execute in order and all 64 lanes retire an instruction together.
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 
+// One 512-point DFT (same DAG and exchange images as fft512_pair below) held by one wave; used
+// by the two-waves-per-ciphertext kernel, where the partner wave on the SIMD hides the LDS
+// round trips.  `buf` is the wave's private 8 KiB tile.
+template <int DIR>
+__device__ __forceinline__ void fft512_single(c64 (&V)[8], char* buf, const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
+    radix8<DIR>(V);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) V[k1] = cmul_tw<DIR>(V[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = V[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) V[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
+    radix8<DIR>(V);
+#pragma unroll
+    for (int c = 1; c < 8; c++) V[c] = cmul_tw<DIR>(V[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    compiler_fence();
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = V[c];
+    wave_lds_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) V[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
+    radix8<DIR>(V);
+    compiler_fence();
+}
+
 // Two independent 512-point DFTs (the even / odd sample halves of one 1024-point transform),
 // DIF 8x8x8, held by one wave and advanced in lockstep so that one transform's LDS round trip
 // hides under the other's butterflies.  For each: lane l, register j holds element 64*j + l on

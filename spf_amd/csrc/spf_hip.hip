@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -157,14 +158,21 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
     const size_t lds = kBlindRotateLds;
-    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(256);
+    // variant 2 (default): two waves per ciphertext, 512-thread workgroups; variant 1: one wave
+    // per ciphertext, 256-thread workgroups.  Same results; SPF_BLIND_ROTATE_VARIANT picks.
+    static const int variant = [] {
+        const char* e = getenv("SPF_BLIND_ROTATE_VARIANT");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(variant == 2 ? 512 : 256);
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
-    hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, lds, s, a);
+    if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, lds, s, a);
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
@@ -274,6 +282,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
         CK(hipMemcpy(c->d_cbs_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice));
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
 #undef CK
     *out = c;

@@ -299,6 +299,246 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// blind_rotate2_kernel: TWO WAVEFRONTS PER CIPHERTEXT, eight waves (four ciphertexts) per
+// workgroup, i.e. two waves per SIMD, so one wave's LDS round trips and barrier waits hide under
+// its SIMD partner's f64 issue.  Wave w (0/1) of a ciphertext owns the complex samples of parity
+// w — polynomial coefficients c = half*1024 + 128*n1 + 2*lane + w — which is exactly the input of
+// one of the two 512-point transforms of DAG-I: the forward transform ends with, and the inverse
+// starts with, a 4 KiB exchange between the two waves (the radix-2 stage across parities); all
+// other FFT exchanges stay inside a wave.  Same arithmetic, bit for bit, as blind_rotate_kernel.
+//
+// The ciphertext's 16 KiB tile is two 8 KiB regions, region w written only by wave w:
+// rotation staging (region = coefficient parity), the wave's private FFT exchange image, and the
+// outgoing half of the cross exchange.  A workgroup barrier precedes every first write of a
+// region after a phase in which the partner reads it.
+template <int L, int LOGB>
+__global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a)
+{
+    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int cslot = wv >> 1;
+    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
+    char* mine = tile + w * 8192;
+    char* theirs = tile + (w ^ 1) * 8192;
+    char* bskring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
+
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
+    }
+
+    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
+    const bool owns_output = ct_raw < a.B;
+    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
+    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
+    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
+
+    const uint32_t total_g = a.n * (2 * L);
+    auto slot_src = [&](uint32_t g) -> const c64* {
+        uint32_t step = g / (2 * L), m = g % (2 * L), p = m / L, j = m % L;
+        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf);
+    };
+    auto slot_dma = [&](uint32_t g) {
+        const c64* src = slot_src(g);
+        char* dst = bskring + (g & 1) * kBskSlotBytes;
+        const int wave_base = tid & ~63;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + k * 512 + tid),
+                (__attribute__((address_space(3))) void*)(dst + (k * 512 + wave_base) * 16), 16, 0, 0);
+    };
+    slot_dma(0);
+
+    // lane-private element e = half*8 + n1  <->  coefficient half*1024 + 128*n1 + 2*lane + w
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+
+    uint64_t acc[2][16];
+    {
+        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + bt;
+                uint64_t v = lut[p * kN + (idx & (kN - 1))];
+                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+            }
+    }
+    __syncthreads();
+
+    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
+    const c64* twist = tab + kTWOff + w * 512 + lane;   // e^{+i pi (2n'+w)/2048}, n' = 64 n1 + lane
+    const c64* wc = tab + kWCOff + 256 * w + lane;       // W1024^{lane + 64 (4w + i)}
+    uint64_t a_next = lwe[0];
+    uint32_t g = 0;
+    for (uint32_t step = 0; step < a.n; step++) {
+        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
+        a_next = lwe[step + 1];
+
+        c64 prod[2][8]; // bins lane + 64 (4w + i) + 512 s  at index i + 4 s
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
+
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            uint32_t dig[16];
+            // partner must be done reading my region: for p = 0 the barrier ahead of the last
+            // inverse transform already guarantees it
+            if (p == 1) __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
+            __syncthreads(); // both parities staged
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
+                uint32_t srcc = idx & (kN - 1);
+                uint64_t v = reinterpret_cast<const uint64_t*>(tile + (srcc & 1) * 8192)[srcc >> 1];
+                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+                uint64_t diff = rot - acc[p][e];
+                constexpr int shift = 64 - L * LOGB;
+                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    uint32_t d = s & ((1u << LOGB) - 1);
+                    s >>= LOGB;
+                    s += d >> (LOGB - 1);
+                    packed |= d << (j * LOGB);
+                }
+                dig[e] = packed;
+            }
+
+#pragma unroll 1
+            for (int j = 0; j < L; j++, g++) {
+                const int sh = j * LOGB;
+                c64 V[8];
+#pragma unroll
+                for (int n1 = 0; n1 < 8; n1++) {
+                    int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                    int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                    V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
+                }
+                __syncthreads(); // partner is done gathering / done with my last cross data
+                fft512_single<+1>(V, mine, tab, lane);
+                // radix-2 stage across the two waves: wave 0 finishes bins with d < 4, wave 1 d >= 4
+                c64 Ei[4], Oi[4];
+                if (w == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[4 + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[i];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of key slot g has landed
+                __syncthreads();
+                if (g + 1 < total_g) slot_dma(g + 1);
+                if (w == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { Ei[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; Oi[i] = V[4 + i]; }
+                }
+                c64 X[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    c64 t = cmul_tw<+1>(Oi[i], wc[64 * i]);
+                    X[i] = cadd(Ei[i], t);
+                    X[i + 4] = csub(Ei[i], t);
+                }
+                const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes) + 256 * w + lane;
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        c64 k = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                        double re = __builtin_fma(k.re, X[r].re, prod[q][r].re);
+                        double im = __builtin_fma(k.re, X[r].im, prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, X[r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, X[r].re, im);
+                    }
+            }
+        }
+
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            c64 Ep[4], Op[4], V[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Ep[i] = cadd(prod[q][i], prod[q][i + 4]);
+                c64 dd = csub(prod[q][i], prod[q][i + 4]);
+                Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
+            }
+            if (q == 0) __syncthreads(); // partner is done with my last forward cross data
+            if (w == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
+            }
+            __syncthreads();
+            if (w == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
+            }
+            __syncthreads(); // both cross reads retired before either region is overwritten
+            fft512_single<-1>(V, mine, tab, lane);
+            double tv[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+                c64 t = cmul_nf_conj(xs, twist[64 * n1]);
+                tv[n1] = t.re;
+                tv[8 + n1] = t.im;
+            }
+            double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+            for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+            if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[q][e] += f64_round_to_torus(tv[e]);
+            }
+        }
+    }
+
+    if (!owns_output) return;
+    uint64_t* out = a.out + (size_t)ct * a.out_stride;
+    if (!a.sample_extract) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int c = coef2(e);
+            if (c == 0) {
+                out[0] = acc[0][e];
+                out[kN] = acc[1][e];
+            } else {
+                out[kN - c] = (uint64_t)0 - acc[0][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // LWE keyswitch L1 -> L0 (ops/keyswitch/lwe_keyswitch.rs:23-62; lev_ciphertext_ops.rs:18-42;
 // lwe_ciphertext_ops.rs:48-66), batched: out[ct] = (0,..,0,b) - sum_i sum_j d_{i,j} KSK[i][l-1-j].
 // A workgroup owns a tile of KS_CT ciphertexts x 256 output columns; each thread owns one
