@@ -157,7 +157,6 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
-    const size_t lds = kBlindRotateLds;
     // variant 2 (default): two waves per ciphertext, 512-thread workgroups; variant 1: one wave
     // per ciphertext, 256-thread workgroups.  Same results; SPF_BLIND_ROTATE_VARIANT picks.
     static const int variant = [] {
@@ -171,8 +170,8 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
-    if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, lds, s, a);
+    if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16>), grid, block, kBlindRotate2Lds, s, a);
+    else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, kBlindRotateLds, s, a);
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
@@ -284,7 +283,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2Lds));
 #undef CK
     *out = c;
     return SPF_OK;

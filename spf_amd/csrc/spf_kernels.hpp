@@ -69,6 +69,7 @@ __device__ __forceinline__ int stage_pos(int c) { return ((c & 1) << 10) | (c >>
 //                         workgroup multiplies by next, filled by LDS-DMA (global_load_lds)
 constexpr int kBskSlotBytes = 2 * kHalf * 16; // one (row, level): both output polynomials
 constexpr int kBlindRotateLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 2 * kBskSlotBytes;
+constexpr int kBlindRotate2Lds = kBlindRotateLds + 64; // + one rendezvous word per wave
 
 // issue this thread's share of the DMA that brings one 32 KiB key slot into LDS: 8 x 16 bytes
 // per lane, each wave-instruction lands 1 KiB contiguously (wave-uniform base + lane*16).
@@ -311,6 +312,20 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
 // rotation staging (region = coefficient parity), the wave's private FFT exchange image, and the
 // outgoing half of the cross exchange.  A workgroup barrier precedes every first write of a
 // region after a phase in which the partner reads it.
+// Two-wave rendezvous through an LDS word per wave (the two waves of one ciphertext): publish my
+// phase number, spin until the partner has published the same.  LDS services a CU's DS
+// instructions in order, so data written (and drained with lgkmcnt(0)) before the flag is
+// visible to whoever has seen the flag; reads drained before the flag are complete.  Unlike
+// s_barrier this does not re-align the four ciphertexts of the workgroup with each other.
+__device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, int partner, uint32_t& seq)
+{
+    seq++;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    flags[me] = seq;
+    while ((int)(__builtin_amdgcn_readfirstlane(flags[partner]) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
 template <int L, int LOGB>
 __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a)
 {
@@ -326,11 +341,15 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
     char* bskring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
+    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kBlindRotateLds);
+    uint32_t seq = 0;
+    const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
 
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
+        if (tid < 8) flags[tid] = 0;
     }
 
     const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
@@ -393,10 +412,10 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
             uint32_t dig[16];
             // partner must be done reading my region: for p = 0 the barrier ahead of the last
             // inverse transform already guarantees it
-            if (p == 1) __syncthreads();
+            if (p == 1) pair_barrier(flags, me, partner, seq);
 #pragma unroll
             for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
-            __syncthreads(); // both parities staged
+            pair_barrier(flags, me, partner, seq); // both parities staged
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
                     int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
                     V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
                 }
-                __syncthreads(); // partner is done gathering / done with my last cross data
+                pair_barrier(flags, me, partner, seq); // partner is done gathering / done with my last cross data
                 fft512_single<+1>(V, mine, tab, lane);
                 // radix-2 stage across the two waves: wave 0 finishes bins with d < 4, wave 1 d >= 4
                 c64 Ei[4], Oi[4];
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
                 c64 dd = csub(prod[q][i], prod[q][i + 4]);
                 Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
             }
-            if (q == 0) __syncthreads(); // partner is done with my last forward cross data
+            if (q == 0) pair_barrier(flags, me, partner, seq); // partner is done with my last forward cross data
             if (w == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
 #pragma unroll
                 for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
             }
-            __syncthreads();
+            pair_barrier(flags, me, partner, seq);
             if (w == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
 #pragma unroll
                 for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
             }
-            __syncthreads(); // both cross reads retired before either region is overwritten
+            pair_barrier(flags, me, partner, seq); // both cross reads retired before either region is overwritten
             fft512_single<-1>(V, mine, tab, lane);
             double tv[16];
 #pragma unroll
