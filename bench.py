@@ -48,6 +48,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
+                    "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -66,15 +68,19 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()   # == local_rank on a full node
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     P = spf_amd.DEFAULT_128
     spf_amd.build_library()
-    eng = spf_amd.Engine(P, device=local_rank)
+    eng = spf_amd.Engine(P, device=local_dev)
 
     # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob
     t_keys0 = time.time()
@@ -113,7 +119,10 @@ def main() -> int:
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_dev])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

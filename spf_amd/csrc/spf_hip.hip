@@ -50,6 +50,9 @@ struct spf_ctx {
     bool ksk_ready = false;
     uint64_t* d_cbs_lut = nullptr; // fill_multifunctional_cbs_decomposition_lut, constant per params
     DevBuf in, out, mid, aux;      // staging for the host-pointer entry points
+    int8_t* d_ksk_planes = nullptr; // key byte planes for the int8-MFMA keyswitch [Npad][K]
+    size_t ks_npad = 0;
+    DevBuf ks_dig, ks_rowsum;       // per-call digits [Mpad][K] and digit sums [Mpad]
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
     bool timing = false;
     std::vector<TimedLaunch> t_pbs, t_ks;
@@ -180,23 +183,70 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     return SPF_OK;
 }
 
+// the int8-MFMA formulation applies when digits fit int8, K is a multiple of the MFMA depth and
+// the int32 accumulators cannot overflow
+bool ks_mfma_ok(const spf_params& p)
+{
+    const uint64_t K = (uint64_t)p.glwe_size * p.polynomial_degree * p.ks_radix_count;
+    return p.ks_radix_log <= 8 && K % 32 == 0 && K * ((uint64_t)1 << (p.ks_radix_log - 1)) * 128 < ((uint64_t)1 << 31);
+}
+
+// (re)build the byte-plane image of the keyswitch key; called whenever the key becomes ready
+spf_status build_ks_planes(spf_ctx* c)
+{
+    if (!ks_mfma_ok(c->prm)) return SPF_OK;
+    const uint32_t n_in = c->prm.glwe_size * c->prm.polynomial_degree, w = c->prm.lwe_dimension + 1;
+    const size_t K = (size_t)n_in * c->prm.ks_radix_count;
+    const size_t npad = ((size_t)w * 8 + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
+    if (!c->d_ksk_planes) HIPCHK(c, hipMalloc((void**)&c->d_ksk_planes, npad * K));
+    c->ks_npad = npad;
+    HIPCHK(c, hipMemsetAsync(c->d_ksk_planes, 0, npad * K, c->stream));
+    const size_t total = (size_t)n_in * c->prm.ks_radix_count * w;
+    hipLaunchKernelGGL(ks_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_ksk,
+                       c->d_ksk_planes, n_in, w, c->prm.ks_radix_count, K);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
 spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_in,
                             uint64_t* d_out)
 {
     if (!c->ksk_ready) return fail(c, SPF_ERR_NO_KEY, "keyswitch key not loaded");
     if (B == 0) return SPF_OK;
+    if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
     KeyswitchArgs a{};
     a.in = d_in; a.ksk = c->d_ksk; a.out = d_out;
     a.n_in = c->prm.glwe_size * c->prm.polynomial_degree; a.n_out = c->prm.lwe_dimension;
     a.B = (uint32_t)B; a.radix_log = c->prm.ks_radix_log; a.count = c->prm.ks_radix_count;
-    dim3 grid((a.n_out + 1 + 255) / 256, (unsigned)((B + KS_CT - 1) / KS_CT)), block(256);
+    static const bool force_valu = [] { const char* e = getenv("SPF_KEYSWITCH_VALU"); return e && e[0] == '1'; }();
+    const bool mfma = c->d_ksk_planes && !force_valu;
+    const size_t K = (size_t)a.n_in * a.count, mpad = (B + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
+    if (mfma) {
+        spf_status st = ensure(c, c->ks_dig, mpad * K);
+        if (st != SPF_OK) return st;
+        st = ensure(c, c->ks_rowsum, mpad * sizeof(int));
+        if (st != SPF_OK) return st;
+    }
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
-    hipLaunchKernelGGL(keyswitch_kernel, grid, block, 0, s, a);
+    if (mfma) {
+        HIPCHK(c, hipMemsetAsync(c->ks_rowsum.p, 0, mpad * sizeof(int), s));
+        hipLaunchKernelGGL(ks_digits_kernel, dim3((unsigned)B), dim3(256), 0, s, d_in, (int8_t*)c->ks_dig.p,
+                           (int*)c->ks_rowsum.p, a.n_in, a.B, a.radix_log, a.count);
+        KsGemmArgs g{};
+        g.A = (const int8_t*)c->ks_dig.p; g.Bt = c->d_ksk_planes; g.rowsum = (const int*)c->ks_rowsum.p;
+        g.in = d_in; g.out = d_out; g.B = a.B; g.n_in = a.n_in; g.n_out = a.n_out; g.K = (uint32_t)K;
+        dim3 grid((unsigned)(c->ks_npad / KSG_TILE), (unsigned)(mpad / KSG_TILE));
+        hipLaunchKernelGGL(ks_gemm_kernel, grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((a.n_out + 1 + 255) / 256, (unsigned)((B + KS_CT - 1) / KS_CT)), block(256);
+        hipLaunchKernelGGL(keyswitch_kernel, grid, block, 0, s, a);
+    }
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
@@ -297,7 +347,8 @@ void spf_destroy(spf_ctx* c)
     for (auto& t : c->t_pbs) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto& t : c->t_ks) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_ksk, (void*)c->d_cbs_lut,
-                    c->in.p, c->out.p, c->mid.p, c->aux.p})
+                    c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->ks_dig.p,
+                    c->ks_rowsum.p})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -327,7 +378,11 @@ spf_status spf_key_blob_commit(spf_ctx* c, int which)
     if (!c) return SPF_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> g(c->mu);
     if (which == 0 && c->d_bsk) c->bsk_ready = true;
-    else if (which == 1 && c->d_ksk) c->ksk_ready = true;
+    else if (which == 1 && c->d_ksk) {
+        spf_status st = build_ks_planes(c);
+        if (st != SPF_OK) return st;
+        c->ksk_ready = true;
+    }
     else return fail(c, SPF_ERR_INVALID_ARGUMENT, "blob not allocated");
     return SPF_OK;
 }
@@ -358,6 +413,8 @@ spf_status spf_load_keyswitch_key(spf_ctx* c, const uint64_t* ksk, size_t n_word
     if (s != SPF_OK) return s;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, ksk, bytes, hipMemcpyHostToDevice));
+    spf_status st = build_ks_planes(c);
+    if (st != SPF_OK) return st;
     c->ksk_ready = true;
     return SPF_OK;
 }

@@ -620,6 +620,132 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(KeyswitchArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Keyswitch as an int8 block-GEMM on the matrix cores.  The batched keyswitch
+//   out[b] = (0,..,0,body_b) - sum_k d[b][k] * KSK_k          (k = i*count + j, wrapping u64)
+// is a dense [B x K] x [K x (n_out+1)] product whose left factor holds tiny signed digits.
+// Each 64-bit key word is split into its 8 byte planes, stored signed as (byte - 128) so they fit
+// v_mfma_i32_32x32x32_i8; the exact integer identity
+//   sum_k d_k * word_k = sum_t 2^(8t) * ( sum_k d_k * (byte_{k,t} - 128)  +  128 * sum_k d_k )
+// restores the product: the inner sums are the GEMM (int32 accumulators cannot overflow:
+// K * 2^(radix_log-1) * 128 < 2^31), the correction needs only each ciphertext's digit sum, and
+// the recombination happens in the epilogue in wrapping 64-bit arithmetic.  Results are identical,
+// bit for bit, to the scalar definition (integer arithmetic is exact).
+//   A  [Mpad][K]  int8   digits, K-contiguous            (ks_digits_kernel, per call)
+//   Bt [Npad][K]  int8   key byte planes, n = 8*col + t   (ks_planes_kernel, once per key)
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+constexpr int KSG_TILE = 128; // block tile (M and N); 4 waves, each 64 x 64
+
+// digits of every mask word: round (radix.rs:157-162) then vector_next_decomp (scalar.rs:52-71)
+__global__ __launch_bounds__(256) void ks_digits_kernel(const uint64_t* in, int8_t* dig, int* rowsum,
+                                                        uint32_t n_in, uint32_t B, uint32_t radix_log,
+                                                        uint32_t count)
+{
+    const uint32_t ct = blockIdx.x;
+    if (ct >= B) return; // padded rows stay zero (buffer is cleared by the host)
+    const uint64_t* x = in + (size_t)ct * (n_in + 1);
+    int8_t* d = dig + (size_t)ct * n_in * count;
+    const uint32_t shift = 64 - radix_log * count;
+    const uint64_t mask = ((uint64_t)1 << radix_log) - 1;
+    int local = 0;
+    for (uint32_t i = threadIdx.x; i < n_in; i += 256) {
+        uint64_t v = x[i];
+        uint64_t st = (v >> shift) + ((v >> (shift - 1)) & 1);
+        for (uint32_t j = 0; j < count; j++) {
+            uint64_t dg = st & mask;
+            st >>= radix_log;
+            uint64_t carry = dg >> (radix_log - 1);
+            st += carry;
+            int digit = (int)dg - (int)(carry << radix_log);
+            d[(size_t)i * count + j] = (int8_t)digit;
+            local += digit;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&rowsum[ct], local);
+}
+
+// key byte planes: Bt[8*col + t][i*count + j] = byte t of KSK[i][count-1-j][col], minus 128
+// (LEV rows are consumed in reverse, lev_ciphertext_ops.rs:36).  Rows past the key stay zero.
+__global__ __launch_bounds__(256) void ks_planes_kernel(const uint64_t* ksk, int8_t* bt, uint32_t n_in,
+                                                        uint32_t w, uint32_t count, size_t K)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; // over (i, j, col), col fastest
+    const size_t total = (size_t)n_in * count * w;
+    if (idx >= total) return;
+    const uint32_t col = (uint32_t)(idx % w);
+    const size_t ij = idx / w;
+    const uint32_t jrow = (uint32_t)(ij % count), i = (uint32_t)(ij / count);
+    const uint64_t word = ksk[idx];
+    const size_t k = (size_t)i * count + (count - 1 - jrow);
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        bt[((size_t)col * 8 + t) * K + k] = (int8_t)((int)((word >> (8 * t)) & 0xFF) - 128);
+}
+
+struct KsGemmArgs {
+    const int8_t* A;    // [Mpad][K]
+    const int8_t* Bt;   // [Npad][K]
+    const int* rowsum;  // [Mpad]
+    const uint64_t* in; // B x (n_in+1), for the body word
+    uint64_t* out;      // B x (n_out+1)
+    uint32_t B, n_in, n_out, K;
+};
+
+__global__ __launch_bounds__(256) void ks_gemm_kernel(KsGemmArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const size_t K = a.K;
+    const uint32_t m0 = blockIdx.y * KSG_TILE + wm * 64, n0 = blockIdx.x * KSG_TILE + wn * 64;
+    // v_mfma_i32_32x32x32_i8: lane (r, h) supplies 16 consecutive k of A row r and of B column r
+    // for its half h; any k permutation common to both operands leaves the dot products unchanged.
+    const int8_t* pa0 = a.A + (size_t)(m0 + r) * K + 16 * h;
+    const int8_t* pa1 = pa0 + 32 * K;
+    const int8_t* pb0 = a.Bt + (size_t)(n0 + r) * K + 16 * h;
+    const int8_t* pb1 = pb0 + 32 * K;
+    v16i32 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+#pragma unroll 4
+    for (size_t k0 = 0; k0 < K; k0 += 32) {
+        v4i32 a0 = *reinterpret_cast<const v4i32*>(pa0 + k0);
+        v4i32 a1 = *reinterpret_cast<const v4i32*>(pa1 + k0);
+        v4i32 b0 = *reinterpret_cast<const v4i32*>(pb0 + k0);
+        v4i32 b1 = *reinterpret_cast<const v4i32*>(pb1 + k0);
+        acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
+    }
+    // epilogue: C/D map of the 32x32 forms: row = (reg&3) + 8*(reg>>2) + 4*h, col = r.
+    // Column n = 8*word + t: shift plane t into place and add the 8 lanes of a word.
+    const uint32_t w = a.n_out + 1;
+    const int t = r & 7;
+    auto finish = [&](const v16i32& acc, uint32_t mbase, uint32_t nbase) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t row = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const long long s = (long long)acc[reg] + 128ll * (long long)a.rowsum[row];
+            unsigned long long v = (unsigned long long)s << (8 * t);
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            const uint32_t word = (nbase + r) >> 3;
+            if (t == 0 && row < a.B && word < w) {
+                const uint64_t body = (word == a.n_out) ? a.in[(size_t)row * (a.n_in + 1) + a.n_in] : 0;
+                a.out[(size_t)row * w + word] = body - v;
+            }
+        }
+    };
+    finish(acc00, m0, n0);
+    finish(acc01, m0, n0 + 32);
+    finish(acc10, m0 + 32, n0);
+    finish(acc11, m0 + 32, n0 + 32);
+}
+
 // sample_extract (ops/ciphertext/glwe_ciphertext_ops.rs:31-76), k = 1, batched
 __global__ void sample_extract_kernel(const uint64_t* glwe, uint64_t* lwe, uint32_t B, uint32_t h)
 {
