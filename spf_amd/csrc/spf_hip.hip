@@ -334,6 +334,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2Lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
 #undef CK
     *out = c;
     return SPF_OK;
@@ -472,9 +474,24 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     return SPF_OK;
 }
 
-spf_status spf_cmux_dev(spf_ctx* c, void*, size_t, const double*, const uint64_t*, const uint64_t*, uint64_t*)
+spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel, const uint64_t* d_a, const uint64_t* d_b,
+                        uint64_t* d_out)
 {
-    return fail(c, SPF_ERR_UNSUPPORTED, "cmux (cbs_radix GGSW) is not built yet");
+    if (!c || (B && (!d_sel || !d_a || !d_b || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
+        return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
+    if (B == 0) return SPF_OK;
+    if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    CmuxArgs a{};
+    // cmux(c, d_0 = a, d_1 = b, b_fft = sel) (crypto/evaluation.rs:68-83)
+    a.ggsw = reinterpret_cast<const c64*>(d_sel); a.d0 = d_a; a.d1 = d_b; a.out = d_out;
+    a.tables = c->d_tables; a.B = (uint32_t)B;
+    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
+    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, (hipStream_t)stream, a);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
 }
 
 // ---------------------------------------------------------------- host-pointer forms
@@ -569,9 +586,27 @@ spf_status spf_sample_extract_l1_batch(spf_ctx* c, size_t B, const uint64_t* glw
     return SPF_OK;
 }
 
-spf_status spf_cmux_batch(spf_ctx* c, size_t, const double*, const uint64_t*, const uint64_t*, uint64_t*)
+spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_t* a, const uint64_t* b, uint64_t* out)
 {
-    return fail(c, SPF_ERR_UNSUPPORTED, "cmux (cbs_radix GGSW) is not built yet");
+    if (!c || (B && (!sel || !a || !b || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t gw = glwe_words(c->prm) * 8, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->aux, sel, B * sw);
+        STAGE_IN(c->in, a, B * gw);
+        STAGE_IN(c->mid, b, B * gw);
+        spf_status s = ensure(c, c->out, B * gw);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_cmux_dev(c, c->stream, B, (const double*)c->aux.p, (const uint64_t*)c->in.p,
+                                (const uint64_t*)c->mid.p, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
 }
 
 spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, uint64_t* glwe_out)

@@ -558,6 +558,205 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
 }
 
 // ------------------------------------------------------------------------------------------
+// cmux_kernel: batched `cmux` (ops/fft_ops.rs:149-181) with a per-ciphertext GGSW selector,
+//   out = d0 + IFFT( sum_{p,j} FFT(digit_j(d1 - d0)_p) . GGSW[p][L-1-j] ),
+// the operation `KeylessEvaluation::cmux` performs for every gate of a CMUX tree (GGSW in
+// cbs_radix shape, L = 4 digits of 4 bits at DEFAULT_128).  Same two-waves-per-ciphertext
+// arithmetic as blind_rotate2_kernel (one step, no rotation), but every ciphertext brings its own
+// 2*L*2 polynomials of key (256 KiB at L = 4), read exactly once straight from HBM into registers:
+// algorithmic traffic 256 KiB + 3 x 32 KiB per CMUX makes this kernel HBM-bound.  No workgroup
+// barrier: the two waves of a ciphertext meet through pair_barrier only.
+struct CmuxArgs {
+    const c64* ggsw;      // B x [2][L][2][1024]
+    const uint64_t* d0;   // B x 4096 (selected when the GGSW encrypts 0)
+    const uint64_t* d1;   // B x 4096
+    uint64_t* out;        // B x 4096
+    const c64* tables;
+    uint32_t B;
+};
+constexpr int kCmuxLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
+{
+    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int cslot = wv >> 1;
+    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
+    char* mine = tile + w * 8192;
+    char* theirs = tile + (w ^ 1) * 8192;
+    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes);
+    uint32_t seq = 0;
+    const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
+        if (tid < 8) flags[tid] = 0;
+    }
+    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
+    const bool owns_output = ct_raw < a.B;
+    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
+    const c64* ggsw = a.ggsw + (size_t)ct * (2 * L * 2 * kHalf);
+    const uint64_t* d0 = a.d0 + (size_t)ct * 2 * kN;
+    const uint64_t* d1 = a.d1 + (size_t)ct * 2 * kN;
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+
+    uint32_t dig[2][16];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int c = p * kN + coef2(e);
+            uint64_t diff = d1[c] - d0[c]; // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+            constexpr int shift = 64 - L * LOGB;
+            uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                uint32_t d = s & ((1u << LOGB) - 1);
+                s >>= LOGB;
+                s += d >> (LOGB - 1);
+                packed |= d << (j * LOGB);
+            }
+            dig[p][e] = packed;
+        }
+    __syncthreads(); // twiddle image and flags ready
+
+    const c64* twist = tab + kTWOff + w * 512 + lane;
+    const c64* wc = tab + kWCOff + 256 * w + lane;
+    c64 prod[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
+
+#pragma unroll 1
+    for (int m = 0; m < 2 * L; m++) {
+        const int p = m / L, j = m - p * L, sh = j * LOGB;
+        // this wave's bins of key row (p, L-1-j): issue the loads for output polynomial 0 now,
+        // they land while the transform runs
+        const c64* row = ggsw + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf + 256 * w + lane;
+        c64 k0[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) k0[r] = row[64 * (r & 3) + 512 * (r >> 2)];
+        c64 V[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) {
+            uint32_t wre = p ? dig[1][n1] : dig[0][n1];
+            uint32_t wim = p ? dig[1][8 + n1] : dig[0][8 + n1];
+            int dre = ((int)(wre << (32 - LOGB - sh))) >> (32 - LOGB);
+            int dim = ((int)(wim << (32 - LOGB - sh))) >> (32 - LOGB);
+            V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
+        }
+        if (m > 0) pair_barrier(flags, me, partner, seq); // partner is done with my last cross data
+        fft512_single<+1>(V, mine, tab, lane);
+        c64 Ei[4], Oi[4];
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[4 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[i];
+        }
+        pair_barrier(flags, me, partner, seq);
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { Ei[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; Oi[i] = V[4 + i]; }
+        }
+        c64 X[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c64 t = cmul_tw<+1>(Oi[i], wc[64 * i]);
+            X[i] = cadd(Ei[i], t);
+            X[i + 4] = csub(Ei[i], t);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double re = __builtin_fma(k0[r].re, X[r].re, prod[0][r].re);
+            double im = __builtin_fma(k0[r].re, X[r].im, prod[0][r].im);
+            prod[0][r].re = __builtin_fma(-k0[r].im, X[r].im, re);
+            prod[0][r].im = __builtin_fma(k0[r].im, X[r].re, im);
+        }
+        c64 k1[8]; // the SIMD partner wave covers this round trip
+#pragma unroll
+        for (int r = 0; r < 8; r++) k1[r] = row[kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double re = __builtin_fma(k1[r].re, X[r].re, prod[1][r].re);
+            double im = __builtin_fma(k1[r].re, X[r].im, prod[1][r].im);
+            prod[1][r].re = __builtin_fma(-k1[r].im, X[r].im, re);
+            prod[1][r].im = __builtin_fma(k1[r].im, X[r].re, im);
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        c64 Ep[4], Op[4], V[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Ep[i] = cadd(prod[q][i], prod[q][i + 4]);
+            c64 dd = csub(prod[q][i], prod[q][i + 4]);
+            Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
+        }
+        if (q == 0) pair_barrier(flags, me, partner, seq);
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
+        }
+        pair_barrier(flags, me, partner, seq);
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
+        }
+        pair_barrier(flags, me, partner, seq);
+        fft512_single<-1>(V, mine, tab, lane);
+        double tv[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) {
+            c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+            c64 t = cmul_nf_conj(xs, twist[64 * n1]);
+            tv[n1] = t.re;
+            tv[8 + n1] = t.im;
+        }
+        double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+        for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+        // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180); d_0 is re-read rather than held
+        // in registers across the transforms
+        uint64_t* out = a.out + (size_t)ct * 2 * kN + q * kN;
+        const uint64_t* base = d0 + q * kN;
+        if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint64_t v = base[coef2(e)] + f64_bigint_to_torus(tv[e]);
+                if (owns_output) out[coef2(e)] = v;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint64_t v = base[coef2(e)] + f64_round_to_torus(tv[e]);
+                if (owns_output) out[coef2(e)] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // LWE keyswitch L1 -> L0 (ops/keyswitch/lwe_keyswitch.rs:23-62; lev_ciphertext_ops.rs:18-42;
 // lwe_ciphertext_ops.rs:48-66), batched: out[ct] = (0,..,0,b) - sum_i sum_j d_{i,j} KSK[i][l-1-j].
 // A workgroup owns a tile of KS_CT ciphertexts x 256 output columns; each thread owns one

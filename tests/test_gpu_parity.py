@@ -172,3 +172,41 @@ def test_full_parameter_set_parity():
     got = eng.circuit_bootstrap_pbs(lwe)
     for i, b in enumerate(bits):
         assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
+
+
+@pytest.mark.parametrize("B", [1, 6])
+def test_cmux_cbs_radix_parity_and_select(small, B):
+    # KeylessEvaluation::cmux (crypto/evaluation.rs:68-83) with a cbs_radix GGSW (4 x 4 bits);
+    # mirrors fft_ops.rs:537-576 (can_cmux_fft): parity with the oracle and decrypt == selected
+    ks, eng = small
+    P = ks.params
+    rng = O.Rng(4242 + B)
+    nrng = np.random.default_rng(B)
+    sels = [int(v) for v in nrng.integers(0, 2, B)]
+    msgs = [[np.array([O.encode(int(v), 3) for v in nrng.integers(0, 8, P.N)], dtype=np.uint64)
+             for _ in range(2)] for _ in range(B)]
+    d = [[O.encrypt_glwe(rng, ks.glwe_sk, m, P.N, P.k, P.glwe_std) for m in pair] for pair in msgs]
+    g = np.stack([O.encrypt_ggsw_fft(rng, ks.glwe_sk, s, P.N, P.k, P.cbs_radix_log, P.cbs_count, P.glwe_std)
+                  for s in sels])
+    a = np.stack([x[0] for x in d])
+    b = np.stack([x[1] for x in d])
+    got = eng.cmux(g, a, b)
+    for i in range(B):
+        exp = O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)
+        assert np.array_equal(got[i], exp), i
+        dec = O.decrypt_glwe_raw(got[i], ks.glwe_sk, P.N, P.k)
+        assert [O.decode(int(v), 3) for v in dec] == [O.decode(int(v), 3) for v in msgs[i][sels[i]]]
+
+
+def test_cmux_random_words_parity(small):
+    # parity does not need valid encryptions: arbitrary torus words and key bins
+    ks, eng = small
+    P = ks.params
+    nrng = np.random.default_rng(99)
+    B = 5
+    a = random_glwe(1, B, P.glwe_len)
+    b = random_glwe(2, B, P.glwe_len)
+    g = (nrng.standard_normal((B, 2 * 4 * 2 * 1024)) + 1j * nrng.standard_normal((B, 2 * 4 * 2 * 1024))) * 2.0 ** 60
+    got = eng.cmux(g, a, b)
+    for i in range(B):
+        assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
