@@ -48,6 +48,7 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
+    ap.add_argument("--with-cmux", action="store_true", help="also time the batched cbs_radix CMUX kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -164,6 +165,28 @@ def main() -> int:
         step()
         torch.cuda.synchronize()
 
+    cmux = None
+    if args.with_cmux:
+        # KeylessEvaluation::cmux over a batch: every ciphertext brings its own 256 KiB GGSW
+        gg = torch.randn((B, P.cbs_ggsw_complex * 2), generator=g, device=dev, dtype=torch.float64) * (2.0 ** 60)
+        da = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
+        db = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
+        dc = torch.empty_like(da)
+        eng.cmux_dev(stream, B, gg.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr())
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            eng.cmux_dev(stream, B, gg.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr())
+        e1.record()
+        barrier()
+        ms = e0.elapsed_time(e1) / reps
+        cm_bytes = B * (P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8)
+        cmux = {"cmux_per_s": round(B / ms * 1e3, 1), "kernel_ms": round(ms, 4),
+                "algorithmic_GBs": round(cm_bytes / ms / 1e6, 1), "hbm_frac": round(cm_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del gg, da, db, dc
+
     total_units = world * B * args.steps
     value = total_units / dt
     ms_per_step = dt / args.steps * 1e3
@@ -172,10 +195,17 @@ def main() -> int:
     per_launch_s = kernel_ms * 1e-3 if launches else float("nan")
     achieved_tflops = FLOP_PER_PBS * B / per_launch_s / 1e12
     alg_bytes = P.bsk_complex * 16 + B * (P.lwe0_words * 8 + P.glwe_words * 8)
+    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate runs; FETCH_SIZE
+    # doubled per the gfx950 correction) — written by tools_summarize_prof.py, only valid for B = 4096
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    if B == 4096 and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)
     roofline = {
         "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "blind_rotate_kernel<2,16>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
+        "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
+        "kernel": "blind_rotate2_kernel<2,16>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
         "note": "f64 work runs on the VALU (v_fma_f64); MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and "
                 "MFMA alike, so the MFMA-f64 peak is the compute roof",
@@ -221,6 +251,8 @@ def main() -> int:
         }
         if gate:
             line["gate"] = gate
+        if cmux:
+            line["cmux"] = cmux
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

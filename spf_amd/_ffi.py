@@ -221,6 +221,9 @@ class Engine:
     def circuit_bootstrap_pbs_dev(self, stream: int, B: int, d_lwe: int, d_out: int):
         self._ck(self._lib.spf_circuit_bootstrap_pbs_dev(self._h, stream, B, d_lwe, d_out))
 
+    def cmux_dev(self, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out):
+        self._ck(self._lib.spf_cmux_dev(self._h, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out))
+
     def sample_extract_l1_dev(self, stream, B, d_glwe, idx, d_out):
         self._ck(self._lib.spf_sample_extract_l1_dev(self._h, stream, B, d_glwe, idx, d_out))
 

@@ -14,6 +14,7 @@ if ks:
     lines.append("")
 lines += ["## PMC passes (one rocprofv3 --pmc run per row group; per-dispatch averages, dominant kernel only)", "",
           "| pass | counter | dispatches | avg per dispatch |", "|---|---|---|---|"]
+allacc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
     if not os.path.isdir(d): continue
     fs = glob.glob(os.path.join(d, "*/*_counter_collection.csv"))
@@ -22,7 +23,21 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
     for r in csv.DictReader(open(fs[0])):
         if "blind_rotate" in r["Kernel_Name"] or "keyswitch_kernel" in r["Kernel_Name"]:
             acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    allacc.update(acc)
     for (k, c), v in sorted(acc.items()):
         lines.append(f"| {os.path.basename(d)} | {k} {c} | {len(v)} | {sum(v)/len(v):.6g} |")
 open(os.path.join("profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+# HBM traffic of the dominant kernel per launch, corrected as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE (KB) under-counts wide coalesced reads by exactly 2x on gfx950; WRITE_SIZE (KB) is exact.
+import json
+tr = {}
+for (k, c), v in sorted(allacc.items()):
+    if "blind_rotate" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+        tr[c] = sum(v) / len(v)
+if "FETCH_SIZE" in tr:
+    out = {"fetch_bytes": tr["FETCH_SIZE"] * 1024 * 2, "write_bytes": tr.get("WRITE_SIZE", 0) * 1024,
+           "unit": "bytes per launch (B=4096)", "source": f"profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+           "separate passes; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B)"}
+    out["total_bytes"] = out["fetch_bytes"] + out["write_bytes"]
+    json.dump(out, open(os.path.join("profiles", "latest_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
