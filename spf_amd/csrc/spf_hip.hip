@@ -276,7 +276,7 @@ void spf_default_params(spf_params* o)
     *o = spf_params{637, 2048, 1, 16, 2, 4, 4, 2, 6};
 }
 
-const char* spf_version(void) { return "spf_hip 0.1 (gfx950, wave-per-ciphertext blind rotation)"; }
+const char* spf_version(void) { return "spf_hip 0.2 (gfx950: two-wave blind rotation, int8-MFMA keyswitch, cbs_radix cmux)"; }
 
 const char* spf_last_error(const spf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
