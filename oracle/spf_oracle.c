@@ -864,6 +864,193 @@ void spfo_gen_ksk(spfo_rng *r, uint64_t *ksk, const uint64_t *sk_in, size_t n_in
         }
 }
 
+/* ======================================================================== circuit-bootstrap tail
+ * (SURVEY.md §8 f2): homomorphic trace over FFT-domain GLWE keyswitches, then the scheme switch
+ * that turns the GLEV into a GGSW in the FFT domain. */
+
+/* ops/fft_ops.rs:67-98 for one polynomial: c_fft += <decomp(poly), glev>, rows in reverse */
+static void glev_mad(spfo_c64 *c_fft, const uint64_t *poly, const spfo_c64 *glev_fft, size_t N,
+                     size_t k, uint32_t radix_log, uint32_t count)
+{
+    size_t h = N / 2, glwe_fft_len = (k + 1) * h;
+    uint64_t *state = (uint64_t *)malloc(N * sizeof(uint64_t));
+    uint64_t *digit = (uint64_t *)malloc(N * sizeof(uint64_t));
+    spfo_c64 *dfft = (spfo_c64 *)malloc(h * sizeof(spfo_c64));
+    for (size_t i = 0; i < N; i++) state[i] = spfo_radix_round(poly[i], radix_log, count);
+    for (uint32_t j = 0; j < count; j++) {
+        for (size_t i = 0; i < N; i++) digit[i] = spfo_radix_next_digit(&state[i], radix_log);
+        spfo_poly_fft(digit, N, dfft);
+        const spfo_c64 *b_glwe = glev_fft + (size_t)(count - 1 - j) * glwe_fft_len;
+        for (size_t q = 0; q <= k; q++) spfo_complex_mad(c_fft + q * h, b_glwe + q * h, dfft, h);
+    }
+    free(state); free(digit); free(dfft);
+}
+
+/* ops/fft_ops.rs:457-495.  ksk layout [row<k][level<count][poly<k+1][N/2] */
+void spfo_keyswitch_glwe_to_glwe(uint64_t *out, const uint64_t *in, const spfo_c64 *ksk_fft, size_t N,
+                                 size_t k, uint32_t radix_log, uint32_t count)
+{
+    size_t h = N / 2, glev_len = (size_t)count * (k + 1) * h;
+    spfo_c64 *sum = (spfo_c64 *)calloc((k + 1) * h, sizeof(spfo_c64));
+    uint64_t *s = (uint64_t *)malloc((k + 1) * N * sizeof(uint64_t));
+    for (size_t i = 0; i < k; i++) glev_mad(sum, in + i * N, ksk_fft + i * glev_len, N, k, radix_log, count);
+    for (size_t q = 0; q <= k; q++) spfo_poly_ifft(sum + q * h, N, s + q * N);
+    /* output = trivial_encrypt(b) - sum */
+    for (size_t i = 0; i < k * N; i++) out[i] = (uint64_t)0 - s[i];
+    for (size_t i = 0; i < N; i++) out[k * N + i] = in[k * N + i] - s[k * N + i];
+    free(sum); free(s);
+}
+
+/* ops/automorphisms/mod.rs:53-85.  ak layout [i<log2 N][glwe ksk] */
+void spfo_trace(uint64_t *out, const uint64_t *x, const spfo_c64 *ak_fft, size_t N, size_t k,
+                uint32_t radix_log, uint32_t count)
+{
+    size_t len = (k + 1) * N, ksk_len = k * (size_t)count * (k + 1) * (N / 2);
+    uint64_t *glwe_k = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint64_t *ks = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint32_t logn = 0;
+    while (((size_t)1 << logn) < N) logn++;
+    memcpy(out, x, len * sizeof(uint64_t));
+    for (uint32_t i = 1; i <= logn; i++) {
+        size_t kk = N / ((size_t)1 << (i - 1)) + 1;
+        for (size_t p = 0; p <= k; p++) spfo_poly_pow_k(glwe_k + p * N, out + p * N, N, kk);
+        spfo_keyswitch_glwe_to_glwe(ks, glwe_k, ak_fft + (size_t)(i - 1) * ksk_len, N, k, radix_log, count);
+        for (size_t t = 0; t < len; t++) out[t] += ks[t];
+    }
+    free(glwe_k); free(ks);
+}
+
+/* ops/bootstrapping/circuit_bootstrapping.rs:260-298: glev is cbs_count GLWEs */
+void spfo_mod_switch_trace_and_rotate(uint64_t *glev, const uint64_t *lo_noise_glwe, const spfo_c64 *ak_fft,
+                                      size_t N, size_t k, uint32_t tr_radix_log, uint32_t tr_count,
+                                      uint32_t cbs_radix_log, uint32_t cbs_count)
+{
+    size_t len = (k + 1) * N;
+    uint32_t shift_amount = 0;
+    while (((size_t)1 << shift_amount) < N) shift_amount++;
+    uint64_t *rotated = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint64_t *permuted = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint64_t *shifted = (uint64_t *)malloc(len * sizeof(uint64_t));
+    memcpy(rotated, lo_noise_glwe, len * sizeof(uint64_t));
+    for (uint32_t i = 0; i < cbs_count; i++) {
+        uint32_t plaintext_bits = cbs_radix_log * (i + 1) + 1;
+        /* undo the rotation applied during the functional bootstrap, coefficient i only */
+        rotated[k * N + i] += spfo_encode(1, plaintext_bits);
+        memcpy(permuted, rotated, len * sizeof(uint64_t));
+        for (size_t p = 0; p <= k; p++) spfo_poly_mul_neg_monomial(permuted + p * N, N, i);
+        /* glwe_mod_switch_and_expand_pow_2 (ops/ciphertext/glwe_ciphertext_ops.rs:268-281) */
+        spfo_poly_shr_round(shifted, permuted, len, shift_amount);
+        spfo_trace(glev + (size_t)i * len, shifted, ak_fft, N, k, tr_radix_log, tr_count);
+    }
+    free(rotated); free(permuted); free(shifted);
+}
+
+static size_t tri_index(size_t i, size_t j, size_t n)
+{
+    /* entities/scheme_switch_key.rs: get_linear_index */
+    size_t row = i <= j ? i : j, col = i <= j ? j : i;
+    return (n * (n + 1) / 2) - (n - row) * ((n - row) + 1) / 2 + col - row;
+}
+
+/* ops/fft_ops.rs:225-279, 403-442.  out layout [row<k+1][level<ggsw_count][poly<k+1][N/2];
+ * ssk layout [pair][level<ss_count][poly<k+1][N/2].  The reference accumulates into rows it
+ * assumes zeroed (fresh allocate_ggsw_l1); the restatement clears the output first. */
+void spfo_scheme_switch_fft(spfo_c64 *out, const uint64_t *glev, const spfo_c64 *ssk_fft, size_t N,
+                            size_t k, uint32_t ggsw_count, uint32_t ss_radix_log, uint32_t ss_count)
+{
+    size_t h = N / 2, glwe_fft_len = (k + 1) * h, glwe_len = (k + 1) * N;
+    size_t ss_glev_len = (size_t)ss_count * glwe_fft_len;
+    memset(out, 0, (k + 1) * (size_t)ggsw_count * glwe_fft_len * sizeof(spfo_c64));
+    for (size_t j = 0; j <= k; j++)
+        for (uint32_t i = 0; i < ggsw_count; i++) {
+            spfo_c64 *y = out + (j * ggsw_count + i) * glwe_fft_len;
+            const uint64_t *x = glev + (size_t)i * glwe_len;
+            if (j == k) {
+                for (size_t p = 0; p <= k; p++) spfo_poly_fft(x + p * N, N, y + p * h);
+                continue;
+            }
+            spfo_poly_fft(x + k * N, N, y + j * h); /* y.a[j] = FFT(x.b) */
+            for (size_t r = 0; r < k; r++)
+                glev_mad(y, x + r * N, ssk_fft + tri_index(j, r, k) * ss_glev_len, N, k, ss_radix_log, ss_count);
+        }
+}
+
+/* ops/bootstrapping/circuit_bootstrapping.rs:342-385 */
+void spfo_circuit_bootstrap(spfo_c64 *ggsw_out, const uint64_t *lwe_in, const spfo_c64 *bsk_fft,
+                            const spfo_c64 *ak_fft, const spfo_c64 *ssk_fft, size_t n, size_t N, size_t k,
+                            uint32_t pbs_radix_log, uint32_t pbs_count, uint32_t tr_radix_log,
+                            uint32_t tr_count, uint32_t ss_radix_log, uint32_t ss_count,
+                            uint32_t cbs_radix_log, uint32_t cbs_count)
+{
+    size_t len = (k + 1) * N;
+    uint64_t *glwe = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint64_t *glev = (uint64_t *)malloc((size_t)cbs_count * len * sizeof(uint64_t));
+    spfo_cbs_pbs(glwe, lwe_in, bsk_fft, n, N, k, pbs_radix_log, pbs_count, cbs_radix_log, cbs_count);
+    spfo_mod_switch_trace_and_rotate(glev, glwe, ak_fft, N, k, tr_radix_log, tr_count, cbs_radix_log, cbs_count);
+    spfo_scheme_switch_fft(ggsw_out, glev, ssk_fft, N, k, cbs_count, ss_radix_log, ss_count);
+    free(glwe); free(glev);
+}
+
+/* ops/keyswitch/glwe_keyswitch_key.rs (encrypt_keyswitch_key_generic) + FFT of every polynomial:
+ * row i, level j encrypts original_sk_i * 2^(64 - logB (j+1)) under the new key */
+void spfo_gen_glwe_ksk_fft(spfo_rng *r, spfo_c64 *out, const uint64_t *sk_orig, const uint64_t *sk_new,
+                           size_t N, size_t k, uint32_t radix_log, uint32_t count, double std)
+{
+    size_t h = N / 2, len = (k + 1) * N;
+    uint64_t *ct = (uint64_t *)malloc(len * sizeof(uint64_t));
+    uint64_t *msg = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (size_t i = 0; i < k; i++)
+        for (uint32_t j = 0; j < count; j++) {
+            uint64_t factor = (uint64_t)1 << (64 - radix_log * (j + 1));
+            for (size_t t = 0; t < N; t++) msg[t] = sk_orig[i * N + t] * factor;
+            spfo_encrypt_glwe(r, ct, sk_new, msg, N, k, std);
+            for (size_t p = 0; p <= k; p++)
+                spfo_poly_fft(ct + p * N, N, out + ((i * count + j) * (k + 1) + p) * h);
+        }
+    free(ct); free(msg);
+}
+
+/* ops/automorphisms/mod.rs:18-46 */
+void spfo_gen_auto_key_fft(spfo_rng *r, spfo_c64 *ak_fft, const uint64_t *glwe_sk, size_t N, size_t k,
+                           uint32_t radix_log, uint32_t count, double std)
+{
+    size_t ksk_len = k * (size_t)count * (k + 1) * (N / 2);
+    uint64_t *sk_k = (uint64_t *)malloc(k * N * sizeof(uint64_t));
+    uint32_t logn = 0;
+    while (((size_t)1 << logn) < N) logn++;
+    for (uint32_t i = 1; i <= logn; i++) {
+        size_t kk = N / ((size_t)1 << (i - 1)) + 1;
+        for (size_t p = 0; p < k; p++) spfo_poly_pow_k(sk_k + p * N, glwe_sk + p * N, N, kk);
+        spfo_gen_glwe_ksk_fft(r, ak_fft + (size_t)(i - 1) * ksk_len, sk_k, glwe_sk, N, k, radix_log, count, std);
+    }
+    free(sk_k);
+}
+
+/* ops/bootstrapping/scheme_switch.rs:22-70: GLEV(s_i * s_j) for the upper-triangular pairs.  The
+ * reference multiplies through its FFT; the product of binary polynomials is small, so that is
+ * exact and equals the integer negacyclic product used here. */
+void spfo_gen_ssk_fft(spfo_rng *r, spfo_c64 *ssk_fft, const uint64_t *glwe_sk, size_t N, size_t k,
+                      uint32_t radix_log, uint32_t count, double std)
+{
+    size_t h = N / 2, len = (k + 1) * N;
+    uint64_t *sij = (uint64_t *)malloc(N * sizeof(uint64_t));
+    uint64_t *msg = (uint64_t *)malloc(N * sizeof(uint64_t));
+    uint64_t *ct = (uint64_t *)malloc(len * sizeof(uint64_t));
+    size_t idx = 0;
+    for (size_t i = 0; i < k; i++)
+        for (size_t j = i; j < k; j++, idx++) {
+            spfo_negacyclic_mul_exact(sij, glwe_sk + i * N, glwe_sk + j * N, N);
+            for (uint32_t t = 0; t < count; t++) {
+                uint64_t factor = (uint64_t)1 << (64 - radix_log * (t + 1));
+                for (size_t c = 0; c < N; c++) msg[c] = sij[c] * factor;
+                spfo_encrypt_glwe(r, ct, glwe_sk, msg, N, k, std);
+                for (size_t p = 0; p <= k; p++)
+                    spfo_poly_fft(ct + p * N, N, ssk_fft + ((idx * count + t) * (k + 1) + p) * h);
+            }
+        }
+    free(sij); free(msg); free(ct);
+}
+
 /* ======================================================================== cpu_baseline driver */
 
 typedef struct {

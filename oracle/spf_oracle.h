@@ -139,6 +139,27 @@ void spfo_cbs_pbs(uint64_t *glwe_out, const uint64_t *lwe_in, const spfo_c64 *bs
                   size_t N, size_t k, uint32_t pbs_radix_log, uint32_t pbs_count,
                   uint32_t cbs_radix_log, uint32_t cbs_count);
 
+/* ---------------------------------------------------------------- circuit-bootstrap tail (§8 f2) */
+
+/* ops/fft_ops.rs:457-495 (keyswitch_glwe_to_glwe); ksk_fft [row<k][level][poly<k+1][N/2] */
+void spfo_keyswitch_glwe_to_glwe(uint64_t *out, const uint64_t *in, const spfo_c64 *ksk_fft, size_t N,
+                                 size_t k, uint32_t radix_log, uint32_t count);
+/* ops/automorphisms/mod.rs:53-85 (trace); ak_fft [i<log2 N][glwe keyswitch key] */
+void spfo_trace(uint64_t *out, const uint64_t *x, const spfo_c64 *ak_fft, size_t N, size_t k,
+                uint32_t radix_log, uint32_t count);
+/* ops/bootstrapping/circuit_bootstrapping.rs:260-298; glev is cbs_count GLWEs */
+void spfo_mod_switch_trace_and_rotate(uint64_t *glev, const uint64_t *lo_noise_glwe, const spfo_c64 *ak_fft,
+                                      size_t N, size_t k, uint32_t tr_radix_log, uint32_t tr_count,
+                                      uint32_t cbs_radix_log, uint32_t cbs_count);
+/* ops/fft_ops.rs:403-442 (scheme_switch_fft); out [row<k+1][level<ggsw_count][poly][N/2] */
+void spfo_scheme_switch_fft(spfo_c64 *out, const uint64_t *glev, const spfo_c64 *ssk_fft, size_t N,
+                            size_t k, uint32_t ggsw_count, uint32_t ss_radix_log, uint32_t ss_count);
+/* ops/bootstrapping/circuit_bootstrapping.rs:342-385 (circuit_bootstrap_via_trace_and_scheme_switch) */
+void spfo_circuit_bootstrap(spfo_c64 *ggsw_out, const uint64_t *lwe_in, const spfo_c64 *bsk_fft,
+                            const spfo_c64 *ak_fft, const spfo_c64 *ssk_fft, size_t n, size_t N, size_t k,
+                            uint32_t pbs_radix_log, uint32_t pbs_count, uint32_t tr_radix_log,
+                            uint32_t tr_count, uint32_t ss_radix_log, uint32_t ss_count,
+                            uint32_t cbs_radix_log, uint32_t cbs_count);
 /* ---------------------------------------------------------------- keygen / encrypt subset
  * (self-contained test vectors; the reference uses an unseeded thread_rng (rand.rs:23,34,39),
  * so RNG parity is neither possible nor needed).  PRNG: xoshiro256** seeded by splitmix64. */
@@ -171,6 +192,14 @@ void spfo_gen_bsk_fft(spfo_rng *r, spfo_c64 *bsk_fft, const uint64_t *lwe_sk, si
 void spfo_gen_ksk(spfo_rng *r, uint64_t *ksk, const uint64_t *sk_in, size_t n_in,
                   const uint64_t *sk_out, size_t n_out, uint32_t radix_log, uint32_t count,
                   double std);
+/* keygen for the circuit-bootstrap tail: ops/keyswitch/glwe_keyswitch_key.rs,
+ * ops/automorphisms/mod.rs:18-46, ops/bootstrapping/scheme_switch.rs:22-70 — returned FFT'd */
+void spfo_gen_glwe_ksk_fft(spfo_rng *r, spfo_c64 *out, const uint64_t *sk_orig, const uint64_t *sk_new,
+                           size_t N, size_t k, uint32_t radix_log, uint32_t count, double std);
+void spfo_gen_auto_key_fft(spfo_rng *r, spfo_c64 *ak_fft, const uint64_t *glwe_sk, size_t N, size_t k,
+                           uint32_t radix_log, uint32_t count, double std);
+void spfo_gen_ssk_fft(spfo_rng *r, spfo_c64 *ssk_fft, const uint64_t *glwe_sk, size_t N, size_t k,
+                      uint32_t radix_log, uint32_t count, double std);
 /* math/torus.rs:284-300 */
 uint64_t spfo_encode(uint64_t val, uint32_t plain_bits);
 uint64_t spfo_decode(uint64_t torus, uint32_t plain_bits);

@@ -104,6 +104,14 @@ def _declare(lib):
     f("spfo_ggsw_fft", None, P, P, sz, sz, u32)
     f("spfo_gen_bsk_fft", None, P, P, P, sz, P, sz, sz, u32, u32, dbl)
     f("spfo_gen_ksk", None, P, P, P, sz, P, sz, u32, u32, dbl)
+    f("spfo_keyswitch_glwe_to_glwe", None, P, P, P, sz, sz, u32, u32)
+    f("spfo_trace", None, P, P, P, sz, sz, u32, u32)
+    f("spfo_mod_switch_trace_and_rotate", None, P, P, P, sz, sz, u32, u32, u32, u32)
+    f("spfo_scheme_switch_fft", None, P, P, P, sz, sz, u32, u32, u32)
+    f("spfo_circuit_bootstrap", None, P, P, P, P, P, sz, sz, sz, u32, u32, u32, u32, u32, u32, u32, u32)
+    f("spfo_gen_glwe_ksk_fft", None, P, P, P, P, sz, sz, u32, u32, dbl)
+    f("spfo_gen_auto_key_fft", None, P, P, P, sz, sz, u32, u32, dbl)
+    f("spfo_gen_ssk_fft", None, P, P, P, sz, sz, u32, u32, dbl)
     f("spfo_encode", u64, u64, u32)
     f("spfo_decode", u64, u64, u32)
     f("spfo_bench_cbs_pbs", dbl, P, sz, P, sz, sz, sz, u32, u32, u32, u32, C.c_int, P)
@@ -141,6 +149,10 @@ class Params:
     cbs_count: int = 4
     ks_radix_log: int = 2            # :122-125
     ks_count: int = 6
+    tr_radix_log: int = 7            # :130-133 (trace / automorphism keyswitch)
+    tr_count: int = 6
+    ss_radix_log: int = 3            # :126-129 (scheme switch)
+    ss_count: int = 15
 
     @property
     def glwe_len(self) -> int:
@@ -149,6 +161,18 @@ class Params:
     @property
     def ggsw_fft_len(self) -> int:   # complex bins of one PBS-radix GGSW
         return (self.k + 1) * self.pbs_count * (self.k + 1) * (self.N // 2)
+
+    @property
+    def cbs_ggsw_fft_len(self) -> int:  # complex bins of one cbs-radix GGSW
+        return (self.k + 1) * self.cbs_count * (self.k + 1) * (self.N // 2)
+
+    @property
+    def ak_fft_len(self) -> int:       # log2(N) GLWE keyswitch keys
+        return (self.N.bit_length() - 1) * self.k * self.tr_count * (self.k + 1) * (self.N // 2)
+
+    @property
+    def ssk_fft_len(self) -> int:
+        return (self.k * (self.k + 1) // 2) * self.ss_count * (self.k + 1) * (self.N // 2)
 
     def replace(self, **kw) -> "Params":
         d = dict(self.__dict__)
@@ -496,3 +520,65 @@ def encrypt_bits_l0(seed: int, keys: KeySet, bits) -> np.ndarray:
     rng = Rng(seed)
     return np.stack([encrypt_lwe(rng, keys.lwe_sk, encode(int(b), 1), keys.params.lwe_std)
                      for b in bits])
+
+
+# ----------------------------------------------------------------------------- circuit-bootstrap tail
+
+
+def keyswitch_glwe_to_glwe(ct, ksk_fft, N, k, radix_log, count) -> np.ndarray:
+    ct, ksk_fft = _u(ct), _c(ksk_fft)
+    out = np.zeros((k + 1) * N, dtype=np.uint64)
+    _load().spfo_keyswitch_glwe_to_glwe(_p(out), _p(ct), _p(ksk_fft), N, k, radix_log, count)
+    return out
+
+
+def trace(x, ak_fft, params: Params = DEFAULT_128) -> np.ndarray:
+    x, ak_fft = _u(x), _c(ak_fft)
+    assert ak_fft.size == params.ak_fft_len
+    out = np.zeros(params.glwe_len, dtype=np.uint64)
+    _load().spfo_trace(_p(out), _p(x), _p(ak_fft), params.N, params.k, params.tr_radix_log, params.tr_count)
+    return out
+
+
+def mod_switch_trace_and_rotate(lo_noise_glwe, ak_fft, params: Params = DEFAULT_128) -> np.ndarray:
+    g, ak_fft = _u(lo_noise_glwe), _c(ak_fft)
+    out = np.zeros((params.cbs_count, params.glwe_len), dtype=np.uint64)
+    _load().spfo_mod_switch_trace_and_rotate(_p(out), _p(g), _p(ak_fft), params.N, params.k, params.tr_radix_log,
+                                             params.tr_count, params.cbs_radix_log, params.cbs_count)
+    return out
+
+
+def scheme_switch_fft(glev, ssk_fft, params: Params = DEFAULT_128) -> np.ndarray:
+    glev, ssk_fft = _u(glev), _c(ssk_fft)
+    assert ssk_fft.size == params.ssk_fft_len
+    out = np.zeros(params.cbs_ggsw_fft_len, dtype=np.complex128)
+    _load().spfo_scheme_switch_fft(_p(out), _p(glev), _p(ssk_fft), params.N, params.k, params.cbs_count,
+                                   params.ss_radix_log, params.ss_count)
+    return out
+
+
+def circuit_bootstrap(lwe_in, bsk_fft, ak_fft, ssk_fft, params: Params = DEFAULT_128) -> np.ndarray:
+    """Evaluation::circuit_bootstrap: L0 LWE -> L1 GGSW-FFT (cbs_radix shape)."""
+    lwe_in, bsk_fft, ak_fft, ssk_fft = _u(lwe_in), _c(bsk_fft), _c(ak_fft), _c(ssk_fft)
+    out = np.zeros(params.cbs_ggsw_fft_len, dtype=np.complex128)
+    _load().spfo_circuit_bootstrap(_p(out), _p(lwe_in), _p(bsk_fft), _p(ak_fft), _p(ssk_fft), lwe_in.size - 1,
+                                   params.N, params.k, params.pbs_radix_log, params.pbs_count, params.tr_radix_log,
+                                   params.tr_count, params.ss_radix_log, params.ss_count, params.cbs_radix_log,
+                                   params.cbs_count)
+    return out
+
+
+def gen_auto_key_fft(rng: Rng, glwe_sk, params: Params = DEFAULT_128) -> np.ndarray:
+    glwe_sk = _u(glwe_sk)
+    out = np.zeros(params.ak_fft_len, dtype=np.complex128)
+    _load().spfo_gen_auto_key_fft(rng.ref, _p(out), _p(glwe_sk), params.N, params.k, params.tr_radix_log,
+                                  params.tr_count, params.glwe_std)
+    return out
+
+
+def gen_ssk_fft(rng: Rng, glwe_sk, params: Params = DEFAULT_128) -> np.ndarray:
+    glwe_sk = _u(glwe_sk)
+    out = np.zeros(params.ssk_fft_len, dtype=np.complex128)
+    _load().spfo_gen_ssk_fft(rng.ref, _p(out), _p(glwe_sk), params.N, params.k, params.ss_radix_log,
+                             params.ss_count, params.glwe_std)
+    return out

@@ -31,7 +31,8 @@ class _CParams(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libspf_hip.so")
+    # SPF_HIP_LIBRARY lets experiments (e.g. timing-only ablation builds) swap the library
+    return os.environ.get("SPF_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libspf_hip.so")
 
 
 # every symbol include/spf_hip.h declares: (name, restype, argtypes)

@@ -266,3 +266,40 @@ def test_cmux_selects(small_keys):
         dec = O.decrypt_glwe_raw(out, small_keys.glwe_sk, P.N, P.k)
         got = [O.decode(int(v), 3) for v in dec]
         assert got == [O.decode(int(v), 3) for v in msgs[sel]]
+
+
+# ------------------------------------------------------------------ circuit-bootstrap tail (§8 f2)
+
+
+@pytest.fixture(scope="module")
+def tail_keys(small_keys):
+    r = O.Rng(0x7A11)
+    return O.gen_auto_key_fft(r, small_keys.glwe_sk, SMALL), O.gen_ssk_fft(r, small_keys.glwe_sk, SMALL)
+
+
+def test_trace_keeps_only_the_constant_term(small_keys, tail_keys):
+    # ops/automorphisms/mod.rs tests: trace zeroes every coefficient but the constant one and
+    # multiplies it by N; pre-dividing by N (shr_round by log2 N) makes it the identity there
+    P = SMALL
+    msg = np.array([O.encode(int(v), 4) for v in np.random.default_rng(3).integers(0, 16, P.N)], dtype=np.uint64)
+    ct = O.encrypt_glwe(O.Rng(1), small_keys.glwe_sk, msg, P.N, P.k, P.glwe_std)
+    tr = O.trace(O.poly_shr_round(ct, 11), tail_keys[0], P)
+    dec = [O.decode(int(v), 4) for v in O.decrypt_glwe_raw(tr, small_keys.glwe_sk, P.N, P.k)]
+    assert dec[0] == O.decode(int(msg[0]), 4) and not any(dec[1:])
+
+
+def test_can_circuit_bootstrap_via_trace_ss(small_keys, tail_keys):
+    # circuit_bootstrapping.rs:721-805 / evaluation.rs:277-300: the GGSW a circuit bootstrap
+    # produces must drive a CMUX like a fresh GGSW encryption of the same bit
+    P = SMALL
+    ak, ssk = tail_keys
+    rng = O.Rng(9)
+    m = [np.array([O.encode(int(v), 3) for v in np.random.default_rng(s).integers(0, 8, P.N)], dtype=np.uint64)
+         for s in (1, 2)]
+    d = [O.encrypt_glwe(rng, small_keys.glwe_sk, x, P.N, P.k, P.glwe_std) for x in m]
+    for bit in (0, 1):
+        lwe = O.encrypt_lwe(O.Rng(30 + bit), small_keys.lwe_sk, O.encode(bit, 1), P.lwe_std)
+        g = O.circuit_bootstrap(lwe, small_keys.bsk_fft, ak, ssk, P)
+        out = O.cmux(d[0], d[1], g, P.N, P.k, P.cbs_radix_log, P.cbs_count)
+        dec = [O.decode(int(v), 3) for v in O.decrypt_glwe_raw(out, small_keys.glwe_sk, P.N, P.k)]
+        assert dec == [O.decode(int(v), 3) for v in m[bit]]
