@@ -57,6 +57,10 @@ typedef struct spf_params {
     uint32_t cbs_radix_count;   /* cbs_radix.count          = 4    */
     uint32_t ks_radix_log;      /* ks_radix.radix_log       = 2    */
     uint32_t ks_radix_count;    /* ks_radix.count           = 6    */
+    uint32_t tr_radix_log;      /* tr_radix.radix_log       = 7    (trace / automorphism keyswitch) */
+    uint32_t tr_radix_count;    /* tr_radix.count           = 6    */
+    uint32_t ss_radix_log;      /* ss_radix.radix_log       = 3    (scheme switch) */
+    uint32_t ss_radix_count;    /* ss_radix.count           = 15   */
 } spf_params;
 
 /* DEFAULT_128 (parasol_runtime/src/params.rs:107-134) */
@@ -79,9 +83,17 @@ spf_status spf_load_bootstrap_key(spf_ctx *ctx, const double *bsk_fft, size_t n_
 /* `ComputeKey::ks_key` : LweKeyswitchKey<u64>.  n_words = k*N * l_ks * (lwe_dimension+1). */
 spf_status spf_load_keyswitch_key(spf_ctx *ctx, const uint64_t *ksk, size_t n_words);
 
+/* `ComputeKey::auto_key` : AutomorphismKeyFft<Complex<f64>> = log2(N) GLWE keyswitch keys
+ * [i<log2 N][row<k][level<l_tr][poly<k+1][bin<N/2] (entities/automorphism_key.rs). */
+spf_status spf_load_automorphism_key(spf_ctx *ctx, const double *ak_fft, size_t n_complex);
+/* `ComputeKey::ss_key` : SchemeSwitchKeyFft<Complex<f64>> = k(k+1)/2 GLEVs
+ * [pair][level<l_ss][poly<k+1][bin<N/2] (entities/scheme_switch_key.rs). */
+spf_status spf_load_scheme_switch_key(spf_ctx *ctx, const double *ssk_fft, size_t n_complex);
+
 /* Multi-GPU key replication (no reference counterpart): the device-resident
  * key blobs, so that a caller can RCCL-broadcast rank 0's keys into every other rank's
- * context.  which: 0 = bootstrap key, 1 = keyswitch key.  Allocates the blob if needed;
+ * context.  which: 0 = bootstrap key, 1 = keyswitch key, 2 = automorphism key,
+ * 3 = scheme-switch key.  Allocates the blob if needed;
  * after filling it externally call spf_key_blob_commit. */
 spf_status spf_key_blob(spf_ctx *ctx, int which, void **dev_ptr, size_t *bytes);
 spf_status spf_key_blob_commit(spf_ctx *ctx, int which);
@@ -120,6 +132,20 @@ spf_status spf_pbs_univariate_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0
 spf_status spf_circuit_bootstrap_pbs_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0_in,
                                            uint64_t *glwe_out);
 
+/* B x `Evaluation::circuit_bootstrap` (crypto/evaluation.rs:211-226) =
+ * `circuit_bootstrap_via_trace_and_scheme_switch` (ops/bootstrapping/circuit_bootstrapping.rs:342-385):
+ * the bootstrap above, then `mod_switch_trace_and_rotate` (:260-298) and `scheme_switch_fft`
+ * (ops/fft_ops.rs:403-442).  ggsw_fft_out: B x (k+1)*l_cbs*(k+1)*N/2 complex, the layout
+ * `L1GgswCiphertext` holds and `cmux` consumes.  Needs all four keys. */
+spf_status spf_circuit_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe0_in,
+                                       double *ggsw_fft_out);
+/* B x `mod_switch_trace_and_rotate` alone: lo-noise GLWE -> GLEV (l_cbs GLWEs per ciphertext). */
+spf_status spf_mod_switch_trace_and_rotate_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in,
+                                                 uint64_t *glev_out);
+/* B x `Evaluation::scheme_switch` (crypto/evaluation.rs:231-240) = `scheme_switch_fft`:
+ * GLEV (l_cbs GLWEs) -> GGSW-FFT. */
+spf_status spf_scheme_switch_batch(spf_ctx *ctx, size_t B, const uint64_t *glev_in, double *ggsw_fft_out);
+
 /* B x `KeylessEvaluation::sample_extract_l1` (crypto/evaluation.rs:126-133) =
  * `sample_extract` (ops/ciphertext/glwe_ciphertext_ops.rs:31-76), same index for the batch. */
 spf_status spf_sample_extract_l1_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in, size_t idx,
@@ -150,6 +176,12 @@ spf_status spf_pbs_univariate_dev(spf_ctx *ctx, void *stream, size_t B, const ui
                                   uint64_t *d_lwe1_out);
 spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx *ctx, void *stream, size_t B,
                                          const uint64_t *d_lwe0_in, uint64_t *d_glwe_out);
+spf_status spf_circuit_bootstrap_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_lwe0_in,
+                                     double *d_ggsw_fft_out);
+spf_status spf_mod_switch_trace_and_rotate_dev(spf_ctx *ctx, void *stream, size_t B,
+                                               const uint64_t *d_glwe_in, uint64_t *d_glev_out);
+spf_status spf_scheme_switch_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_glev_in,
+                                 double *d_ggsw_fft_out);
 spf_status spf_sample_extract_l1_dev(spf_ctx *ctx, void *stream, size_t B,
                                      const uint64_t *d_glwe_in, size_t idx, uint64_t *d_lwe1_out);
 spf_status spf_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,

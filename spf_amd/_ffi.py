@@ -27,7 +27,8 @@ class SpfError(RuntimeError):
 class _CParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "lwe_dimension", "polynomial_degree", "glwe_size", "pbs_radix_log", "pbs_radix_count",
-        "cbs_radix_log", "cbs_radix_count", "ks_radix_log", "ks_radix_count")]
+        "cbs_radix_log", "cbs_radix_count", "ks_radix_log", "ks_radix_count", "tr_radix_log",
+        "tr_radix_count", "ss_radix_log", "ss_radix_count")]
 
 
 def lib_path() -> str:
@@ -44,12 +45,17 @@ SYMBOLS = [
     ("spf_last_error", C.c_char_p, [_P]),
     ("spf_load_bootstrap_key", _I, [_P, _P, _SZ]),
     ("spf_load_keyswitch_key", _I, [_P, _P, _SZ]),
+    ("spf_load_automorphism_key", _I, [_P, _P, _SZ]),
+    ("spf_load_scheme_switch_key", _I, [_P, _P, _SZ]),
     ("spf_key_blob", _I, [_P, _I, C.POINTER(_P), C.POINTER(_SZ)]),
     ("spf_key_blob_commit", _I, [_P, _I]),
     ("spf_keyswitch_lwe_l1_lwe_l0_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_generalized_pbs_batch", _I, [_P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
     ("spf_pbs_univariate_batch", _I, [_P, _SZ, _P, _P, _SZ, _P]),
     ("spf_circuit_bootstrap_pbs_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_mod_switch_trace_and_rotate_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_scheme_switch_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_sample_extract_l1_batch", _I, [_P, _SZ, _P, _SZ, _P]),
     ("spf_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
     ("spf_gate_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
@@ -57,6 +63,9 @@ SYMBOLS = [
     ("spf_generalized_pbs_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
     ("spf_pbs_univariate_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     ("spf_circuit_bootstrap_pbs_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_circuit_bootstrap_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_mod_switch_trace_and_rotate_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_scheme_switch_dev", _I, [_P, _P, _SZ, _P, _P]),
     ("spf_sample_extract_l1_dev", _I, [_P, _P, _SZ, _P, _SZ, _P]),
     ("spf_cmux_dev", _I, [_P, _P, _SZ, _P, _P, _P, _P]),
     ("spf_set_timing", _I, [_P, _I]),
@@ -139,6 +148,14 @@ class Engine:
         a = _u64(ksk).reshape(-1)
         self._ck(self._lib.spf_load_keyswitch_key(self._h, _ptr(a), a.size))
 
+    def load_automorphism_key(self, ak_fft: np.ndarray):
+        a = np.ascontiguousarray(ak_fft, dtype=np.complex128).reshape(-1)
+        self._ck(self._lib.spf_load_automorphism_key(self._h, _ptr(a), a.size))
+
+    def load_scheme_switch_key(self, ssk_fft: np.ndarray):
+        a = np.ascontiguousarray(ssk_fft, dtype=np.complex128).reshape(-1)
+        self._ck(self._lib.spf_load_scheme_switch_key(self._h, _ptr(a), a.size))
+
     def key_blob(self, which: int):
         """(device pointer, bytes) of the device-resident key; for RCCL broadcast."""
         p, n = C.c_void_p(), C.c_size_t()
@@ -188,6 +205,25 @@ class Engine:
         self._ck(self._lib.spf_circuit_bootstrap_pbs_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
         return out
 
+    def circuit_bootstrap(self, lwe0) -> np.ndarray:
+        """Evaluation::circuit_bootstrap: L0 LWE -> L1 GGSW-FFT (B x cbs_ggsw_complex)."""
+        x = _u64(lwe0).reshape(-1, self.params.lwe0_words)
+        out = np.empty((x.shape[0], self.params.cbs_ggsw_complex), dtype=np.complex128)
+        self._ck(self._lib.spf_circuit_bootstrap_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def mod_switch_trace_and_rotate(self, glwe) -> np.ndarray:
+        x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        out = np.empty((x.shape[0], self.params.cbs_radix_count, self.params.glwe_words), dtype=np.uint64)
+        self._ck(self._lib.spf_mod_switch_trace_and_rotate_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def scheme_switch(self, glev) -> np.ndarray:
+        x = _u64(glev).reshape(-1, self.params.cbs_radix_count * self.params.glwe_words)
+        out = np.empty((x.shape[0], self.params.cbs_ggsw_complex), dtype=np.complex128)
+        self._ck(self._lib.spf_scheme_switch_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
     def sample_extract_l1(self, glwe, idx: int) -> np.ndarray:
         x = _u64(glwe).reshape(-1, self.params.glwe_words)
         out = np.empty((x.shape[0], self.params.lwe1_words), dtype=np.uint64)
@@ -221,6 +257,9 @@ class Engine:
 
     def circuit_bootstrap_pbs_dev(self, stream: int, B: int, d_lwe: int, d_out: int):
         self._ck(self._lib.spf_circuit_bootstrap_pbs_dev(self._h, stream, B, d_lwe, d_out))
+
+    def circuit_bootstrap_dev(self, stream, B, d_lwe, d_ggsw_out):
+        self._ck(self._lib.spf_circuit_bootstrap_dev(self._h, stream, B, d_lwe, d_ggsw_out))
 
     def cmux_dev(self, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out):
         self._ck(self._lib.spf_cmux_dev(self._h, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out))

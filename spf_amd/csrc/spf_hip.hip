@@ -6,6 +6,7 @@
 // No exception leaves this file; every entry point returns spf_status.
 #include "../../include/spf_hip.h"
 #include "spf_kernels.hpp"
+#include "spf_cbs_tail.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -53,6 +54,13 @@ struct spf_ctx {
     int8_t* d_ksk_planes = nullptr; // key byte planes for the int8-MFMA keyswitch [Npad][K]
     size_t ks_npad = 0;
     DevBuf ks_dig, ks_rowsum;       // per-call digits [Mpad][K] and digit sums [Mpad]
+    c64* d_ak = nullptr;            // automorphism key, FFT'd: [log2 N][l_tr][2][N/2]
+    size_t ak_bytes = 0;
+    bool ak_ready = false;
+    c64* d_ssk = nullptr;           // scheme-switch key, FFT'd: [l_ss][2][N/2]
+    size_t ssk_bytes = 0;
+    bool ssk_ready = false;
+    DevBuf cbs_glwe, cbs_glev;      // circuit-bootstrap intermediates (lo-noise GLWE, GLEV)
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
     bool timing = false;
     std::vector<TimedLaunch> t_pbs, t_ks;
@@ -136,6 +144,17 @@ size_t glwe_words(const spf_params& p) { return (size_t)(p.glwe_size + 1) * p.po
 size_t ggsw_fft_complex(const spf_params& p, uint32_t count)
 {
     return (size_t)(p.glwe_size + 1) * count * (p.glwe_size + 1) * (p.polynomial_degree / 2);
+}
+
+size_t ak_complex(const spf_params& p)
+{
+    uint32_t logn = 0;
+    while ((1u << logn) < p.polynomial_degree) logn++;
+    return (size_t)logn * p.glwe_size * p.tr_radix_count * (p.glwe_size + 1) * (p.polynomial_degree / 2);
+}
+size_t ssk_complex(const spf_params& p)
+{
+    return (size_t)(p.glwe_size * (p.glwe_size + 1) / 2) * p.ss_radix_count * (p.glwe_size + 1) * (p.polynomial_degree / 2);
 }
 
 spf_status get_events(spf_ctx* c, hipEvent_t* a, hipEvent_t* b)
@@ -273,7 +292,7 @@ extern "C" {
 void spf_default_params(spf_params* o)
 {
     if (!o) return;
-    *o = spf_params{637, 2048, 1, 16, 2, 4, 4, 2, 6};
+    *o = spf_params{637, 2048, 1, 16, 2, 4, 4, 2, 6, 7, 6, 3, 15};
 }
 
 const char* spf_version(void) { return "spf_hip 0.2 (gfx950: two-wave blind rotation, int8-MFMA keyswitch, cbs_radix cmux)"; }
@@ -336,6 +355,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scheme_switch_kernel<15, 3>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds));
 #undef CK
     *out = c;
     return SPF_OK;
@@ -350,7 +373,7 @@ void spf_destroy(spf_ctx* c)
     for (auto& t : c->t_ks) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_ksk, (void*)c->d_cbs_lut,
                     c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->ks_dig.p,
-                    c->ks_rowsum.p})
+                    c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -369,8 +392,16 @@ spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
         size_t need = (size_t)c->prm.glwe_size * c->prm.polynomial_degree * c->prm.ks_radix_count * lwe0_words(c->prm) * 8;
         if (!c->d_ksk) { HIPCHK(c, hipMalloc((void**)&c->d_ksk, need)); c->ksk_bytes = need; }
         *dev_ptr = c->d_ksk; *bytes = c->ksk_bytes;
+    } else if (which == 2) {
+        size_t need = ak_complex(c->prm) * sizeof(c64);
+        if (!c->d_ak) { HIPCHK(c, hipMalloc((void**)&c->d_ak, need)); c->ak_bytes = need; }
+        *dev_ptr = c->d_ak; *bytes = c->ak_bytes;
+    } else if (which == 3) {
+        size_t need = ssk_complex(c->prm) * sizeof(c64);
+        if (!c->d_ssk) { HIPCHK(c, hipMalloc((void**)&c->d_ssk, need)); c->ssk_bytes = need; }
+        *dev_ptr = c->d_ssk; *bytes = c->ssk_bytes;
     } else {
-        return fail(c, SPF_ERR_INVALID_ARGUMENT, "which must be 0 (bootstrap key) or 1 (keyswitch key)");
+        return fail(c, SPF_ERR_INVALID_ARGUMENT, "which must be 0 (bootstrap), 1 (keyswitch), 2 (automorphism) or 3 (scheme switch)");
     }
     return SPF_OK;
 }
@@ -385,6 +416,8 @@ spf_status spf_key_blob_commit(spf_ctx* c, int which)
         if (st != SPF_OK) return st;
         c->ksk_ready = true;
     }
+    else if (which == 2 && c->d_ak) c->ak_ready = true;
+    else if (which == 3 && c->d_ssk) c->ssk_ready = true;
     else return fail(c, SPF_ERR_INVALID_ARGUMENT, "blob not allocated");
     return SPF_OK;
 }
@@ -459,6 +492,87 @@ spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx* c, void* stream, size_t B, con
     // hi_noise_lwe_to_lo_noise_glwe (circuit_bootstrapping.rs:387-427)
     return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count),
                                (uint64_t)1 << 62, d_out, glwe_words(c->prm), false);
+}
+
+static spf_status tail_supported(spf_ctx* c)
+{
+    const spf_params& p = c->prm;
+    if (p.cbs_radix_log != 4 || p.cbs_radix_count != 4 || p.tr_radix_log != 7 || p.tr_radix_count != 6 ||
+        p.ss_radix_log != 3 || p.ss_radix_count != 15)
+        return fail(c, SPF_ERR_UNSUPPORTED, "circuit-bootstrap tail is built for cbs 4x4, tr 6x7, ss 15x3 bits");
+    return SPF_OK;
+}
+
+static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_glwe, uint64_t* d_glev)
+{
+    if (!c->ak_ready) return fail(c, SPF_ERR_NO_KEY, "automorphism key not loaded");
+    TraceArgs a{};
+    a.glwe_in = d_glwe; a.glev_out = d_glev; a.ak = c->d_ak; a.tables = c->d_tables;
+    a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
+    a.cbs_radix_log = c->prm.cbs_radix_log;
+    dim3 grid((a.units + kWavesPerBlock - 1) / kWavesPerBlock), block(512);
+    hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTailLds, s, a);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
+static spf_status launch_scheme_switch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_glev, double* d_ggsw)
+{
+    if (!c->ssk_ready) return fail(c, SPF_ERR_NO_KEY, "scheme-switch key not loaded");
+    SchemeSwitchArgs a{};
+    a.glev = d_glev; a.ggsw_out = reinterpret_cast<c64*>(d_ggsw); a.ssk = c->d_ssk; a.tables = c->d_tables;
+    a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
+    dim3 grid((a.units + kWavesPerBlock - 1) / kWavesPerBlock), block(512);
+    hipLaunchKernelGGL((scheme_switch_kernel<15, 3>), grid, block, kTailLds, s, a);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
+spf_status spf_mod_switch_trace_and_rotate_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, uint64_t* d_glev)
+{
+    if (!c || (B && (!d_glwe || !d_glev))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    spf_status st = tail_supported(c);
+    if (st != SPF_OK) return st;
+    return launch_trace(c, (hipStream_t)stream, B, d_glwe, d_glev);
+}
+
+spf_status spf_scheme_switch_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glev, double* d_ggsw)
+{
+    if (!c || (B && (!d_glev || !d_ggsw))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    spf_status st = tail_supported(c);
+    if (st != SPF_OK) return st;
+    return launch_scheme_switch(c, (hipStream_t)stream, B, d_glev, d_ggsw);
+}
+
+spf_status spf_circuit_bootstrap_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, double* d_ggsw)
+{
+    if (!c || (B && (!d_lwe || !d_ggsw))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    spf_status st = tail_supported(c);
+    if (st != SPF_OK) return st;
+    // circuit_bootstrap_via_trace_and_scheme_switch (circuit_bootstrapping.rs:342-385)
+    st = ensure(c, c->cbs_glwe, B * glwe_words(c->prm) * 8);
+    if (st != SPF_OK) return st;
+    st = ensure(c, c->cbs_glev, B * c->prm.cbs_radix_count * glwe_words(c->prm) * 8);
+    if (st != SPF_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    st = launch_blind_rotate(c, s, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62,
+                             (uint64_t*)c->cbs_glwe.p, glwe_words(c->prm), false);
+    if (st != SPF_OK) return st;
+    st = launch_trace(c, s, B, (const uint64_t*)c->cbs_glwe.p, (uint64_t*)c->cbs_glev.p);
+    if (st != SPF_OK) return st;
+    return launch_scheme_switch(c, s, B, (const uint64_t*)c->cbs_glev.p, d_ggsw);
 }
 
 spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, size_t idx, uint64_t* d_out)
@@ -605,6 +719,93 @@ spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_
     if (s != SPF_OK) return s;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+static spf_status load_fft_key(spf_ctx* c, int which, const double* src, size_t n_complex, size_t want, bool* ready)
+{
+    if (!c || !src) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_complex != want)
+        return fail(c, SPF_ERR_INVALID_ARGUMENT, "key length " + std::to_string(n_complex) + " != " + std::to_string(want));
+    void* p; size_t bytes;
+    spf_status s = spf_key_blob(c, which, &p, &bytes);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *ready = true;
+    return SPF_OK;
+}
+
+spf_status spf_load_automorphism_key(spf_ctx* c, const double* ak_fft, size_t n_complex)
+{
+    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    return load_fft_key(c, 2, ak_fft, n_complex, ak_complex(c->prm), &c->ak_ready);
+}
+
+spf_status spf_load_scheme_switch_key(spf_ctx* c, const double* ssk_fft, size_t n_complex)
+{
+    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    return load_fft_key(c, 3, ssk_fft, n_complex, ssk_complex(c->prm), &c->ssk_ready);
+}
+
+spf_status spf_mod_switch_trace_and_rotate_batch(spf_ctx* c, size_t B, const uint64_t* glwe_in, uint64_t* glev_out)
+{
+    if (!c || (B && (!glwe_in || !glev_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t gw = glwe_words(c->prm) * 8, ev = gw * c->prm.cbs_radix_count;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->in, glwe_in, B * gw);
+        spf_status s = ensure(c, c->out, B * ev);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_mod_switch_trace_and_rotate_dev(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(glev_out, c->out.p, B * ev, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_scheme_switch_batch(spf_ctx* c, size_t B, const uint64_t* glev_in, double* ggsw_out)
+{
+    if (!c || (B && (!glev_in || !ggsw_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t ev = glwe_words(c->prm) * 8 * c->prm.cbs_radix_count;
+    const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->in, glev_in, B * ev);
+        spf_status s = ensure(c, c->out, B * sw);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_scheme_switch_dev(c, c->stream, B, (const uint64_t*)c->in.p, (double*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(ggsw_out, c->out.p, B * sw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_circuit_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe0_in, double* ggsw_out)
+{
+    if (!c || (B && (!lwe0_in || !ggsw_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->in, lwe0_in, B * lwe0_words(c->prm) * 8);
+        spf_status s = ensure(c, c->out, B * sw);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_circuit_bootstrap_dev(c, c->stream, B, (const uint64_t*)c->in.p, (double*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(ggsw_out, c->out.p, B * sw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
 }

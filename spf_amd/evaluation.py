@@ -23,6 +23,8 @@ class ComputeKey:
 
     bs_key: np.ndarray   # BootstrapKeyFft<Complex<f64>>, complex128, reference layout
     ks_key: np.ndarray   # LweKeyswitchKey<u64>
+    auto_key: np.ndarray = None  # AutomorphismKeyFft<Complex<f64>>
+    ss_key: np.ndarray = None    # SchemeSwitchKeyFft<Complex<f64>>
 
 
 class Evaluation:
@@ -34,6 +36,10 @@ class Evaluation:
         self.engine.load_bootstrap_key(compute_key.bs_key)
         if compute_key.ks_key is not None and np.size(compute_key.ks_key):
             self.engine.load_keyswitch_key(compute_key.ks_key)
+        if compute_key.auto_key is not None:
+            self.engine.load_automorphism_key(compute_key.auto_key)
+        if compute_key.ss_key is not None:
+            self.engine.load_scheme_switch_key(compute_key.ss_key)
 
     @staticmethod
     def _store(output: np.ndarray, result: np.ndarray):
@@ -48,6 +54,16 @@ class Evaluation:
     # Evaluation::keyswitch_lwe_l1_lwe_l0 (evaluation.rs:246-255)
     def keyswitch_lwe_l1_lwe_l0(self, output: np.ndarray, input: np.ndarray):
         self._store(output, self.engine.keyswitch_lwe_l1_lwe_l0(input))
+
+    # Evaluation::circuit_bootstrap (evaluation.rs:211-226): L0 LWE -> L1 GGSW (FFT domain)
+    def circuit_bootstrap(self, output: np.ndarray, input: np.ndarray):
+        if output.dtype != np.complex128:
+            raise TypeError("an L1 GGSW ciphertext is complex128 (FFT domain)")
+        output[...] = self.engine.circuit_bootstrap(input).reshape(output.shape)
+
+    # Evaluation::scheme_switch (evaluation.rs:231-240): L1 GLEV -> L1 GGSW
+    def scheme_switch(self, output: np.ndarray, input: np.ndarray):
+        output[...] = self.engine.scheme_switch(input).reshape(output.shape)
 
     # the bootstrap stage of Evaluation::circuit_bootstrap (evaluation.rs:211-226):
     # hi_noise_lwe_to_lo_noise_glwe (circuit_bootstrapping.rs:387-427).  Output: L1 GLWE whose

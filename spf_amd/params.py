@@ -16,6 +16,10 @@ class Params:
     cbs_radix_count: int = 4
     ks_radix_log: int = 2           # :122-125
     ks_radix_count: int = 6
+    tr_radix_log: int = 7           # :130-133
+    tr_radix_count: int = 6
+    ss_radix_log: int = 3           # :126-129
+    ss_radix_count: int = 15
 
     # derived sizes, in 64-bit words / complex bins
     @property
@@ -43,6 +47,17 @@ class Params:
     def cbs_ggsw_complex(self) -> int:
         k1 = self.glwe_size + 1
         return k1 * self.cbs_radix_count * k1 * (self.polynomial_degree // 2)
+
+    @property
+    def ak_complex(self) -> int:
+        k1 = self.glwe_size + 1
+        logn = self.polynomial_degree.bit_length() - 1
+        return logn * self.glwe_size * self.tr_radix_count * k1 * (self.polynomial_degree // 2)
+
+    @property
+    def ssk_complex(self) -> int:
+        k = self.glwe_size
+        return (k * (k + 1) // 2) * self.ss_radix_count * (k + 1) * (self.polynomial_degree // 2)
 
     def replace(self, **kw) -> "Params":
         return replace(self, **kw)

@@ -34,7 +34,8 @@ def test_default_params_match_reference(lib):
     got = {n: getattr(p, n) for n, _ in _ffi._CParams._fields_}
     assert got == dict(lwe_dimension=637, polynomial_degree=2048, glwe_size=1, pbs_radix_log=16,
                        pbs_radix_count=2, cbs_radix_log=4, cbs_radix_count=4, ks_radix_log=2,
-                       ks_radix_count=6)  # parasol_runtime/src/params.rs:107-134
+                       ks_radix_count=6, tr_radix_log=7, tr_radix_count=6, ss_radix_log=3,
+                       ss_radix_count=15)  # parasol_runtime/src/params.rs:107-134
     assert spf_amd.DEFAULT_128.bsk_complex * 16 == 83_492_864
     assert spf_amd.DEFAULT_128.ksk_words * 8 == 62_717_952
 
