@@ -49,6 +49,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
     ap.add_argument("--with-cmux", action="store_true", help="also time the batched cbs_radix CMUX kernel")
+    ap.add_argument("--with-cbs", action="store_true", help="also time Evaluation::circuit_bootstrap end to end")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -165,6 +166,33 @@ def main() -> int:
         step()
         torch.cuda.synchronize()
 
+    cbs = None
+    if args.with_cbs:
+        # Evaluation::circuit_bootstrap end to end: PBS -> trace (4 x 11 GLWE keyswitches) -> scheme switch
+        for which, scale in ((2, 2.0 ** 67), (3, 2.0 ** 67)):
+            ptr, nbytes = eng.key_blob(which)
+            t = torch.as_tensor(_DevArray(ptr, nbytes), device=dev)
+            if rank == 0:
+                t.copy_((torch.randn(nbytes // 8, generator=g, device=dev, dtype=torch.float64) * scale).view(torch.uint8))
+            if world > 1:
+                broadcast_keys([t], dist, src=0)
+            torch.cuda.synchronize()
+            eng.key_blob_commit(which)
+        ggsw = torch.empty((B, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
+        eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
+        barrier()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
+        barrier()
+        tc = time.perf_counter() - tc
+        if world > 1:
+            tc = max_over_ranks(tc, dist, device=dev)
+        cbs = {"circuit_bootstraps_per_s": round(world * B * args.steps / tc, 1), "ms_per_batch": round(tc / args.steps * 1e3, 3)}
+        del ggsw
+        step()   # restore the plain-PBS output for the parity sample
+        torch.cuda.synchronize()
+
     cmux = None
     if args.with_cmux:
         # KeylessEvaluation::cmux over a batch: every ciphertext brings its own 256 KiB GGSW
@@ -253,6 +281,8 @@ def main() -> int:
             line["gate"] = gate
         if cmux:
             line["cmux"] = cmux
+        if cbs:
+            line["circuit_bootstrap"] = cbs
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

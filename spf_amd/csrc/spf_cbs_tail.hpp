@@ -24,33 +24,34 @@ struct PairCtx {
     int lane, w, me, partner;
 };
 
+// value select on the (wave-uniform) parity: written with scalar selects rather than branches on
+// purpose — branching over struct copies makes hipcc select between *addresses* of register
+// arrays, which pins them in scratch memory.
+__device__ __forceinline__ c64 sel(bool pick_b, c64 a, c64 b)
+{
+    return {pick_b ? b.re : a.re, pick_b ? b.im : a.im};
+}
+
 // forward negacyclic transform of the ciphertext's 16 samples per lane pair: wave w brings its 8
 // twisted samples V and leaves with its 8 bins X (bin = lane + 64(4w + (r&3)) + 512(r>>2)).
 __device__ __forceinline__ void pair_forward(const PairCtx& c, uint32_t& seq, c64 (&V)[8], c64 (&X)[8])
 {
+    const bool odd = c.w != 0;
     pair_barrier(c.flags, c.me, c.partner, seq); // partner is done reading my region
     fft512_single<+1>(V, c.mine, c.tab, c.lane);
-    c64 Ei[4], Oi[4];
-    if (c.w == 0) {
+    // radix-2 stage across the two waves: wave 0 finishes bins d < 4 (keeps E[0..3], needs O[0..3]),
+    // wave 1 bins d >= 4 (keeps O[4..7], needs E[4..7])
 #pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = V[4 + i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = V[i];
-    }
+    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, V[4 + i], V[i]);
     pair_barrier(c.flags, c.me, c.partner, seq);
-    if (c.w == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { Ei[i] = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane]; Oi[i] = V[4 + i]; }
-    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        c64 t = cmul_tw<+1>(Oi[i], c.wc[64 * i]);
-        X[i] = cadd(Ei[i], t);
-        X[i + 4] = csub(Ei[i], t);
+        c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
+        c64 Ei = sel(odd, V[i], got);
+        c64 Oi = sel(odd, got, V[4 + i]);
+        c64 t = cmul_tw<+1>(Oi, c.wc[64 * i]);
+        X[i] = cadd(Ei, t);
+        X[i + 4] = csub(Ei, t);
     }
 }
 
@@ -58,6 +59,7 @@ __device__ __forceinline__ void pair_forward(const PairCtx& c, uint32_t& seq, c6
 // reduced doubles: tv[n1] = coefficient (half 0, n1), tv[8+n1] = (half 1, n1)
 __device__ __forceinline__ void pair_inverse(const PairCtx& c, uint32_t& seq, const c64 (&P)[8], double (&tv)[16])
 {
+    const bool odd = c.w != 0;
     c64 Ep[4], Op[4], V[8];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -66,20 +68,15 @@ __device__ __forceinline__ void pair_inverse(const PairCtx& c, uint32_t& seq, co
         Op[i] = cmul_tw<-1>(dd, c.wc[64 * i]);
     }
     pair_barrier(c.flags, c.me, c.partner, seq);
-    if (c.w == 0) {
+    // wave 0 keeps E'[0..3] and needs E'[4..7]; wave 1 keeps O'[4..7] and needs O'[0..3]
 #pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = Op[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = Ep[i];
-    }
+    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, Op[i], Ep[i]);
     pair_barrier(c.flags, c.me, c.partner, seq);
-    if (c.w == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane]; V[4 + i] = Op[i]; }
+    for (int i = 0; i < 4; i++) {
+        c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
+        V[i] = sel(odd, Ep[i], got);
+        V[4 + i] = sel(odd, got, Op[i]);
     }
     pair_barrier(c.flags, c.me, c.partner, seq);
     fft512_single<-1>(V, c.mine, c.tab, c.lane);
@@ -119,6 +116,26 @@ __device__ __forceinline__ void mad8(c64 (&acc)[8], const c64 (&k)[8], const c64
     }
 }
 
+// acc += key_row * X over this wave's 8 bins, the key streamed 4 bins at a time so that only 16
+// registers of key are live at once
+__device__ __forceinline__ void mad_row(c64 (&acc)[8], const c64* row_w_lane, const c64 (&X)[8])
+{
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+        c64 k[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[i] = row_w_lane[64 * i + 512 * hh];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = i + 4 * hh;
+            double re = __builtin_fma(k[i].re, X[r].re, acc[r].re);
+            double im = __builtin_fma(k[i].re, X[r].im, acc[r].im);
+            acc[r].re = __builtin_fma(-k[i].im, X[r].im, re);
+            acc[r].im = __builtin_fma(k[i].im, X[r].re, im);
+        }
+    }
+}
+
 // this wave's 8 bins of a 1024-bin row: index r -> bin lane + 64(4w + (r&3)) + 512(r>>2)
 __device__ __forceinline__ void load_bins(c64 (&k)[8], const c64* row_w_lane)
 {
@@ -148,6 +165,7 @@ template <int LOGB> __device__ __forceinline__ int next_digit(uint64_t& s)
 }
 
 constexpr int kTailLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
+constexpr int kTraceLds = kTailLds + 8 * 8192; // + the parked mask half of each wave's accumulator
 
 struct TraceArgs {
     const uint64_t* glwe_in; // B x 4096: lo-noise GLWE out of the bootstrap
@@ -185,8 +203,12 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
     const uint32_t ct = unit / a.cbs_count, lvl = unit % a.cbs_count;
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
-    // x = shr_round( (glwe with body coefficients 0..lvl un-rotated) * X^-lvl , log2 N )
-    uint64_t acc[2][16];
+    // x = shr_round( (glwe with body coefficients 0..lvl un-rotated) * X^-lvl , log2 N ).
+    // The accumulator's body half lives in registers (acc_b); its mask half, touched only twice
+    // per round, is parked in this wave's private 8 KiB of the LDS the key ring uses elsewhere
+    // (park[e*64 + lane]): that keeps the kernel inside 256 VGPRs without scratch.
+    uint64_t* park = reinterpret_cast<uint64_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes + 64 + wv * 8192);
+    uint64_t acc_b[16];
     {
         const uint64_t* g = a.glwe_in + (size_t)ct * 2 * kN;
 #pragma unroll
@@ -199,7 +221,8 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
                 if (p == 1 && src <= lvl) // glwe_rotated.b[t] += encode(1, cbs_radix_log*(t+1)+1), t <= lvl
                     v += (uint64_t)1 << (64 - (a.cbs_radix_log * (src + 1) + 1));
                 v = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                acc[p][e] = (v >> 11) + ((v >> 10) & 1); // glwe_mod_switch_and_expand_pow_2
+                v = (v >> 11) + ((v >> 10) & 1); // glwe_mod_switch_and_expand_pow_2
+                if (p == 0) park[e * 64 + lane] = v; else acc_b[e] = v;
             }
     }
     __syncthreads();
@@ -218,7 +241,8 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
         for (int p = 0; p < 2; p++) {
             pair_barrier(flags, pc.me, pc.partner, seq);
 #pragma unroll
-            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
+            for (int e = 0; e < 16; e++)
+                stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = p == 0 ? park[e * 64 + lane] : acc_b[e];
             pair_barrier(flags, pc.me, pc.partner, seq);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
                 uint64_t v = reinterpret_cast<const uint64_t*>(tile + (src & 1) * 8192)[src >> 1];
                 v = (cp >> 11) ? (uint64_t)0 - v : v;
                 if (p == 0) st[e] = radix_round_state<L, LOGB>(v); // keyswitch decomposes the mask
-                else acc[1][e] += v;                                // out.b += trivial(b_k) ...
+                else acc_b[e] += v;                                 // out.b += trivial(b_k) ...
             }
         }
         c64 prod[2][8];
@@ -247,11 +271,9 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
                 V[n1] = cmul_nf({(double)dre, (double)dim}, pc.twist[64 * n1]);
             }
             pair_forward(pc, seq, V, X);
-            c64 k0[8]; // key rows are shared by every unit (L2-resident); the SIMD partner covers the trip
-            load_bins(k0, row);
-            mad8(prod[0], k0, X);
-            load_bins(k0, row + kHalf);
-            mad8(prod[1], k0, X);
+            // key rows are shared by every unit (L2-resident); the SIMD partner covers the trip
+            mad_row(prod[0], row, X);
+            mad_row(prod[1], row + kHalf, X);
         }
         // ... - sum_i <decomp(a_i), glev_i>  (fft_ops.rs:489-494)
 #pragma unroll
@@ -261,15 +283,18 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
             pair_inverse(pc, seq, prod[q], tv);
             tv_to_torus(tv, s);
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[q][e] -= s[e];
+            for (int e = 0; e < 16; e++) {
+                if (q == 0) park[e * 64 + lane] -= s[e]; else acc_b[e] -= s[e];
+            }
         }
     }
     if (!owns_output) return;
     uint64_t* out = a.glev_out + (size_t)unit * 2 * kN;
 #pragma unroll
-    for (int p = 0; p < 2; p++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
+    for (int e = 0; e < 16; e++) {
+        out[coef2(e)] = park[e * 64 + lane];
+        out[kN + coef2(e)] = acc_b[e];
+    }
 }
 
 struct SchemeSwitchArgs {
@@ -349,11 +374,8 @@ __global__ __launch_bounds__(512, 2) void scheme_switch_kernel(SchemeSwitchArgs 
             V[n1] = cmul_nf({(double)dre, (double)dim}, pc.twist[64 * n1]);
         }
         pair_forward(pc, seq, V, X);
-        c64 k0[8];
-        load_bins(k0, row);
-        mad8(prod[0], k0, X);
-        load_bins(k0, row + kHalf);
-        mad8(prod[1], k0, X);
+        mad_row(prod[0], row, X);
+        mad_row(prod[1], row + kHalf, X);
     }
     if (!owns_output) return;
     store_bins(out_row0, prod[0]);

@@ -356,7 +356,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds));
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kTraceLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scheme_switch_kernel<15, 3>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds));
 #undef CK
@@ -511,7 +511,7 @@ static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
     a.cbs_radix_log = c->prm.cbs_radix_log;
     dim3 grid((a.units + kWavesPerBlock - 1) / kWavesPerBlock), block(512);
-    hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTailLds, s, a);
+    hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTraceLds, s, a);
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }
