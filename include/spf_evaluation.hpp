@@ -27,6 +27,10 @@ struct ComputeKey {
     size_t bs_key_complex;
     const uint64_t* ks_key; // LweKeyswitchKey<u64>
     size_t ks_key_words;
+    const double* auto_key = nullptr; // AutomorphismKeyFft<Complex<f64>>
+    size_t auto_key_complex = 0;
+    const double* ss_key = nullptr;   // SchemeSwitchKeyFft<Complex<f64>>
+    size_t ss_key_complex = 0;
 };
 
 class Evaluation {
@@ -37,6 +41,8 @@ class Evaluation {
         check(spf_create(&params, device, &ctx_), nullptr);
         check(spf_load_bootstrap_key(ctx_, key.bs_key, key.bs_key_complex), ctx_);
         if (key.ks_key) check(spf_load_keyswitch_key(ctx_, key.ks_key, key.ks_key_words), ctx_);
+        if (key.auto_key) check(spf_load_automorphism_key(ctx_, key.auto_key, key.auto_key_complex), ctx_);
+        if (key.ss_key) check(spf_load_scheme_switch_key(ctx_, key.ss_key, key.ss_key_complex), ctx_);
     }
     // Evaluation::with_default_params (evaluation.rs:200-204)
     static Evaluation with_default_params(const ComputeKey& key, int device = 0)
@@ -62,6 +68,16 @@ class Evaluation {
     void keyswitch_lwe_l1_lwe_l0(uint64_t* output, const uint64_t* input, size_t B = 1)
     {
         check(spf_keyswitch_lwe_l1_lwe_l0_batch(ctx_, B, input, output), ctx_);
+    }
+    // Evaluation::circuit_bootstrap(&mut L1GgswCiphertext, &L0LweCiphertext) (:211)
+    void circuit_bootstrap(double* output_ggsw_fft, const uint64_t* input_l0, size_t B = 1)
+    {
+        check(spf_circuit_bootstrap_batch(ctx_, B, input_l0, output_ggsw_fft), ctx_);
+    }
+    // Evaluation::scheme_switch(&mut L1GgswCiphertext, &L1GlevCiphertext) (:231)
+    void scheme_switch(double* output_ggsw_fft, const uint64_t* input_glev, size_t B = 1)
+    {
+        check(spf_scheme_switch_batch(ctx_, B, input_glev, output_ggsw_fft), ctx_);
     }
     // bootstrap stage of Evaluation::circuit_bootstrap (:211) = hi_noise_lwe_to_lo_noise_glwe
     void circuit_bootstrap_pbs(uint64_t* output_glwe, const uint64_t* input_l0, size_t B = 1)

@@ -75,7 +75,7 @@ def test_c_header_is_plain_c_and_cpp_mirror_compiles(tmp_path):
     c.write_text('#include "spf_hip.h"\nint main(void){spf_params p; spf_default_params(&p); return (int)p.glwe_size - 1;}\n')
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(c)], check=True)
     cpp = tmp_path / "t.cpp"
-    cpp.write_text('#include "spf_evaluation.hpp"\nint main(){ spf::ComputeKey k{nullptr,0,nullptr,0}; (void)k; return 0; }\n')
+    cpp.write_text('#include "spf_evaluation.hpp"\nint main(){ spf::ComputeKey k{nullptr,0,nullptr,0,nullptr,0,nullptr,0}; (void)k; return 0; }\n')
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], check=True)
     # and a real link + run against the built library (no GPU call: version + params only)
     exe = tmp_path / "t"
