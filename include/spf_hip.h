@@ -187,6 +187,32 @@ spf_status spf_sample_extract_l1_dev(spf_ctx *ctx, void *stream, size_t B,
 spf_status spf_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,
                         const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
 
+/* ---- call coalescing: many threads, one ciphertext each -> one batch per launch ----------
+ * The reference calls `Evaluation` from many rayon workers with a single ciphertext per call
+ * (circuit_processor/mod.rs:192-253).  A pool keeps that calling convention — submit, then wait
+ * like the synchronous call it replaces — while a worker thread runs whatever is pending of one
+ * kind as ONE batch (up to max_batch operations, or max_wait_us after the oldest arrived).
+ * Input and output buffers must stay valid until spf_pool_wait returns for their ticket.
+ * spf_pool_wait returns the status of the batch the operation ran in (first-error-wins per
+ * batch, as circuit_processor/mod.rs:214-223 does per graph). */
+typedef struct spf_pool spf_pool;
+spf_status spf_pool_create(spf_ctx *ctx, size_t max_batch, uint32_t max_wait_us, spf_pool **out);
+void spf_pool_destroy(spf_pool *pool); /* drains pending work first */
+/* `Evaluation::keyswitch_lwe_l1_lwe_l0` for one ciphertext */
+spf_status spf_pool_submit_keyswitch(spf_pool *pool, const uint64_t *lwe1_in, uint64_t *lwe0_out, uint64_t *ticket);
+/* `Evaluation::circuit_bootstrap` for one ciphertext */
+spf_status spf_pool_submit_circuit_bootstrap(spf_pool *pool, const uint64_t *lwe0_in, double *ggsw_fft_out,
+                                             uint64_t *ticket);
+/* FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap for one ciphertext (L1 LWE in, L1 GGSW out) */
+spf_status spf_pool_submit_keyswitch_circuit_bootstrap(spf_pool *pool, const uint64_t *lwe1_in,
+                                                       double *ggsw_fft_out, uint64_t *ticket);
+/* `KeylessEvaluation::cmux` for one gate */
+spf_status spf_pool_submit_cmux(spf_pool *pool, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
+                                uint64_t *out, uint64_t *ticket);
+spf_status spf_pool_wait(spf_pool *pool, uint64_t ticket);
+/* operations completed and batches launched so far (ops / launches = achieved batch size) */
+spf_status spf_pool_stats(spf_pool *pool, uint64_t *ops, uint64_t *launches);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------- */
 
 /* Average device time in milliseconds of the `reps` most recent blind-rotation launches made

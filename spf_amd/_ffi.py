@@ -68,6 +68,14 @@ SYMBOLS = [
     ("spf_scheme_switch_dev", _I, [_P, _P, _SZ, _P, _P]),
     ("spf_sample_extract_l1_dev", _I, [_P, _P, _SZ, _P, _SZ, _P]),
     ("spf_cmux_dev", _I, [_P, _P, _SZ, _P, _P, _P, _P]),
+    ("spf_pool_create", _I, [_P, _SZ, _U32, C.POINTER(_P)]),
+    ("spf_pool_destroy", None, [_P]),
+    ("spf_pool_submit_keyswitch", _I, [_P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_circuit_bootstrap", _I, [_P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_keyswitch_circuit_bootstrap", _I, [_P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_cmux", _I, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_wait", _I, [_P, _U64]),
+    ("spf_pool_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spf_set_timing", _I, [_P, _I]),
     ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
     ("spf_version", C.c_char_p, []),
@@ -275,3 +283,71 @@ class Engine:
         ms, n = C.c_double(), C.c_int()
         self._ck(self._lib.spf_last_kernel_ms(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Pool:
+    """Call-coalescing front end (`spf_pool`): many threads submit single-ciphertext operations and
+    block in wait(); a worker thread runs what is pending as one batch.  The synchronous methods
+    below are what a per-op caller (the reference's rayon task) would use."""
+
+    def __init__(self, engine: Engine, max_batch: int = 4096, max_wait_us: int = 200):
+        self._lib = engine._lib
+        self.engine = engine
+        h = C.c_void_p()
+        st = self._lib.spf_pool_create(engine._h, max_batch, max_wait_us, C.byref(h))
+        if st != 0:
+            raise SpfError(st, "spf_pool_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.spf_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _wait(self, ticket):
+        st = self._lib.spf_pool_wait(self._h, ticket)
+        if st != 0:
+            raise SpfError(st, (self._lib.spf_last_error(self.engine._h) or b"").decode())
+
+    def keyswitch_lwe_l1_lwe_l0(self, output: np.ndarray, input: np.ndarray):
+        t = C.c_uint64()
+        x = _u64(input)
+        st = self._lib.spf_pool_submit_keyswitch(self._h, _ptr(x), _ptr(output), C.byref(t))
+        if st != 0:
+            raise SpfError(st, "submit failed")
+        self._wait(t.value)
+
+    def circuit_bootstrap(self, output: np.ndarray, input: np.ndarray):
+        t = C.c_uint64()
+        x = _u64(input)
+        st = self._lib.spf_pool_submit_circuit_bootstrap(self._h, _ptr(x), _ptr(output), C.byref(t))
+        if st != 0:
+            raise SpfError(st, "submit failed")
+        self._wait(t.value)
+
+    def keyswitch_circuit_bootstrap(self, output: np.ndarray, input_l1: np.ndarray):
+        t = C.c_uint64()
+        x = _u64(input_l1)
+        st = self._lib.spf_pool_submit_keyswitch_circuit_bootstrap(self._h, _ptr(x), _ptr(output), C.byref(t))
+        if st != 0:
+            raise SpfError(st, "submit failed")
+        self._wait(t.value)
+
+    def cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
+        t = C.c_uint64()
+        s_, a_, b_ = np.ascontiguousarray(sel, dtype=np.complex128), _u64(a), _u64(b)
+        st = self._lib.spf_pool_submit_cmux(self._h, _ptr(s_), _ptr(a_), _ptr(b_), _ptr(output), C.byref(t))
+        if st != 0:
+            raise SpfError(st, "submit failed")
+        self._wait(t.value)
+
+    def stats(self):
+        ops, launches = C.c_uint64(), C.c_uint64()
+        self._lib.spf_pool_stats(self._h, C.byref(ops), C.byref(launches))
+        return ops.value, launches.value

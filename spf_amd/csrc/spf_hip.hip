@@ -67,6 +67,8 @@ struct spf_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
 
+#include "spf_pool.hpp"
+
 namespace {
 
 spf_status fail(spf_ctx* c, spf_status s, const std::string& msg)
@@ -863,6 +865,70 @@ spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, in
     v->clear();
     *avg_ms = n ? total / n : 0.0;
     *launches = n;
+    return SPF_OK;
+}
+
+// ---------------------------------------------------------------- call-coalescing pool
+
+spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, spf_pool** out)
+{
+    if (!c || !out || max_batch == 0) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument or max_batch == 0");
+    spf_pool* p = new (std::nothrow) spf_pool();
+    if (!p) return fail(c, SPF_ERR_HIP, "out of host memory");
+    p->ctx = c; p->prm = c->prm; p->max_batch = max_batch;
+    p->max_wait = std::chrono::microseconds(max_wait_us);
+    p->worker = std::thread([p] { p->loop(); });
+    *out = p;
+    return SPF_OK;
+}
+
+void spf_pool_destroy(spf_pool* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_work.notify_all();
+    if (p->worker.joinable()) p->worker.join();
+    delete p;
+}
+
+spf_status spf_pool_submit_keyswitch(spf_pool* p, const uint64_t* in, uint64_t* out, uint64_t* ticket)
+{
+    return p ? p->submit(spf_pool_impl::OP_KEYSWITCH, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+}
+spf_status spf_pool_submit_circuit_bootstrap(spf_pool* p, const uint64_t* in, double* out, uint64_t* ticket)
+{
+    return p ? p->submit(spf_pool_impl::OP_CBS, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+}
+spf_status spf_pool_submit_keyswitch_circuit_bootstrap(spf_pool* p, const uint64_t* in, double* out, uint64_t* ticket)
+{
+    return p ? p->submit(spf_pool_impl::OP_GATE_CBS, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+}
+spf_status spf_pool_submit_cmux(spf_pool* p, const double* sel, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                                uint64_t* ticket)
+{
+    if (!p || !a || !b) return SPF_ERR_INVALID_ARGUMENT;
+    return p->submit(spf_pool_impl::OP_CMUX, sel, a, b, out, ticket);
+}
+
+spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (ticket == 0 || ticket >= p->next_ticket) return SPF_ERR_INVALID_ARGUMENT;
+    p->cv_done.wait(lk, [&] { return p->done.count(ticket) != 0; });
+    spf_status st = p->done[ticket];
+    p->done.erase(ticket);
+    return st;
+}
+
+spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
+{
+    if (!p || !ops || !launches) return SPF_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(p->mu);
+    *ops = p->n_ops; *launches = p->n_launches;
     return SPF_OK;
 }
 

@@ -1,0 +1,80 @@
+"""The call-coalescing pool: many threads call single-ciphertext operations the way
+the reference's rayon tasks call `Evaluation` (circuit_processor/mod.rs:192-253); the pool must
+return exactly what the batch entry points return, and must actually coalesce."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle as O
+import spf_amd
+from tests.util import keyset, random_glwe, random_lwe_batch, to_engine_params
+
+pytestmark = pytest.mark.gpu
+
+SMALL_N = 12
+
+
+@pytest.fixture(scope="module")
+def rig():
+    ks = keyset(0x5EED0001, SMALL_N)
+    P = ks.params
+    r = O.Rng(0x7A11)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(O.gen_auto_key_fft(r, ks.glwe_sk, P))
+    eng.load_scheme_switch_key(O.gen_ssk_fft(r, ks.glwe_sk, P))
+    return ks, eng
+
+
+def test_pool_matches_batch_entry_points_and_coalesces(rig):
+    ks, eng = rig
+    P = ks.params
+    n_ops = 96
+    lwe1 = random_lwe_batch(1, n_ops, P.N * P.k)
+    a = random_glwe(2, n_ops, P.glwe_len)
+    b = random_glwe(3, n_ops, P.glwe_len)
+    # expected, through the ordinary batch entry points
+    exp_ggsw = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(lwe1))
+    exp_mux = eng.cmux(exp_ggsw, a, b)
+
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=20000)
+    ggsw = np.zeros((n_ops, eng.params.cbs_ggsw_complex), dtype=np.complex128)
+    mux = np.zeros((n_ops, P.glwe_len), dtype=np.uint64)
+
+    def gate(i):  # what one rayon task of the reference does: convert its bit, then use it
+        pool.keyswitch_circuit_bootstrap(ggsw[i], lwe1[i])
+        pool.cmux(mux[i], ggsw[i], a[i], b[i])
+        return i
+
+    with ThreadPoolExecutor(max_workers=48) as ex:
+        assert sorted(ex.map(gate, range(n_ops))) == list(range(n_ops))
+    ops, launches = pool.stats()
+    pool.close()
+    assert np.array_equal(ggsw.view(np.float64), exp_ggsw.view(np.float64))
+    assert np.array_equal(mux, exp_mux)
+    assert ops == 2 * n_ops
+    assert launches < ops / 4, (ops, launches)   # it really batched
+
+
+def test_pool_single_caller_and_keyswitch(rig):
+    ks, eng = rig
+    P = ks.params
+    pool = spf_amd.Pool(eng, max_batch=8, max_wait_us=100)
+    lwe1 = random_lwe_batch(9, 3, P.N * P.k)
+    for i in range(3):
+        out = np.zeros(P.lwe_n + 1, dtype=np.uint64)
+        pool.keyswitch_lwe_l1_lwe_l0(out, lwe1[i])
+        assert np.array_equal(out, O.keyswitch_lwe(lwe1[i], ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count))
+    pool.close()
+
+
+def test_pool_reports_errors_to_the_waiter():
+    ks = keyset(0x5EED0001, SMALL_N)
+    eng = spf_amd.Engine(to_engine_params(ks.params))      # no keys loaded
+    pool = spf_amd.Pool(eng, max_batch=4, max_wait_us=100)
+    out = np.zeros(eng.params.cbs_ggsw_complex, dtype=np.complex128)
+    with pytest.raises(spf_amd.SpfError):
+        pool.circuit_bootstrap(out, random_lwe_batch(1, 1, SMALL_N)[0])
+    pool.close()
