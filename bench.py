@@ -81,7 +81,11 @@ def main() -> int:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     P = spf_amd.DEFAULT_128
-    spf_amd.build_library()
+    # only one rank (re)builds the library if it is stale; the others wait for it
+    if rank == 0:
+        spf_amd.build_library()
+    if world > 1:
+        dist.barrier(device_ids=[local_dev]) if args.backend == "nccl" else dist.barrier()
     eng = spf_amd.Engine(P, device=local_dev)
 
     # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob

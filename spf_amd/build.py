@@ -40,8 +40,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", OUT, SRC]
+    # compile beside the target and rename atomically, so a concurrent loader (another rank of a
+    # multi-GPU launch) never sees a half-written library
+    tmp = f"{OUT}.{os.getpid()}.tmp"
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
