@@ -158,6 +158,16 @@ spf_status spf_sample_extract_l1_batch(spf_ctx *ctx, size_t B, const uint64_t *g
 spf_status spf_cmux_batch(spf_ctx *ctx, size_t B, const double *sel_ggsw_fft, const uint64_t *a,
                           const uint64_t *b, uint64_t *out);
 
+/* B x `KeylessEvaluation::glev_cmux` (crypto/evaluation.rs:86-101) = `glev_cmux`
+ * (ops/fft_ops.rs:203-220): one selector per item; a / b / out are GLEVs of l_cbs GLWEs
+ * (B x l_cbs x (k+1)*N words). */
+spf_status spf_glev_cmux_batch(spf_ctx *ctx, size_t B, const double *sel_ggsw_fft, const uint64_t *a,
+                               const uint64_t *b, uint64_t *out);
+/* B x `KeylessEvaluation::multiply_glwe_ggsw` (crypto/evaluation.rs:104-123):
+ * out = IFFT(glwe [*] ggsw), `glwe_ggsw_mad` into a cleared accumulator (ops/fft_ops.rs:23-56). */
+spf_status spf_multiply_glwe_ggsw_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe, const double *ggsw_fft,
+                                        uint64_t *out);
+
 /* The north-star "gate": keyswitch L1->L0 then the circuit-bootstrap PBS, fused on device
  * (FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, circuit_processor/mod.rs:329-340,453-463).
  * lwe1_in: B x (k*N+1); glwe_out: B x (k+1)*N. */
@@ -186,6 +196,10 @@ spf_status spf_sample_extract_l1_dev(spf_ctx *ctx, void *stream, size_t B,
                                      const uint64_t *d_glwe_in, size_t idx, uint64_t *d_lwe1_out);
 spf_status spf_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,
                         const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+spf_status spf_glev_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,
+                             const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+spf_status spf_multiply_glwe_ggsw_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_glwe,
+                                      const double *d_ggsw_fft, uint64_t *d_out);
 
 /* ---- call coalescing: many threads, one ciphertext each -> one batch per launch ----------
  * The reference calls `Evaluation` from many rayon workers with a single ciphertext per call

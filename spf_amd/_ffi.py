@@ -58,6 +58,10 @@ SYMBOLS = [
     ("spf_scheme_switch_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_sample_extract_l1_batch", _I, [_P, _SZ, _P, _SZ, _P]),
     ("spf_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
+    ("spf_glev_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
+    ("spf_multiply_glwe_ggsw_batch", _I, [_P, _SZ, _P, _P, _P]),
+    ("spf_glev_cmux_dev", _I, [_P, _P, _SZ, _P, _P, _P, _P]),
+    ("spf_multiply_glwe_ggsw_dev", _I, [_P, _P, _SZ, _P, _P, _P]),
     ("spf_gate_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_keyswitch_lwe_l1_lwe_l0_dev", _I, [_P, _P, _SZ, _P, _P]),
     ("spf_generalized_pbs_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
@@ -244,6 +248,22 @@ class Engine:
         b = _u64(b).reshape(-1, self.params.glwe_words)
         out = np.empty_like(a)
         self._ck(self._lib.spf_cmux_batch(self._h, a.shape[0], _ptr(g), _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def glev_cmux(self, sel_ggsw_fft, a, b) -> np.ndarray:
+        n = self.params.cbs_radix_count * self.params.glwe_words
+        g = np.ascontiguousarray(sel_ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
+        a = _u64(a).reshape(-1, n)
+        b = _u64(b).reshape(-1, n)
+        out = np.empty_like(a)
+        self._ck(self._lib.spf_glev_cmux_batch(self._h, a.shape[0], _ptr(g), _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def multiply_glwe_ggsw(self, glwe, ggsw_fft) -> np.ndarray:
+        g = np.ascontiguousarray(ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
+        x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        out = np.empty_like(x)
+        self._ck(self._lib.spf_multiply_glwe_ggsw_batch(self._h, x.shape[0], _ptr(x), _ptr(g), _ptr(out)))
         return out
 
     def gate_bootstrap(self, lwe1) -> np.ndarray:

@@ -590,24 +590,52 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     return SPF_OK;
 }
 
+static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t per_ggsw, const double* d_sel,
+                              const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out)
+{
+    if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
+        return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
+    if (units == 0) return SPF_OK;
+    if (units > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    CmuxArgs a{};
+    // cmux(c, d_0 = a, d_1 = b, b_fft = sel) (crypto/evaluation.rs:68-83); d_a == nullptr means the
+    // zero ciphertext (multiply_glwe_ggsw)
+    a.ggsw = reinterpret_cast<const c64*>(d_sel); a.d0 = d_a ? d_a : d_b; a.d1 = d_b; a.out = d_out;
+    a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = per_ggsw; a.d0_zero = d_a ? 0u : 1u;
+    dim3 grid((unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
+    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, s, a);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
 spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel, const uint64_t* d_a, const uint64_t* d_b,
                         uint64_t* d_out)
 {
     if (!c || (B && (!d_sel || !d_a || !d_b || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
-        return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
-    if (B == 0) return SPF_OK;
-    if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    CmuxArgs a{};
-    // cmux(c, d_0 = a, d_1 = b, b_fft = sel) (crypto/evaluation.rs:68-83)
-    a.ggsw = reinterpret_cast<const c64*>(d_sel); a.d0 = d_a; a.d1 = d_b; a.out = d_out;
-    a.tables = c->d_tables; a.B = (uint32_t)B;
-    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
-    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, (hipStream_t)stream, a);
-    HIPCHK(c, hipGetLastError());
-    return SPF_OK;
+    return launch_cmux(c, (hipStream_t)stream, B, 1, d_sel, d_a, d_b, d_out);
+}
+
+// KeylessEvaluation::glev_cmux (crypto/evaluation.rs:86-101) = glev_cmux (ops/fft_ops.rs:203-220):
+// a cmux over each of the l_cbs GLWEs of two GLEVs with one selector
+spf_status spf_glev_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel, const uint64_t* d_a,
+                             const uint64_t* d_b, uint64_t* d_out)
+{
+    if (!c || (B && (!d_sel || !d_a || !d_b || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_cmux(c, (hipStream_t)stream, B * c->prm.cbs_radix_count, c->prm.cbs_radix_count, d_sel, d_a, d_b, d_out);
+}
+
+// KeylessEvaluation::multiply_glwe_ggsw (crypto/evaluation.rs:104-123): out = IFFT(glwe [*] ggsw)
+spf_status spf_multiply_glwe_ggsw_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, const double* d_ggsw,
+                                      uint64_t* d_out)
+{
+    if (!c || (B && (!d_glwe || !d_ggsw || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_cmux(c, (hipStream_t)stream, B, 1, d_ggsw, nullptr, d_glwe, d_out);
 }
 
 // ---------------------------------------------------------------- host-pointer forms
@@ -718,6 +746,51 @@ spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_
     }
     spf_status s = spf_cmux_dev(c, c->stream, B, (const double*)c->aux.p, (const uint64_t*)c->in.p,
                                 (const uint64_t*)c->mid.p, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_glev_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+    if (!c || (B && (!sel || !a || !b || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t ev = glwe_words(c->prm) * 8 * c->prm.cbs_radix_count, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->aux, sel, B * sw);
+        STAGE_IN(c->in, a, B * ev);
+        STAGE_IN(c->mid, b, B * ev);
+        spf_status s = ensure(c, c->out, B * ev);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_glev_cmux_dev(c, c->stream, B, (const double*)c->aux.p, (const uint64_t*)c->in.p,
+                                     (const uint64_t*)c->mid.p, (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * ev, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_multiply_glwe_ggsw_batch(spf_ctx* c, size_t B, const uint64_t* glwe, const double* ggsw, uint64_t* out)
+{
+    if (!c || (B && (!glwe || !ggsw || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t gw = glwe_words(c->prm) * 8, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->aux, ggsw, B * sw);
+        STAGE_IN(c->in, glwe, B * gw);
+        spf_status s = ensure(c, c->out, B * gw);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = spf_multiply_glwe_ggsw_dev(c, c->stream, B, (const uint64_t*)c->in.p, (const double*)c->aux.p,
+                                              (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));

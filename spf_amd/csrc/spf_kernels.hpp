@@ -572,7 +572,9 @@ struct CmuxArgs {
     const uint64_t* d1;   // B x 4096
     uint64_t* out;        // B x 4096
     const c64* tables;
-    uint32_t B;
+    uint32_t B;           // work units (GLWE pairs)
+    uint32_t per_ggsw;    // consecutive units sharing one GGSW: 1 for cmux, l for glev_cmux
+    uint32_t d0_zero;     // 1: d0 is the zero ciphertext and is not read (multiply_glwe_ggsw)
 };
 constexpr int kCmuxLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
 
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
     const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
-    const c64* ggsw = a.ggsw + (size_t)ct * (2 * L * 2 * kHalf);
+    const c64* ggsw = a.ggsw + (size_t)(ct / a.per_ggsw) * (2 * L * 2 * kHalf);
     const uint64_t* d0 = a.d0 + (size_t)ct * 2 * kN;
     const uint64_t* d1 = a.d1 + (size_t)ct * 2 * kN;
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int c = p * kN + coef2(e);
-            uint64_t diff = d1[c] - d0[c]; // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+            uint64_t diff = d1[c] - (a.d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
             constexpr int shift = 64 - L * LOGB;
             uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
             uint32_t packed = 0;
@@ -743,13 +745,13 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
         if (__all(mn >= 4503599627370496.0)) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = base[coef2(e)] + f64_bigint_to_torus(tv[e]);
+                uint64_t v = (a.d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = base[coef2(e)] + f64_round_to_torus(tv[e]);
+                uint64_t v = (a.d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         }
