@@ -59,6 +59,21 @@ class Evaluation {
     const spf_params& params() const { return params_; }
     spf_ctx* raw() const { return ctx_; }
 
+    // KeylessEvaluation::not(&mut L1GlweCiphertext, &L1GlweCiphertext) (:48); `not`/`xor` are C++ tokens
+    void not_(uint64_t* output, const uint64_t* input, size_t B = 1)
+    {
+        check(spf_glwe_not_batch(ctx_, B, input, output), ctx_);
+    }
+    // KeylessEvaluation::xor(&mut L1GlweCiphertext, a, b) (:53)
+    void xor_(uint64_t* output, const uint64_t* a, const uint64_t* b, size_t B = 1)
+    {
+        check(spf_glwe_xor_batch(ctx_, B, a, b, output), ctx_);
+    }
+    // KeylessEvaluation::mul_xn(&mut L1GlweCiphertext, &L1GlweCiphertext, n) (:58)
+    void mul_xn(uint64_t* output, const uint64_t* input, size_t n, size_t B = 1)
+    {
+        check(spf_glwe_mul_xn_batch(ctx_, B, input, n, output), ctx_);
+    }
     // KeylessEvaluation::sample_extract_l1(&mut L1LweCiphertext, &L1GlweCiphertext, idx) (:126)
     void sample_extract_l1(uint64_t* output, const uint64_t* input, size_t idx, size_t B = 1)
     {

@@ -151,6 +151,19 @@ spf_status spf_scheme_switch_batch(spf_ctx *ctx, size_t B, const uint64_t *glev_
 spf_status spf_sample_extract_l1_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in, size_t idx,
                                        uint64_t *lwe1_out);
 
+/* The linear `KeylessEvaluation` operations on L1 GLWE ciphertexts (B x (k+1)*N words each):
+ *   not    (crypto/evaluation.rs:47-50): out = in + trivial_one, i.e. body coefficient 0 += 2^63
+ *          (`trivial_glwe_l1_one`, crypto/encryption.rs:359-364, one plaintext bit :132);
+ *   xor    (:52-55): out = a + b, wrapping;
+ *   mul_xn (:57-65): out = in * X^n mod X^N + 1 = `rotate_glwe_positive_monomial_negacyclic`
+ *          (sunscreen_tfhe/src/ops/bootstrapping/blind_rotation.rs:126-135), same n for the batch,
+ *          n taken mod 2N (entities/polynomial.rs:208-236). */
+spf_status spf_glwe_not_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in, uint64_t *glwe_out);
+spf_status spf_glwe_xor_batch(spf_ctx *ctx, size_t B, const uint64_t *a, const uint64_t *b,
+                              uint64_t *glwe_out);
+spf_status spf_glwe_mul_xn_batch(spf_ctx *ctx, size_t B, const uint64_t *glwe_in, size_t n,
+                                 uint64_t *glwe_out);
+
 /* B x `KeylessEvaluation::cmux` (crypto/evaluation.rs:68-83) = `cmux`
  * (sunscreen_tfhe/src/ops/fft_ops.rs:149-181) with the GGSW in cbs_radix shape.
  * sel_ggsw_fft: B x (k+1)*l_cbs*(k+1)*N/2 complex; a (selected when 0), b (when 1), out:
@@ -194,6 +207,11 @@ spf_status spf_scheme_switch_dev(spf_ctx *ctx, void *stream, size_t B, const uin
                                  double *d_ggsw_fft_out);
 spf_status spf_sample_extract_l1_dev(spf_ctx *ctx, void *stream, size_t B,
                                      const uint64_t *d_glwe_in, size_t idx, uint64_t *d_lwe1_out);
+spf_status spf_glwe_not_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_in, uint64_t *d_out);
+spf_status spf_glwe_xor_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_a,
+                            const uint64_t *d_b, uint64_t *d_out);
+spf_status spf_glwe_mul_xn_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_in, size_t n,
+                               uint64_t *d_out);
 spf_status spf_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,
                         const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
 spf_status spf_glev_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double *d_sel_ggsw_fft,

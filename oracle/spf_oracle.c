@@ -150,6 +150,30 @@ void spfo_sample_extract(uint64_t *lwe_out, const uint64_t *glwe, size_t h, size
     lwe_out[k * N] = glwe[k * N + h];
 }
 
+/* crypto/evaluation.rs:47-50: output = input + l1glwe_one, where l1glwe_one =
+ * trivial_glwe(1, l1_params, PlaintextBits(1)) (encryption.rs:359-376): zero mask, body = encode(1) */
+void spfo_glwe_not(uint64_t *out, const uint64_t *in, size_t N, size_t k)
+{
+    for (size_t i = 0; i < (k + 1) * N; i++) out[i] = in[i];
+    out[k * N] += spfo_encode(1, 1);
+}
+
+/* crypto/evaluation.rs:52-55 -> add_glwe_ciphertexts (glwe_ciphertext_ops.rs:79-99) */
+void spfo_glwe_xor(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t N, size_t k)
+{
+    for (size_t i = 0; i < (k + 1) * N; i++) out[i] = a[i] + b[i];
+}
+
+/* crypto/evaluation.rs:57-65 -> rotate_glwe_monomial_negacyclic (blind_rotation.rs:79-98): clone
+ * each mask polynomial and the body, then mul_by_monomial_negacyclic(+n) in place */
+void spfo_glwe_mul_xn(uint64_t *out, const uint64_t *in, size_t n, size_t N, size_t k)
+{
+    for (size_t p = 0; p <= k; p++) {
+        for (size_t i = 0; i < N; i++) out[p * N + i] = in[p * N + i];
+        spfo_poly_mul_pos_monomial(out + p * N, N, n);
+    }
+}
+
 /* ops/homomorphisms/lwe.rs:9-20 */
 void spfo_lwe_rotate(uint64_t *out, const uint64_t *in, size_t n, uint64_t rot)
 {

@@ -65,6 +65,16 @@ void spfo_poly_pow_k(uint64_t *p_k, const uint64_t *p, size_t N, size_t k);
 void spfo_sample_extract(uint64_t *lwe_out /*k*N+1*/, const uint64_t *glwe /*(k+1)*N*/, size_t h,
                          size_t N, size_t k);
 
+/* parasol_runtime/src/crypto/evaluation.rs:47-66, the linear KeylessEvaluation operations on one
+ * L1 GLWE ciphertext ((k+1)*N words):
+ *   not    : out = in + trivial_one (crypto/encryption.rs:359-364: the polynomial 1 at one
+ *            plaintext bit (:132), zero mask)
+ *   xor    : out = a + b (ops/ciphertext/glwe_ciphertext_ops.rs:79-99)
+ *   mul_xn : every polynomial * X^n (ops/bootstrapping/blind_rotation.rs:79-98,126-135) */
+void spfo_glwe_not(uint64_t *out, const uint64_t *in, size_t N, size_t k);
+void spfo_glwe_xor(uint64_t *out, const uint64_t *a, const uint64_t *b, size_t N, size_t k);
+void spfo_glwe_mul_xn(uint64_t *out, const uint64_t *in, size_t n, size_t N, size_t k);
+
 /* ops/homomorphisms/lwe.rs:9-20 : out = in with body += rot */
 void spfo_lwe_rotate(uint64_t *out, const uint64_t *in, size_t n, uint64_t rot);
 

@@ -71,6 +71,9 @@ def _declare(lib):
     f("spfo_poly_shr_round", None, P, P, sz, u32)
     f("spfo_poly_pow_k", None, P, P, sz, sz)
     f("spfo_sample_extract", None, P, P, sz, sz, sz)
+    f("spfo_glwe_not", None, P, P, sz, sz)
+    f("spfo_glwe_xor", None, P, P, P, sz, sz)
+    f("spfo_glwe_mul_xn", None, P, P, sz, sz, sz)
     f("spfo_lwe_rotate", None, P, P, sz, u64)
     f("spfo_generate_lut", None, P, sz, P, sz, u32)
     f("spfo_generate_negacyclic_lut", None, P, sz, P, u32)
@@ -230,6 +233,27 @@ def poly_pow_k(p, k: int) -> np.ndarray:
     p = _u(p)
     out = np.zeros_like(p)
     _load().spfo_poly_pow_k(_p(out), _p(p), p.size, k)
+    return out
+
+
+def glwe_not(glwe, N: int, k: int) -> np.ndarray:
+    glwe = _u(glwe)
+    out = np.zeros_like(glwe)
+    _load().spfo_glwe_not(_p(out), _p(glwe), N, k)
+    return out
+
+
+def glwe_xor(a, b, N: int, k: int) -> np.ndarray:
+    a, b = _u(a), _u(b)
+    out = np.zeros_like(a)
+    _load().spfo_glwe_xor(_p(out), _p(a), _p(b), N, k)
+    return out
+
+
+def glwe_mul_xn(glwe, n: int, N: int, k: int) -> np.ndarray:
+    glwe = _u(glwe)
+    out = np.zeros_like(glwe)
+    _load().spfo_glwe_mul_xn(_p(out), _p(glwe), n, N, k)
     return out
 
 

@@ -57,6 +57,12 @@ SYMBOLS = [
     ("spf_mod_switch_trace_and_rotate_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_scheme_switch_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_sample_extract_l1_batch", _I, [_P, _SZ, _P, _SZ, _P]),
+    ("spf_glwe_not_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_glwe_xor_batch", _I, [_P, _SZ, _P, _P, _P]),
+    ("spf_glwe_mul_xn_batch", _I, [_P, _SZ, _P, _SZ, _P]),
+    ("spf_glwe_not_dev", _I, [_P, _P, _SZ, _P, _P]),
+    ("spf_glwe_xor_dev", _I, [_P, _P, _SZ, _P, _P, _P]),
+    ("spf_glwe_mul_xn_dev", _I, [_P, _P, _SZ, _P, _SZ, _P]),
     ("spf_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
     ("spf_glev_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
     ("spf_multiply_glwe_ggsw_batch", _I, [_P, _SZ, _P, _P, _P]),
@@ -242,6 +248,27 @@ class Engine:
         self._ck(self._lib.spf_sample_extract_l1_batch(self._h, x.shape[0], _ptr(x), idx, _ptr(out)))
         return out
 
+    def glwe_not(self, glwe) -> np.ndarray:
+        x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        out = np.empty_like(x)
+        self._ck(self._lib.spf_glwe_not_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def glwe_xor(self, a, b) -> np.ndarray:
+        a = _u64(a).reshape(-1, self.params.glwe_words)
+        b = _u64(b).reshape(-1, self.params.glwe_words)
+        if a.shape != b.shape:
+            raise SpfError(-2, "glwe_xor: operand batches differ in size")
+        out = np.empty_like(a)
+        self._ck(self._lib.spf_glwe_xor_batch(self._h, a.shape[0], _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def glwe_mul_xn(self, glwe, n: int) -> np.ndarray:
+        x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        out = np.empty_like(x)
+        self._ck(self._lib.spf_glwe_mul_xn_batch(self._h, x.shape[0], _ptr(x), n, _ptr(out)))
+        return out
+
     def cmux(self, sel_ggsw_fft, a, b) -> np.ndarray:
         g = np.ascontiguousarray(sel_ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
         a = _u64(a).reshape(-1, self.params.glwe_words)
@@ -291,6 +318,15 @@ class Engine:
 
     def cmux_dev(self, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out):
         self._ck(self._lib.spf_cmux_dev(self._h, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out))
+
+    def glwe_not_dev(self, stream, B, d_in, d_out):
+        self._ck(self._lib.spf_glwe_not_dev(self._h, stream, B, d_in, d_out))
+
+    def glwe_xor_dev(self, stream, B, d_a, d_b, d_out):
+        self._ck(self._lib.spf_glwe_xor_dev(self._h, stream, B, d_a, d_b, d_out))
+
+    def glwe_mul_xn_dev(self, stream, B, d_in, n, d_out):
+        self._ck(self._lib.spf_glwe_mul_xn_dev(self._h, stream, B, d_in, n, d_out))
 
     def sample_extract_l1_dev(self, stream, B, d_glwe, idx, d_out):
         self._ck(self._lib.spf_sample_extract_l1_dev(self._h, stream, B, d_glwe, idx, d_out))

@@ -590,6 +590,38 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     return SPF_OK;
 }
 
+static spf_status glwe_linear_dev(spf_ctx* c, void* stream, size_t B, uint32_t op, const uint64_t* d_a,
+                                  const uint64_t* d_b, uint32_t n, uint64_t* d_out)
+{
+    if (!c || (B && (!d_a || !d_out || (op == GLWE_XOR && !d_b)))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    if (B > 65535) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large (at most 65535 per call)");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    dim3 grid(2 * kN / 256, (unsigned)B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (op == GLWE_NOT) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_NOT>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
+    else if (op == GLWE_XOR) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_XOR>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
+    else hipLaunchKernelGGL(glwe_linear_kernel<GLWE_MUL_XN>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
+spf_status spf_glwe_not_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_in, uint64_t* d_out)
+{
+    return glwe_linear_dev(c, stream, B, GLWE_NOT, d_in, nullptr, 0, d_out);
+}
+
+spf_status spf_glwe_xor_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out)
+{
+    return glwe_linear_dev(c, stream, B, GLWE_XOR, d_a, d_b, 0, d_out);
+}
+
+spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_in, size_t n, uint64_t* d_out)
+{
+    return glwe_linear_dev(c, stream, B, GLWE_MUL_XN, d_in, nullptr, (uint32_t)(n % (2 * (size_t)kN)), d_out);
+}
+
 static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t per_ggsw, const double* d_sel,
                               const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out)
 {
@@ -728,6 +760,45 @@ spf_status spf_sample_extract_l1_batch(spf_ctx* c, size_t B, const uint64_t* glw
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * lwe1_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
+}
+
+static spf_status glwe_linear_host(spf_ctx* c, size_t B, uint32_t op, const uint64_t* a, const uint64_t* b, size_t n,
+                                   uint64_t* out)
+{
+    if (!c || (B && (!a || !out || (op == GLWE_XOR && !b)))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t gw = glwe_words(c->prm) * 8;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        STAGE_IN(c->in, a, B * gw);
+        if (op == GLWE_XOR) STAGE_IN(c->mid, b, B * gw);
+        spf_status s = ensure(c, c->out, B * gw);
+        if (s != SPF_OK) return s;
+    }
+    spf_status s = glwe_linear_dev(c, c->stream, B, op, (const uint64_t*)c->in.p,
+                                   op == GLWE_XOR ? (const uint64_t*)c->mid.p : nullptr,
+                                   (uint32_t)(n % (2 * (size_t)kN)), (uint64_t*)c->out.p);
+    if (s != SPF_OK) return s;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
+spf_status spf_glwe_not_batch(spf_ctx* c, size_t B, const uint64_t* in, uint64_t* out)
+{
+    return glwe_linear_host(c, B, GLWE_NOT, in, nullptr, 0, out);
+}
+
+spf_status spf_glwe_xor_batch(spf_ctx* c, size_t B, const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+    return glwe_linear_host(c, B, GLWE_XOR, a, b, 0, out);
+}
+
+spf_status spf_glwe_mul_xn_batch(spf_ctx* c, size_t B, const uint64_t* in, size_t n, uint64_t* out)
+{
+    return glwe_linear_host(c, B, GLWE_MUL_XN, in, nullptr, n, out);
 }
 
 spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_t* a, const uint64_t* b, uint64_t* out)

@@ -960,6 +960,35 @@ __global__ void sample_extract_kernel(const uint64_t* glwe, uint64_t* lwe, uint3
     else o[j] = (uint64_t)0 - g[h + kN - j];
 }
 
+// The three linear `KeylessEvaluation` operations on L1 GLWE ciphertexts (crypto/evaluation.rs:47-66),
+// one thread per coefficient, streaming (HBM-bound, 16-24 bytes per coefficient):
+//   GLWE_NOT    out = in + trivial_one: the trivial GLWE of the polynomial 1 at one plaintext bit is
+//               all zero except body coefficient 0 = 2^63 (encryption.rs:359-364, :132)
+//   GLWE_XOR    out = a + b, wrapping (`add_glwe_ciphertexts`, glwe_ciphertext_ops.rs:79-99)
+//   GLWE_MUL_XN out = in * X^n mod X^N + 1 on mask and body
+//               (`rotate_glwe_positive_monomial_negacyclic`, blind_rotation.rs:126-135 ->
+//               `mul_by_positive_monomial_negacyclic`, entities/polynomial.rs:208-236; n taken mod 2N)
+enum : uint32_t { GLWE_NOT = 0, GLWE_XOR = 1, GLWE_MUL_XN = 2 };
+template <uint32_t OP>
+__global__ void glwe_linear_kernel(const uint64_t* a, const uint64_t* b, uint64_t* out, uint32_t B, uint32_t n)
+{
+    const uint32_t ct = blockIdx.y;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; // 0 .. 2N-1: polynomial j / N, coefficient j % N
+    if (ct >= B || j >= 2 * kN) return;
+    const uint64_t* x = a + (size_t)ct * 2 * kN;
+    uint64_t* o = out + (size_t)ct * 2 * kN;
+    if constexpr (OP == GLWE_NOT) {
+        o[j] = x[j] + (j == kN ? (uint64_t)1 << 63 : (uint64_t)0);
+    } else if constexpr (OP == GLWE_XOR) {
+        o[j] = x[j] + b[(size_t)ct * 2 * kN + j];
+    } else {
+        const uint32_t poly = j & ~(uint32_t)(kN - 1), i = j & (kN - 1);
+        const uint32_t idx = (i + 2 * kN - n) & (2 * kN - 1); // exponent of the source term, mod 2N
+        const uint64_t v = x[poly + (idx & (kN - 1))];
+        o[j] = (idx & kN) ? (uint64_t)0 - v : v;
+    }
+}
+
 // lwe_rotate (ops/homomorphisms/lwe.rs:9-20) is folded into blind_rotate_kernel's body_rotate.
 
 } // namespace spf

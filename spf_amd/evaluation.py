@@ -47,6 +47,18 @@ class Evaluation:
             raise TypeError("output must be uint64")
         output[...] = result.reshape(output.shape)
 
+    # KeylessEvaluation::not (evaluation.rs:47-50); `not` is a Python keyword, hence the underscore
+    def not_(self, output: np.ndarray, input: np.ndarray):
+        self._store(output, self.engine.glwe_not(input))
+
+    # KeylessEvaluation::xor (evaluation.rs:52-55)
+    def xor(self, output: np.ndarray, a: np.ndarray, b: np.ndarray):
+        self._store(output, self.engine.glwe_xor(a, b))
+
+    # KeylessEvaluation::mul_xn (evaluation.rs:57-65)
+    def mul_xn(self, output: np.ndarray, input: np.ndarray, n: int):
+        self._store(output, self.engine.glwe_mul_xn(input, n))
+
     # KeylessEvaluation::sample_extract_l1 (evaluation.rs:126-133)
     def sample_extract_l1(self, output: np.ndarray, input: np.ndarray, idx: int):
         self._store(output, self.engine.sample_extract_l1(input, idx))

@@ -40,3 +40,50 @@ def test_multiply_glwe_ggsw_parity():
                               P.cbs_radix_log, P.cbs_count)
         exp = np.concatenate([O.poly_ifft(fft[:P.N // 2]), O.poly_ifft(fft[P.N // 2:])])
         assert np.array_equal(got[i], exp), i
+
+
+# The three linear operations (crypto/evaluation.rs:47-66).  The reference's own tests for them are
+# functional (`evaluation.rs` tests decrypt after not/xor; `can_rotate_*` in blind_rotation.rs:390-470);
+# here the bar is bit equality with the oracle plus the algebraic properties those tests rely on.
+def test_not_xor_parity_and_involution():
+    eng = spf_amd.Engine(to_engine_params(P))
+    B = 5
+    a = random_glwe(11, B, P.glwe_len)
+    b = random_glwe(12, B, P.glwe_len)
+    n1 = eng.glwe_not(a)
+    x = eng.glwe_xor(a, b)
+    for i in range(B):
+        assert np.array_equal(n1[i], O.glwe_not(a[i], P.N, P.k))
+        assert np.array_equal(x[i], O.glwe_xor(a[i], b[i], P.N, P.k))
+    assert np.array_equal(eng.glwe_not(n1), a)                       # 2 * 2^63 = 0 mod 2^64
+    assert np.array_equal(eng.glwe_xor(b, a), x) and np.array_equal(x, a + b)   # commutes, wraps
+    # only body coefficient 0 moves
+    d = n1 - a
+    assert d[:, P.N * P.k].tolist() == [1 << 63] * B and np.count_nonzero(d) == B
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 2047, 2048, 2049, 4095, 4096, 4097 + 4096 * 3])
+def test_mul_xn_parity(n):
+    eng = spf_amd.Engine(to_engine_params(P))
+    B = 3
+    a = random_glwe(20 + n % 7, B, P.glwe_len)
+    got = eng.glwe_mul_xn(a, n)
+    for i in range(B):
+        assert np.array_equal(got[i], O.glwe_mul_xn(a[i], n, P.N, P.k)), i
+    # X^n * X^(2N - n) = 1
+    back = eng.glwe_mul_xn(got, (2 * P.N - n % (2 * P.N)) % (2 * P.N))
+    assert np.array_equal(back, a)
+
+
+def test_evaluation_mirror_linear_ops():
+    key = spf_amd.ComputeKey(bs_key=np.zeros((P.lwe_n, (P.k + 1) ** 2 * P.pbs_count * (P.N // 2)), dtype=np.complex128), ks_key=None)
+    ev = spf_amd.Evaluation(key, to_engine_params(P))
+    a = random_glwe(31, 1, P.glwe_len)[0]
+    b = random_glwe(32, 1, P.glwe_len)[0]
+    out = np.zeros_like(a)
+    ev.not_(out, a)
+    assert np.array_equal(out, O.glwe_not(a, P.N, P.k))
+    ev.xor(out, a, b)
+    assert np.array_equal(out, O.glwe_xor(a, b, P.N, P.k))
+    ev.mul_xn(out, a, 5)
+    assert np.array_equal(out, O.glwe_mul_xn(a, 5, P.N, P.k))

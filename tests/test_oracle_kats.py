@@ -97,6 +97,23 @@ def test_monomial_rotation(kats, which):
         assert np.array_equal(fn(_s(k["p"]), int(deg)), _s(exp)), (which, deg)
 
 
+def test_glwe_linear_ops_follow_the_polynomial_kats(kats):
+    """KeylessEvaluation::{not, xor, mul_xn} (crypto/evaluation.rs:47-66): mul_xn is the monomial KAT applied
+    to mask and body; not adds the trivial one (body coefficient 0 += 2^63); xor is the wrapping sum."""
+    k = kats["pos_monomial"]
+    p = _s(k["p"])
+    N = p.size
+    glwe = np.concatenate([p, p[::-1].copy()])
+    for deg, exp in k["cases"].items():
+        got = O.glwe_mul_xn(glwe, int(deg), N, 1)
+        assert np.array_equal(got[:N], _s(exp)), deg
+        assert np.array_equal(got[N:], O.poly_mul_pos_monomial(p[::-1].copy(), int(deg))), deg
+    n1 = O.glwe_not(glwe, N, 1)
+    assert n1[N] == (glwe[N] + (1 << 63)) & M64 and np.array_equal(np.delete(n1, N), np.delete(glwe, N))
+    assert np.array_equal(O.glwe_not(n1, N, 1), glwe)
+    assert np.array_equal(O.glwe_xor(glwe, n1, N, 1), glwe + n1)
+
+
 def test_can_polynomial_pow_k(kats):
     k = kats["poly_pow_k"]
     p = np.zeros(k["N"], dtype=np.uint64)
