@@ -50,6 +50,8 @@ def main() -> int:
     ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
     ap.add_argument("--with-cmux", action="store_true", help="also time the batched cbs_radix CMUX kernel")
     ap.add_argument("--with-cbs", action="store_true", help="also time Evaluation::circuit_bootstrap end to end")
+    ap.add_argument("--with-add32", type=int, default=0, metavar="K",
+                    help="also time K independent 32-bit encrypted additions as ONE gate graph (BASELINE config 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -197,6 +199,12 @@ def main() -> int:
         step()   # restore the plain-PBS output for the parity sample
         torch.cuda.synchronize()
 
+    add32 = None
+    if args.with_add32 > 0 and rank == 0:
+        add32 = _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, args.with_cbs)
+        step()
+        torch.cuda.synchronize()
+
     cmux = None
     if args.with_cmux:
         # KeylessEvaluation::cmux over a batch: every ciphertext brings its own 256 KiB GGSW
@@ -287,10 +295,62 @@ def main() -> int:
             line["cmux"] = cmux
         if cbs:
             line["circuit_bootstrap"] = cbs
+        if add32:
+            line["add32"] = add32
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):
+    """BASELINE config 3: K independent 32-bit additions (the circuit of tests/test_gpu_graph.py:
+    64 x (SampleExtract -> KeyswitchL1toL0 -> CircuitBootstrap) + a ripple-carry chain of 192 CMUX and
+    32 Not per addition) as ONE `FheCircuit` run: one input copy, 68 levels enqueued back to back on
+    one stream, one output copy.  Synthetic keys and inputs (timing is value-independent; correctness
+    of the same graph is tests/test_gpu_graph.py::test_encrypted_add_32_as_one_graph)."""
+    import spf_amd
+    from spf_amd import FheOp, ValueKind
+    if not keys_loaded:
+        for which in (2, 3):
+            ptr, nbytes = eng.key_blob(which)
+            t = torch.as_tensor(DevArray(ptr, nbytes), device=dev)
+            t.copy_((torch.randn(nbytes // 8, generator=gen, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
+            torch.cuda.synchronize()
+            eng.key_blob_commit(which)
+    rng = np.random.default_rng(0xADD32)
+    g = spf_amd.FheCircuit(eng)
+    outs = []
+    for _ in range(K):
+        sel = []
+        for _ in range(64):
+            x = g.add_input(ValueKind.GLWE1, rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64))
+            x = g.add_op(FheOp.SampleExtract, [x], 0)
+            x = g.add_op(FheOp.KeyswitchL1toL0, [x])
+            sel.append(g.add_op(FheOp.CircuitBootstrap, [x]))
+        ga, gb = sel[:32], sel[32:]
+        zero = g.add_trivial(ValueKind.GLWE1, 0)
+        one = g.add_trivial(ValueKind.GLWE1, 1)
+        carry = zero
+        for i in range(32):
+            ncarry = g.add_op(FheOp.Not, [carry])
+            l1 = [g.add_op(FheOp.CMux, [gb[i], lo, hi]) for lo, hi in
+                  [(carry, ncarry), (ncarry, carry), (zero, carry), (carry, one)]]
+            outs.append(g.add_output(g.add_op(FheOp.CMux, [ga[i], l1[0], l1[1]]), ValueKind.GLWE1))
+            carry = g.add_op(FheOp.CMux, [ga[i], l1[2], l1[3]])
+        outs.append(g.add_output(carry, ValueKind.GLWE1))
+    g.run()                       # plans, allocates, warms up
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.run()
+    dt = (time.perf_counter() - t0) / reps
+    st = g.stats()
+    g.close()
+    return {"adds_per_graph": K, "ms_per_graph_run": round(dt * 1e3, 3), "adds_per_s": round(K / dt, 2),
+            "gates_per_s": round(K * (64 + 192) / dt, 1), "nodes": st["nodes"], "levels": st["levels"],
+            "launches": st["launches"],
+            "note": "wall time of spf_graph_run: H2D of 64 GLWE inputs per add, all levels, D2H of 33 GLWE outputs per add"}
 
 
 if __name__ == "__main__":

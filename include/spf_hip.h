@@ -245,6 +245,67 @@ spf_status spf_pool_wait(spf_pool *pool, uint64_t ticket);
 /* operations completed and batches launched so far (ops / launches = achieved batch size) */
 spf_status spf_pool_stats(spf_pool *pool, uint64_t *ops, uint64_t *launches);
 
+/* ---- gate graphs: level-batched, device-resident execution ------------- *
+ *
+ * The counterpart of `FheCircuit` + `CircuitProcessor::run_graph_blocking`
+ * (parasol_runtime/src/fhe_circuit.rs:34-126, circuit_processor/mod.rs:573-623): build a DAG of
+ * `FheOp`-like nodes, then run it.  Execution is by topological level: all nodes of one level
+ * and one kind are ONE batched launch, intermediates never leave HBM, the whole graph is
+ * enqueued on one stream.  Node ids are dense, in creation order; operands must already exist
+ * (so the node order is a topological order).  Operand order per operation:
+ *   SAMPLE_EXTRACT(param = index) [glwe1] -> lwe1      KEYSWITCH_L1_TO_L0 [lwe1] -> lwe0
+ *   CIRCUIT_BOOTSTRAP [lwe0] -> ggsw1                  SCHEME_SWITCH [glev1] -> ggsw1
+ *   NOT [glwe1]   GLWE_ADD [glwe1, glwe1]   MUL_XN(param = n) [glwe1]           -> glwe1
+ *   CMUX [sel ggsw1, low glwe1 (taken when sel = 0), high glwe1] -> glwe1   (FheEdge::Sel/Low/High)
+ *   GLEV_CMUX [sel ggsw1, low glev1, high glev1] -> glev1
+ *   MULTIPLY_GGSW_GLWE [ggsw1, glwe1] -> glwe1
+ * Wrong arity or operand type is reported by spf_graph_add_op, before anything runs (the
+ * reference validates per task, task.rs:26-31).  Input and output host buffers are read /
+ * written by every spf_graph_run and must stay valid until it returns; a graph can be run
+ * repeatedly with new input contents.  A graph is not thread-safe; distinct graphs on one
+ * context may run from different threads (their launches serialise on the context's stream). */
+typedef struct spf_graph spf_graph;
+typedef enum spf_value_kind {
+    SPF_VAL_LWE0 = 0,  /* L0LweCiphertext: n+1 words */
+    SPF_VAL_LWE1 = 1,  /* L1LweCiphertext: k*N+1 words */
+    SPF_VAL_GLWE1 = 2, /* L1GlweCiphertext: (k+1)*N words */
+    SPF_VAL_GGSW1 = 3, /* L1GgswCiphertext, FFT domain: (k+1)*l_cbs*(k+1)*N/2 complex */
+    SPF_VAL_GLEV1 = 4  /* L1GlevCiphertext: l_cbs GLWEs */
+} spf_value_kind;
+typedef enum spf_graph_op {
+    SPF_OP_SAMPLE_EXTRACT = 0,
+    SPF_OP_KEYSWITCH_L1_TO_L0 = 1,
+    SPF_OP_NOT = 2,
+    SPF_OP_GLWE_ADD = 3,
+    SPF_OP_CMUX = 4,
+    SPF_OP_GLEV_CMUX = 5,
+    SPF_OP_MULTIPLY_GGSW_GLWE = 6,
+    SPF_OP_CIRCUIT_BOOTSTRAP = 7,
+    SPF_OP_SCHEME_SWITCH = 8,
+    SPF_OP_MUL_XN = 9
+} spf_graph_op;
+spf_status spf_graph_create(spf_ctx *ctx, spf_graph **out);
+void spf_graph_destroy(spf_graph *graph);
+/* FheOp::Input{Lwe0,Lwe1,Glwe1,Ggsw1,Glev1} */
+spf_status spf_graph_add_input(spf_graph *graph, spf_value_kind kind, const void *host, uint32_t *node);
+/* FheOp::{Zero,One}{Lwe0,Glwe1}: trivial encryption of a bit (also LWE1) */
+spf_status spf_graph_add_trivial(spf_graph *graph, spf_value_kind kind, uint64_t bit, uint32_t *node);
+spf_status spf_graph_add_op(spf_graph *graph, spf_graph_op op, const uint32_t *inputs, size_t n_inputs,
+                            uint64_t param, uint32_t *node);
+/* FheOp::Output*: copy the node's value to `host` at the end of every run */
+spf_status spf_graph_add_output(spf_graph *graph, uint32_t node, void *host);
+/* `run_graph_blocking`: returns when every output has been written */
+spf_status spf_graph_run(spf_graph *graph);
+/* nodes in the graph; levels and kernel launches of the most recent run */
+spf_status spf_graph_stats(spf_graph *graph, uint32_t *nodes, uint32_t *levels, uint32_t *launches);
+
+/* cmux over operands that are not contiguous: d_ptrs is a DEVICE array of 4 pointers per unit,
+ * {selector GGSW-FFT, a (NULL = the zero ciphertext, i.e. multiply_glwe_ggsw), b, out}. */
+spf_status spf_cmux_scattered_dev(spf_ctx *ctx, void *stream, size_t units, const void *const *d_ptrs);
+/* dst row r = `words` u64 read from d_src_ptrs[r] (device array of device pointers) */
+spf_status spf_gather_rows_dev(spf_ctx *ctx, void *stream, size_t rows, size_t words,
+                               const uint64_t *const *d_src_ptrs, uint64_t *d_dst);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------- */
 
 /* Average device time in milliseconds of the `reps` most recent blind-rotation launches made

@@ -9,7 +9,8 @@ compiled library or without a GPU raises.
 from .params import Params, DEFAULT_128  # noqa: F401
 from ._ffi import Engine, Pool, SpfError, lib_path, load_library  # noqa: F401
 from .evaluation import Evaluation, ComputeKey  # noqa: F401
+from .graph import FheCircuit, FheOp, ValueKind  # noqa: F401
 from .build import build_library  # noqa: F401
 
-__all__ = ["Params", "DEFAULT_128", "Engine", "Pool", "SpfError", "Evaluation", "ComputeKey",
+__all__ = ["Params", "DEFAULT_128", "Engine", "Pool", "SpfError", "Evaluation", "ComputeKey", "FheCircuit", "FheOp", "ValueKind",
            "build_library", "lib_path", "load_library"]

@@ -86,6 +86,16 @@ SYMBOLS = [
     ("spf_pool_submit_cmux", _I, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_wait", _I, [_P, _U64]),
     ("spf_pool_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
+    ("spf_graph_create", _I, [_P, C.POINTER(_P)]),
+    ("spf_graph_destroy", None, [_P]),
+    ("spf_graph_add_input", _I, [_P, _I, _P, C.POINTER(_U32)]),
+    ("spf_graph_add_trivial", _I, [_P, _I, _U64, C.POINTER(_U32)]),
+    ("spf_graph_add_op", _I, [_P, _I, C.POINTER(_U32), _SZ, _U64, C.POINTER(_U32)]),
+    ("spf_graph_add_output", _I, [_P, _U32, _P]),
+    ("spf_graph_run", _I, [_P]),
+    ("spf_graph_stats", _I, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    ("spf_cmux_scattered_dev", _I, [_P, _P, _SZ, _P]),
+    ("spf_gather_rows_dev", _I, [_P, _P, _SZ, _SZ, _P, _P]),
     ("spf_set_timing", _I, [_P, _I]),
     ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
     ("spf_version", C.c_char_p, []),

@@ -649,6 +649,41 @@ spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel,
     return launch_cmux(c, (hipStream_t)stream, B, 1, d_sel, d_a, d_b, d_out);
 }
 
+// cmux over operands that are not contiguous: d_ptrs is a device array of 4 pointers per unit
+// {selector GGSW-FFT, a (null = the zero ciphertext), b, out}; same kernel, same results
+spf_status spf_cmux_scattered_dev(spf_ctx* c, void* stream, size_t units, const void* const* d_ptrs)
+{
+    if (!c || (units && !d_ptrs)) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
+        return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
+    if (units == 0) return SPF_OK;
+    if (units > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    CmuxArgs a{};
+    a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = 1; a.ptrs = d_ptrs;
+    dim3 grid((unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
+    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, (hipStream_t)stream, a);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
+// dst row r = `words` u64 from d_src_ptrs[r]
+spf_status spf_gather_rows_dev(spf_ctx* c, void* stream, size_t rows, size_t words, const uint64_t* const* d_src_ptrs,
+                               uint64_t* d_dst)
+{
+    if (!c || (rows && (!d_src_ptrs || !d_dst))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (rows == 0 || words == 0) return SPF_OK;
+    if (rows > 65535 || words > 0xffffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "gather too large");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    dim3 grid((unsigned)((words + 255) / 256), (unsigned)rows), block(256);
+    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, d_src_ptrs, d_dst, (uint32_t)rows,
+                       (uint32_t)words);
+    HIPCHK(c, hipGetLastError());
+    return SPF_OK;
+}
+
 // KeylessEvaluation::glev_cmux (crypto/evaluation.rs:86-101) = glev_cmux (ops/fft_ops.rs:203-220):
 // a cmux over each of the l_cbs GLWEs of two GLEVs with one selector
 spf_status spf_glev_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel, const uint64_t* d_a,
@@ -1077,3 +1112,5 @@ spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
 }
 
 } // extern "C"
+
+#include "spf_graph.hpp"

@@ -575,6 +575,9 @@ struct CmuxArgs {
     uint32_t B;           // work units (GLWE pairs)
     uint32_t per_ggsw;    // consecutive units sharing one GGSW: 1 for cmux, l for glev_cmux
     uint32_t d0_zero;     // 1: d0 is the zero ciphertext and is not read (multiply_glwe_ggsw)
+    // Scattered operands (the graph executor, spf_graph.hpp): when non-null, unit u takes
+    // {ggsw, d0 (null = zero ciphertext), d1, out} from ptrs[4u .. 4u+3] instead of the arrays above.
+    const void* const* ptrs;
 };
 constexpr int kCmuxLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
 
@@ -604,9 +607,23 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
     const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
-    const c64* ggsw = a.ggsw + (size_t)(ct / a.per_ggsw) * (2 * L * 2 * kHalf);
-    const uint64_t* d0 = a.d0 + (size_t)ct * 2 * kN;
-    const uint64_t* d1 = a.d1 + (size_t)ct * 2 * kN;
+    const c64* ggsw;
+    const uint64_t *d0, *d1;
+    uint64_t* out_ct;
+    bool d0_zero = a.d0_zero != 0;
+    if (a.ptrs) {
+        const void* const* t = a.ptrs + 4 * (size_t)ct;
+        ggsw = static_cast<const c64*>(t[0]);
+        d1 = static_cast<const uint64_t*>(t[2]);
+        d0_zero = t[1] == nullptr;
+        d0 = d0_zero ? d1 : static_cast<const uint64_t*>(t[1]);
+        out_ct = static_cast<uint64_t*>(const_cast<void*>(t[3]));
+    } else {
+        ggsw = a.ggsw + (size_t)(ct / a.per_ggsw) * (2 * L * 2 * kHalf);
+        d0 = a.d0 + (size_t)ct * 2 * kN;
+        d1 = a.d1 + (size_t)ct * 2 * kN;
+        out_ct = a.out + (size_t)ct * 2 * kN;
+    }
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
     uint32_t dig[2][16];
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int c = p * kN + coef2(e);
-            uint64_t diff = d1[c] - (a.d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+            uint64_t diff = d1[c] - (d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
             constexpr int shift = 64 - L * LOGB;
             uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
             uint32_t packed = 0;
@@ -740,18 +757,18 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
         for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
         // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180); d_0 is re-read rather than held
         // in registers across the transforms
-        uint64_t* out = a.out + (size_t)ct * 2 * kN + q * kN;
+        uint64_t* out = out_ct + q * kN;
         const uint64_t* base = d0 + q * kN;
         if (__all(mn >= 4503599627370496.0)) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = (a.d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
+                uint64_t v = (d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = (a.d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
+                uint64_t v = (d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         }
@@ -987,6 +1004,16 @@ __global__ void glwe_linear_kernel(const uint64_t* a, const uint64_t* b, uint64_
         const uint64_t v = x[poly + (idx & (kN - 1))];
         o[j] = (idx & kN) ? (uint64_t)0 - v : v;
     }
+}
+
+// Row gather for the graph executor: dst row r = the `words` u64 at src[r] (operands of one level of
+// a gate graph live wherever their producers wrote them; the batched kernels want them contiguous).
+__global__ void gather_rows_kernel(const uint64_t* const* src, uint64_t* dst, uint32_t rows, uint32_t words)
+{
+    const uint32_t r = blockIdx.y;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows || j >= words) return;
+    dst[(size_t)r * words + j] = src[r][j];
 }
 
 // lwe_rotate (ops/homomorphisms/lwe.rs:9-20) is folded into blind_rotate_kernel's body_rotate.

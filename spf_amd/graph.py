@@ -1,0 +1,106 @@
+"""Host-side mirror of ``FheCircuit`` + ``CircuitProcessor::run_graph_blocking`` over the graph
+executor of the C ABI (``spf_graph_*``, include/spf_hip.h; spf_amd/csrc/spf_graph.hpp).
+
+The reference builds a petgraph DAG of ``FheOp`` nodes joined by typed ``FheEdge``s
+(parasol_runtime/src/fhe_circuit.rs:34-205) and runs it with one rayon task per node
+(circuit_processor/mod.rs:130-253, 573-623).  Here the same DAG is handed to the library, which runs
+it level by level as batched launches with every intermediate in HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import List, Sequence
+
+import numpy as np
+
+from ._ffi import Engine, SpfError, _ptr
+
+
+class ValueKind(enum.IntEnum):
+    LWE0 = 0
+    LWE1 = 1
+    GLWE1 = 2
+    GGSW1 = 3
+    GLEV1 = 4
+
+
+class FheOp(enum.IntEnum):
+    """The computing variants of ``FheOp`` (fhe_circuit.rs:65-126); inputs, outputs and constants have
+    their own methods on :class:`FheCircuit`."""
+    SampleExtract = 0
+    KeyswitchL1toL0 = 1
+    Not = 2
+    GlweAdd = 3
+    CMux = 4
+    GlevCMux = 5
+    MultiplyGgswGlwe = 6
+    CircuitBootstrap = 7
+    SchemeSwitch = 8
+    MulXN = 9
+
+
+class FheCircuit:
+    def __init__(self, engine: Engine):
+        self._eng = engine
+        self._lib = engine._lib
+        h = C.c_void_p()
+        engine._ck(self._lib.spf_graph_create(engine._h, C.byref(h)))
+        self._g = h
+        self._keep: List[np.ndarray] = []   # input / output buffers the library reads and writes at run()
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.spf_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _words(self, kind: ValueKind) -> int:
+        p = self._eng.params
+        return {ValueKind.LWE0: p.lwe0_words, ValueKind.LWE1: p.lwe1_words, ValueKind.GLWE1: p.glwe_words,
+                ValueKind.GGSW1: 2 * p.cbs_ggsw_complex,
+                ValueKind.GLEV1: p.cbs_radix_count * p.glwe_words}[ValueKind(kind)]
+
+    # FheOp::Input* — the array is read at every run(); change its contents to re-run on new data
+    def add_input(self, kind: ValueKind, value: np.ndarray) -> int:
+        a = np.ascontiguousarray(value)
+        if a.nbytes != self._words(kind) * 8:
+            raise SpfError(1, f"input of kind {ValueKind(kind).name} must have {self._words(kind) * 8} bytes, got {a.nbytes}")
+        self._keep.append(a)
+        node = C.c_uint32()
+        self._eng._ck(self._lib.spf_graph_add_input(self._g, int(kind), _ptr(a), C.byref(node)))
+        return node.value
+
+    # FheOp::{Zero,One}{Lwe0,Glwe1}
+    def add_trivial(self, kind: ValueKind, bit: int) -> int:
+        node = C.c_uint32()
+        self._eng._ck(self._lib.spf_graph_add_trivial(self._g, int(kind), bit, C.byref(node)))
+        return node.value
+
+    def add_op(self, op: FheOp, inputs: Sequence[int], param: int = 0) -> int:
+        arr = (C.c_uint32 * len(inputs))(*inputs)
+        node = C.c_uint32()
+        self._eng._ck(self._lib.spf_graph_add_op(self._g, int(op), arr, len(inputs), param, C.byref(node)))
+        return node.value
+
+    # FheOp::Output* — returns the array run() fills
+    def add_output(self, node: int, kind: ValueKind) -> np.ndarray:
+        dtype = np.complex128 if ValueKind(kind) == ValueKind.GGSW1 else np.uint64
+        out = np.zeros(self._words(kind) * 8 // np.dtype(dtype).itemsize, dtype=dtype)
+        self._keep.append(out)
+        self._eng._ck(self._lib.spf_graph_add_output(self._g, node, _ptr(out)))
+        return out
+
+    # CircuitProcessor::run_graph_blocking
+    def run(self):
+        self._eng._ck(self._lib.spf_graph_run(self._g))
+
+    def stats(self):
+        n, lv, la = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._eng._ck(self._lib.spf_graph_stats(self._g, C.byref(n), C.byref(lv), C.byref(la)))
+        return {"nodes": n.value, "levels": lv.value, "launches": la.value}
