@@ -123,13 +123,67 @@ class Evaluation {
         check(spf_gate_bootstrap_batch(ctx_, B, input_l1, output_glwe), ctx_);
     }
 
+    // KeylessEvaluation::glev_cmux (:86), multiply_glwe_ggsw (:104)
+    void glev_cmux(uint64_t* output, const double* sel_ggsw_fft, const uint64_t* a, const uint64_t* b, size_t B = 1)
+    {
+        check(spf_glev_cmux_batch(ctx_, B, sel_ggsw_fft, a, b, output), ctx_);
+    }
+    void multiply_glwe_ggsw(uint64_t* output, const uint64_t* glwe, const double* ggsw_fft, size_t B = 1)
+    {
+        check(spf_multiply_glwe_ggsw_batch(ctx_, B, glwe, ggsw_fft, output), ctx_);
+    }
+
   private:
+    friend class FheCircuit;
     static void check(spf_status s, const spf_ctx* c)
     {
         if (s != SPF_OK) throw Error(s, spf_last_error(c));
     }
     spf_ctx* ctx_ = nullptr;
     spf_params params_;
+};
+
+// `FheCircuit` + `CircuitProcessor::run_graph_blocking` (parasol_runtime/src/fhe_circuit.rs:34-205,
+// circuit_processor/mod.rs:573-623) over spf_graph_*: build the DAG node by node, run() executes it
+// level by level with every intermediate in HBM.  Node handles are the library's dense ids.
+class FheCircuit {
+  public:
+    using Node = uint32_t;
+    explicit FheCircuit(const Evaluation& ev) : ctx_(ev.raw())
+    {
+        Evaluation::check(spf_graph_create(ctx_, &g_), ctx_);
+    }
+    FheCircuit(const FheCircuit&) = delete;
+    FheCircuit& operator=(const FheCircuit&) = delete;
+    ~FheCircuit() { spf_graph_destroy(g_); }
+
+    // FheOp::Input*: `host` is read at every run()
+    Node input(spf_value_kind kind, const void* host)
+    {
+        Node n = 0;
+        Evaluation::check(spf_graph_add_input(g_, kind, host, &n), ctx_);
+        return n;
+    }
+    // FheOp::{Zero,One}{Lwe0,Glwe1}
+    Node trivial(spf_value_kind kind, uint64_t bit)
+    {
+        Node n = 0;
+        Evaluation::check(spf_graph_add_trivial(g_, kind, bit, &n), ctx_);
+        return n;
+    }
+    Node op(spf_graph_op o, std::initializer_list<Node> operands, uint64_t param = 0)
+    {
+        Node n = 0;
+        Evaluation::check(spf_graph_add_op(g_, o, operands.begin(), operands.size(), param, &n), ctx_);
+        return n;
+    }
+    // FheOp::Output*: `host` is written by every run()
+    void output(Node node, void* host) { Evaluation::check(spf_graph_add_output(g_, node, host), ctx_); }
+    void run() { Evaluation::check(spf_graph_run(g_), ctx_); }
+
+  private:
+    spf_ctx* ctx_ = nullptr;
+    spf_graph* g_ = nullptr;
 };
 
 } // namespace spf
