@@ -61,6 +61,7 @@ struct spf_ctx {
     size_t ssk_bytes = 0;
     bool ssk_ready = false;
     DevBuf cbs_glwe, cbs_glev;      // circuit-bootstrap intermediates (lo-noise GLWE, GLEV)
+    int n_cu = 256;                // compute units of the device (picks the blind-rotation shape)
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
     bool timing = false;
     std::vector<TimedLaunch> t_pbs, t_ks;
@@ -187,14 +188,25 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         const char* e = getenv("SPF_BLIND_ROTATE_VARIANT");
         return (e && e[0] == '1') ? 1 : 2;
     }();
-    dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(variant == 2 ? 512 : 256);
+    // ciphertexts per workgroup of variant 2: four when the batch fills the chip that way, fewer to
+    // spread a small batch over more CUs (SPF_CTS_PER_WG overrides, for measurements)
+    static const int cts_override = [] {
+        const char* e = getenv("SPF_CTS_PER_WG");
+        return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0;
+    }();
+    const size_t n_cu = (size_t)c->n_cu;
+    const int cts = cts_override ? cts_override : (B <= n_cu ? 1 : (B <= 2 * n_cu ? 2 : 4));
+    const size_t per_wg = variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock;
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? 128 * cts : 256);
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
-    if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16>), grid, block, kBlindRotate2Lds, s, a);
+    if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
+    else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
+    else if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 1>), grid, block, blind_rotate2_lds<1>(), s, a);
     else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, kBlindRotateLds, s, a);
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
@@ -326,6 +338,11 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     } while (0)
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int cu = 0;
+        CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id));
+        if (cu > 0) c->n_cu = cu;
+    }
     std::vector<c64> t;
     build_tables(t);
     CK(hipMalloc((void**)&c->d_tables, kTableBytes));
@@ -353,8 +370,12 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2Lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 4>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<1>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),

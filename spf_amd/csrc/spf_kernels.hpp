@@ -69,7 +69,6 @@ __device__ __forceinline__ int stage_pos(int c) { return ((c & 1) << 10) | (c >>
 //                         workgroup multiplies by next, filled by LDS-DMA (global_load_lds)
 constexpr int kBskSlotBytes = 2 * kHalf * 16; // one (row, level): both output polynomials
 constexpr int kBlindRotateLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 2 * kBskSlotBytes;
-constexpr int kBlindRotate2Lds = kBlindRotateLds + 64; // + one rendezvous word per wave
 
 // issue this thread's share of the DMA that brings one 32 KiB key slot into LDS: 8 x 16 bytes
 // per lane, each wave-instruction lands 1 KiB contiguously (wave-uniform base + lane*16).
@@ -326,10 +325,21 @@ __device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, i
     asm volatile("" ::: "memory");
 }
 
-template <int L, int LOGB>
-__global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a)
+//
+// CTS = ciphertexts per workgroup (4, 2 or 1; 128 CTS threads).  Four fill the CU (two waves per
+// SIMD) and share each key slot four ways: the throughput shape.  For batches that do not fill
+// the chip that way (B < 1024) fewer ciphertexts per workgroup spread the batch over more CUs, and
+// a wave that has its SIMD to itself finishes a CMUX step sooner: the latency shape (one
+// 32-bit addition = a 64-wide bootstrap).  Same arithmetic, same results.
+template <int CTS>
+constexpr int blind_rotate2_lds() { return kTableBytes + CTS * kWaveBufBytes + 2 * kBskSlotBytes + 64; }
+
+template <int L, int LOGB, int CTS>
+__global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel(BlindRotateArgs a)
 {
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+    static_assert(CTS == 1 || CTS == 2 || CTS == 4, "1, 2 or 4 ciphertexts per workgroup");
+    constexpr int NT = 128 * CTS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
@@ -340,19 +350,19 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
-    char* bskring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kBlindRotateLds);
+    char* bskring = smem + kTableBytes + CTS * kWaveBufBytes;
+    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(bskring + 2 * kBskSlotBytes);
     uint32_t seq = 0;
     const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
 
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
+        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
         if (tid < 8) flags[tid] = 0;
     }
 
-    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
+    const uint32_t ct_raw = blockIdx.x * CTS + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
     const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
@@ -368,10 +378,10 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2_kernel(BlindRotateArgs a
         char* dst = bskring + (g & 1) * kBskSlotBytes;
         const int wave_base = tid & ~63;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 2 * kHalf / NT; k++)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + k * 512 + tid),
-                (__attribute__((address_space(3))) void*)(dst + (k * 512 + wave_base) * 16), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(src + k * NT + tid),
+                (__attribute__((address_space(3))) void*)(dst + (k * NT + wave_base) * 16), 16, 0, 0);
     };
     slot_dma(0);
 

@@ -34,6 +34,20 @@ def test_circuit_bootstrap_pbs_parity(small, B):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("B", [255, 257, 510, 515, 1030])
+def test_every_workgroup_shape_is_bit_equal(small, B):
+    """The bootstrap kernel runs 1, 2 or 4 ciphertexts per workgroup depending on how the batch fills
+    the chip (B <= #CU, <= 2 #CU, more); ragged last workgroups included.  Same words from each."""
+    ks, eng = small
+    lwe = random_lwe_batch(4000 + B, B, SMALL_N)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    # a sample against the oracle, the rest against the one-ciphertext-per-workgroup shape
+    for i in (0, 1, B // 2, B - 2, B - 1):
+        assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
+    ref = np.concatenate([eng.circuit_bootstrap_pbs(lwe[i:i + 128]) for i in range(0, B, 128)])
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("log_chi,log_v,rot", [(0, 0, 0), (0, 2, 1 << 62), (1, 1, 12345), (3, 0, M64)])
 def test_generalized_pbs_parity_per_ct_lut(small, log_chi, log_v, rot):
     ks, eng = small
