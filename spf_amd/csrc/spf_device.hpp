@@ -133,23 +133,42 @@ __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory")
 // One 512-point DFT (same DAG and exchange images as fft512_pair below) held by one wave; used
 // by the two-waves-per-ciphertext kernel, where the partner wave on the SIMD hides the LDS
 // round trips.  `buf` is the wave's private 8 KiB tile.
-template <int DIR>
+// PRE (0..7): how many of each pass's seven twiddles are fetched from the LDS image BEFORE the
+// butterflies that precede their use, so the reads travel under ~56 f64 instructions instead of
+// being issued one or two at a time right where they are needed (what the compiler does by itself to
+// save registers: about five exposed LDS round trips per pass).  Costs 4 PRE live VGPRs across the
+// radix-8; the kernels pick what their register budget allows.
+template <int DIR, int PRE = 0>
 __device__ __forceinline__ void fft512_single(c64 (&V)[8], char* buf, const c64* tab, int lane)
 {
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
-    radix8<DIR>(V);
+    {
+        c64 tw[PRE > 0 ? PRE : 1];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) V[k1] = cmul_tw<DIR>(V[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+        for (int k = 0; k < PRE; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+        if constexpr (PRE > 0) compiler_fence();
+        radix8<DIR>(V);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; k1++)
+            V[k1] = cmul_tw<DIR>(V[k1], (k1 - 1 < PRE) ? tw[k1 - 1 < PRE ? k1 - 1 : 0] : tab[kT1Off + (k1 - 1) * 64 + lane]);
+    }
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++)
         *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = V[k1];
     wave_lds_fence();
+    {
+        c64 tw[PRE > 0 ? PRE : 1];
 #pragma unroll
-    for (int a = 0; a < 8; a++) V[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
-    radix8<DIR>(V);
+        for (int k = 0; k < PRE; k++) tw[k] = tab[kT2Off + k * 8 + hi3];
 #pragma unroll
-    for (int c = 1; c < 8; c++) V[c] = cmul_tw<DIR>(V[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+        for (int a = 0; a < 8; a++) V[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
+        if constexpr (PRE > 0) compiler_fence();
+        radix8<DIR>(V);
+#pragma unroll
+        for (int c = 1; c < 8; c++)
+            V[c] = cmul_tw<DIR>(V[c], (c - 1 < PRE) ? tw[c - 1 < PRE ? c - 1 : 0] : tab[kT2Off + (c - 1) * 8 + hi3]);
+    }
     compiler_fence();
 #pragma unroll
     for (int c = 0; c < 8; c++)

@@ -316,6 +316,10 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
 // instructions in order, so data written (and drained with lgkmcnt(0)) before the flag is
 // visible to whoever has seen the flag; reads drained before the flag are complete.  Unlike
 // s_barrier this does not re-align the four ciphertexts of the workgroup with each other.
+// `flags` is deliberately a generic pointer: the compiler then reaches the words with flat_load /
+// flat_store (sc0 sc1), which travel through the vector-memory path instead of queueing in order
+// behind the DS traffic of the transforms.  Declaring them address_space(3) (ds_read / ds_write
+// polling) measured 2 % slower on the whole kernel.
 __device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, int partner, uint32_t& seq)
 {
     seq++;
@@ -340,6 +344,10 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
     static_assert(CTS == 1 || CTS == 2 || CTS == 4, "1, 2 or 4 ciphertexts per workgroup");
     constexpr int NT = 128 * CTS;
+    // twiddles prefetched per pass: all seven when a wave has its SIMD (and 512 registers) to itself;
+    // none at two waves per SIMD, where every prefetched value spills and the partner wave covers
+    // the round trips anyway (measured: 2 -> no change, 3 or 4 -> 1.5 % slower)
+    constexpr int kFftPre = CTS == 4 ? 0 : 7;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
                     V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
                 }
                 pair_barrier(flags, me, partner, seq); // partner is done gathering / done with my last cross data
-                fft512_single<+1>(V, mine, tab, lane);
+                fft512_single<+1, kFftPre>(V, mine, tab, lane);
                 // radix-2 stage across the two waves: wave 0 finishes bins with d < 4, wave 1 d >= 4
                 c64 Ei[4], Oi[4];
                 if (w == 0) {
@@ -485,16 +493,33 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
                     X[i + 4] = csub(Ei[i], t);
                 }
                 const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes) + 256 * w + lane;
+                // key reads run two pairs ahead of the FMAs that consume them (left to itself
+                // the compiler reads two values, drains lgkmcnt, uses them: eight exposed LDS round
+                // trips per digit)
+                c64 kb[3][2];
+                auto key2 = [&](int grp, c64 (&dst)[2]) {
 #pragma unroll
-                for (int q = 0; q < 2; q++)
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                    }
+                };
+                key2(0, kb[0]);
+                key2(1, kb[1]);
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        c64 k = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                for (int grp = 0; grp < 8; grp++) {
+                    if (grp + 2 < 8) key2(grp + 2, kb[(grp + 2) % 3]);
+                    compiler_fence();
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        const c64 k = kb[grp % 3][i];
                         double re = __builtin_fma(k.re, X[r].re, prod[q][r].re);
                         double im = __builtin_fma(k.re, X[r].im, prod[q][r].im);
                         prod[q][r].re = __builtin_fma(-k.im, X[r].im, re);
                         prod[q][r].im = __builtin_fma(k.im, X[r].re, im);
                     }
+                }
             }
         }
 
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
                 for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
             }
             pair_barrier(flags, me, partner, seq); // both cross reads retired before either region is overwritten
-            fft512_single<-1>(V, mine, tab, lane);
+            fft512_single<-1, kFftPre>(V, mine, tab, lane);
             double tv[16];
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) {
