@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,8 @@ using namespace spf;
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr size_t kMaxGridRows = 32768; // rows per launch of the one-grid-row-per-ciphertext kernels
 
 struct DevBuf {
     void* p = nullptr;
@@ -605,8 +608,13 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     if (B == 0) return SPF_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dim3 grid((kN + 1 + 255) / 256, (unsigned)B), block(256);
-    hipLaunchKernelGGL(sample_extract_kernel, grid, block, 0, (hipStream_t)stream, d_glwe, d_out, (uint32_t)B, (uint32_t)idx);
+    // one grid row per ciphertext; grid.y is limited to 65535, larger batches go in slices
+    for (size_t at = 0; at < B; at += kMaxGridRows) {
+        const size_t nb = std::min(B - at, kMaxGridRows);
+        dim3 grid((kN + 1 + 255) / 256, (unsigned)nb), block(256);
+        hipLaunchKernelGGL(sample_extract_kernel, grid, block, 0, (hipStream_t)stream, d_glwe + at * 2 * kN,
+                           d_out + at * (kN + 1), (uint32_t)nb, (uint32_t)idx);
+    }
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }
@@ -616,14 +624,18 @@ static spf_status glwe_linear_dev(spf_ctx* c, void* stream, size_t B, uint32_t o
 {
     if (!c || (B && (!d_a || !d_out || (op == GLWE_XOR && !d_b)))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
-    if (B > 65535) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large (at most 65535 per call)");
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dim3 grid(2 * kN / 256, (unsigned)B), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (op == GLWE_NOT) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_NOT>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
-    else if (op == GLWE_XOR) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_XOR>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
-    else hipLaunchKernelGGL(glwe_linear_kernel<GLWE_MUL_XN>, grid, block, 0, s, d_a, d_b, d_out, (uint32_t)B, n);
+    for (size_t at = 0; at < B; at += kMaxGridRows) {
+        const size_t nb = std::min(B - at, kMaxGridRows), off = at * 2 * kN;
+        dim3 grid(2 * kN / 256, (unsigned)nb), block(256);
+        const uint64_t* pa = d_a + off;
+        const uint64_t* pb = d_b ? d_b + off : nullptr;
+        if (op == GLWE_NOT) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_NOT>, grid, block, 0, s, pa, pb, d_out + off, (uint32_t)nb, n);
+        else if (op == GLWE_XOR) hipLaunchKernelGGL(glwe_linear_kernel<GLWE_XOR>, grid, block, 0, s, pa, pb, d_out + off, (uint32_t)nb, n);
+        else hipLaunchKernelGGL(glwe_linear_kernel<GLWE_MUL_XN>, grid, block, 0, s, pa, pb, d_out + off, (uint32_t)nb, n);
+    }
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }
@@ -695,12 +707,15 @@ spf_status spf_gather_rows_dev(spf_ctx* c, void* stream, size_t rows, size_t wor
 {
     if (!c || (rows && (!d_src_ptrs || !d_dst))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (rows == 0 || words == 0) return SPF_OK;
-    if (rows > 65535 || words > 0xffffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "gather too large");
+    if (words > 0xffffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "gather rows too long");
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dim3 grid((unsigned)((words + 255) / 256), (unsigned)rows), block(256);
-    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, d_src_ptrs, d_dst, (uint32_t)rows,
-                       (uint32_t)words);
+    for (size_t at = 0; at < rows; at += kMaxGridRows) {
+        const size_t nb = std::min(rows - at, kMaxGridRows);
+        dim3 grid((unsigned)((words + 255) / 256), (unsigned)nb), block(256);
+        hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, d_src_ptrs + at, d_dst + at * words,
+                           (uint32_t)nb, (uint32_t)words);
+    }
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }

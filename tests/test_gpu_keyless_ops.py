@@ -87,3 +87,22 @@ def test_evaluation_mirror_linear_ops():
     assert np.array_equal(out, O.glwe_xor(a, b, P.N, P.k))
     ev.mul_xn(out, a, 5)
     assert np.array_equal(out, O.glwe_mul_xn(a, 5, P.N, P.k))
+
+
+def test_batches_beyond_one_grid_slice():
+    """The one-grid-row-per-ciphertext kernels run batches above 32 768 in slices (grid.y limit)."""
+    eng = spf_amd.Engine(to_engine_params(P))
+    B, h = 33000, 5
+    glwe = (np.arange(B * P.glwe_len, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).reshape(B, P.glwe_len)
+    got = eng.sample_extract_l1(glwe, h)
+    # sample_extract (glwe_ciphertext_ops.rs:31-76), vectorised over the batch
+    N = P.N
+    exp = np.empty((B, N + 1), dtype=np.uint64)
+    exp[:, :h + 1] = glwe[:, h::-1][:, :h + 1]
+    exp[:, h + 1:N] = np.uint64(0) - glwe[:, N - 1:h:-1]
+    exp[:, N] = glwe[:, N + h]
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got[B - 1], O.sample_extract(glwe[B - 1], h, P.N, P.k))
+    del got, exp
+    n1 = eng.glwe_not(glwe)
+    assert np.array_equal(n1[:, N], glwe[:, N] + np.uint64(1 << 63)) and np.array_equal(n1[:, :N], glwe[:, :N])
