@@ -96,6 +96,14 @@ class Evaluation:
     def cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
         self._store(output, self.engine.cmux(sel, a, b))
 
+    # KeylessEvaluation::glev_cmux (evaluation.rs:86-101): L1 GLEV = cbs_radix.count consecutive GLWEs
+    def glev_cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
+        self._store(output, self.engine.glev_cmux(sel, a, b))
+
+    # KeylessEvaluation::multiply_glwe_ggsw (evaluation.rs:104-123)
+    def multiply_glwe_ggsw(self, output: np.ndarray, glwe: np.ndarray, ggsw: np.ndarray):
+        self._store(output, self.engine.multiply_glwe_ggsw(glwe, ggsw))
+
     # FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap fused (circuit_processor/mod.rs:329-340,453-463)
     def gate_bootstrap(self, output: np.ndarray, input_l1: np.ndarray):
         self._store(output, self.engine.gate_bootstrap(input_l1))
