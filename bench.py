@@ -237,15 +237,16 @@ def main() -> int:
     alg_bytes = P.bsk_complex * 16 + B * (P.lwe0_words * 8 + P.glwe_words * 8)
     # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate runs; FETCH_SIZE
     # doubled per the gfx950 correction) — written by tools_summarize_prof.py, only valid for B = 4096
-    traffic = None
+    traffic, traffic_detail = None, None
     tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
     if B == 4096 and os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f)
+            traffic_detail = json.load(f)
+        traffic = traffic_detail.get("total_bytes")
     roofline = {
         "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
-        "kernel": "blind_rotate2_kernel<2,16>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
+        "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+        "traffic_detail": traffic_detail, "kernel": "blind_rotate2_kernel<2,16,4>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
         "note": "f64 work runs on the VALU (v_fma_f64); MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and "
                 "MFMA alike, so the MFMA-f64 peak is the compute roof",
