@@ -229,6 +229,9 @@ inline spf_status plan(spf_graph* g)
 inline spf_status run(spf_graph* g)
 {
     spf_ctx* c = g->ctx;
+    // one graph at a time per context: the _dev calls below share the context's scratch buffers and
+    // stream, and a run must not interleave its launches with another run's
+    std::lock_guard<std::recursive_mutex> whole(c->mu);
     if (!g->planned) {
         spf_status st = plan(g);
         if (st != SPF_OK) return st;

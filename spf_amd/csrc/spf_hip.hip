@@ -43,7 +43,7 @@ struct TimedLaunch {
 struct spf_ctx {
     spf_params prm{};
     int device = 0;
-    std::mutex mu;
+    std::recursive_mutex mu; // recursive: the host-pointer entry points hold it across the _dev calls they make
     std::string err;
     c64* d_tables = nullptr;
     c64* d_bsk = nullptr;
@@ -408,7 +408,7 @@ void spf_destroy(spf_ctx* c)
 spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
 {
     if (!c || !dev_ptr || !bytes) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (which == 0) {
         size_t need = (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count) * sizeof(c64);
@@ -435,7 +435,7 @@ spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
 spf_status spf_key_blob_commit(spf_ctx* c, int which)
 {
     if (!c) return SPF_ERR_INVALID_ARGUMENT;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     if (which == 0 && c->d_bsk) c->bsk_ready = true;
     else if (which == 1 && c->d_ksk) {
         spf_status st = build_ks_planes(c);
@@ -457,7 +457,7 @@ spf_status spf_load_bootstrap_key(spf_ctx* c, const double* bsk_fft, size_t n_co
     void* p; size_t bytes;
     spf_status s = spf_key_blob(c, 0, &p, &bytes);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, bsk_fft, bytes, hipMemcpyHostToDevice));
     c->bsk_ready = true;
     return SPF_OK;
@@ -472,7 +472,7 @@ spf_status spf_load_keyswitch_key(spf_ctx* c, const uint64_t* ksk, size_t n_word
     void* p; size_t bytes;
     spf_status s = spf_key_blob(c, 1, &p, &bytes);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, ksk, bytes, hipMemcpyHostToDevice));
     spf_status st = build_ks_planes(c);
     if (st != SPF_OK) return st;
@@ -485,7 +485,7 @@ spf_status spf_load_keyswitch_key(spf_ctx* c, const uint64_t* ksk, size_t n_word
 spf_status spf_keyswitch_lwe_l1_lwe_l0_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_in, uint64_t* d_out)
 {
     if (!c || (B && (!d_in || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_keyswitch(c, (hipStream_t)stream, B, d_in, d_out);
 }
@@ -495,7 +495,7 @@ spf_status spf_generalized_pbs_dev(spf_ctx* c, void* stream, size_t B, const uin
                                    uint64_t* d_out)
 {
     if (!c || (B && (!d_lwe || !d_lut || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, d_lut, lut_stride, log_chi, log_v, body_rotate, d_out,
                                glwe_words(c->prm), false);
@@ -505,7 +505,7 @@ spf_status spf_pbs_univariate_dev(spf_ctx* c, void* stream, size_t B, const uint
                                   size_t lut_stride, uint64_t* d_out)
 {
     if (!c || (B && (!d_lwe || !d_lut || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, d_lut, lut_stride, 0, 0, 0, d_out, lwe1_words(c->prm), true);
 }
@@ -513,7 +513,7 @@ spf_status spf_pbs_univariate_dev(spf_ctx* c, void* stream, size_t B, const uint
 spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, uint64_t* d_out)
 {
     if (!c || (B && (!d_lwe || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     // hi_noise_lwe_to_lo_noise_glwe (circuit_bootstrapping.rs:387-427)
     return launch_blind_rotate(c, (hipStream_t)stream, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count),
@@ -559,7 +559,7 @@ spf_status spf_mod_switch_trace_and_rotate_dev(spf_ctx* c, void* stream, size_t 
     if (!c || (B && (!d_glwe || !d_glev))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     spf_status st = tail_supported(c);
     if (st != SPF_OK) return st;
@@ -571,7 +571,7 @@ spf_status spf_scheme_switch_dev(spf_ctx* c, void* stream, size_t B, const uint6
     if (!c || (B && (!d_glev || !d_ggsw))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     spf_status st = tail_supported(c);
     if (st != SPF_OK) return st;
@@ -583,7 +583,7 @@ spf_status spf_circuit_bootstrap_dev(spf_ctx* c, void* stream, size_t B, const u
     if (!c || (B && (!d_lwe || !d_ggsw))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     spf_status st = tail_supported(c);
     if (st != SPF_OK) return st;
@@ -606,7 +606,7 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     if (!c || (B && (!d_glwe || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (idx >= c->prm.polynomial_degree) return fail(c, SPF_ERR_INVALID_ARGUMENT, "sample_extract index >= polynomial_degree");
     if (B == 0) return SPF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     // one grid row per ciphertext; grid.y is limited to 65535, larger batches go in slices
     for (size_t at = 0; at < B; at += kMaxGridRows) {
@@ -624,7 +624,7 @@ static spf_status glwe_linear_dev(spf_ctx* c, void* stream, size_t B, uint32_t o
 {
     if (!c || (B && (!d_a || !d_out || (op == GLWE_XOR && !d_b)))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     for (size_t at = 0; at < B; at += kMaxGridRows) {
@@ -677,7 +677,7 @@ spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel,
                         uint64_t* d_out)
 {
     if (!c || (B && (!d_sel || !d_a || !d_b || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_cmux(c, (hipStream_t)stream, B, 1, d_sel, d_a, d_b, d_out);
 }
@@ -691,7 +691,7 @@ spf_status spf_cmux_scattered_dev(spf_ctx* c, void* stream, size_t units, const 
         return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
     if (units == 0) return SPF_OK;
     if (units > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     CmuxArgs a{};
     a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = 1; a.ptrs = d_ptrs;
@@ -708,7 +708,7 @@ spf_status spf_gather_rows_dev(spf_ctx* c, void* stream, size_t rows, size_t wor
     if (!c || (rows && (!d_src_ptrs || !d_dst))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (rows == 0 || words == 0) return SPF_OK;
     if (words > 0xffffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "gather rows too long");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     for (size_t at = 0; at < rows; at += kMaxGridRows) {
         const size_t nb = std::min(rows - at, kMaxGridRows);
@@ -726,7 +726,7 @@ spf_status spf_glev_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d
                              const uint64_t* d_b, uint64_t* d_out)
 {
     if (!c || (B && (!d_sel || !d_a || !d_b || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_cmux(c, (hipStream_t)stream, B * c->prm.cbs_radix_count, c->prm.cbs_radix_count, d_sel, d_a, d_b, d_out);
 }
@@ -736,7 +736,7 @@ spf_status spf_multiply_glwe_ggsw_dev(spf_ctx* c, void* stream, size_t B, const 
                                       uint64_t* d_out)
 {
     if (!c || (B && (!d_glwe || !d_ggsw || !d_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return launch_cmux(c, (hipStream_t)stream, B, 1, d_ggsw, nullptr, d_glwe, d_out);
 }
@@ -754,7 +754,7 @@ spf_status spf_keyswitch_lwe_l1_lwe_l0_batch(spf_ctx* c, size_t B, const uint64_
 {
     if (!c || (B && (!in || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     STAGE_IN(c->in, in, B * lwe1_words(c->prm) * 8);
     spf_status s = ensure(c, c->out, B * lwe0_words(c->prm) * 8);
@@ -771,7 +771,7 @@ static spf_status pbs_host(spf_ctx* c, size_t B, const uint64_t* lwe, const uint
 {
     if (!c || (B && (!lwe || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     STAGE_IN(c->in, lwe, B * lwe0_words(c->prm) * 8);
     const uint64_t* d_lut = c->d_cbs_lut;
@@ -818,8 +818,8 @@ spf_status spf_sample_extract_l1_batch(spf_ctx* c, size_t B, const uint64_t* glw
     if (!c || (B && (!glwe || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (idx >= c->prm.polynomial_degree) return fail(c, SPF_ERR_INVALID_ARGUMENT, "sample_extract index >= polynomial_degree");
     if (B == 0) return SPF_OK;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->in, glwe, B * glwe_words(c->prm) * 8);
         spf_status s = ensure(c, c->out, B * lwe1_words(c->prm) * 8);
@@ -827,7 +827,7 @@ spf_status spf_sample_extract_l1_batch(spf_ctx* c, size_t B, const uint64_t* glw
     }
     spf_status s = spf_sample_extract_l1_dev(c, c->stream, B, (const uint64_t*)c->in.p, idx, (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * lwe1_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -839,8 +839,8 @@ static spf_status glwe_linear_host(spf_ctx* c, size_t B, uint32_t op, const uint
     if (!c || (B && (!a || !out || (op == GLWE_XOR && !b)))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t gw = glwe_words(c->prm) * 8;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->in, a, B * gw);
         if (op == GLWE_XOR) STAGE_IN(c->mid, b, B * gw);
@@ -851,7 +851,7 @@ static spf_status glwe_linear_host(spf_ctx* c, size_t B, uint32_t op, const uint
                                    op == GLWE_XOR ? (const uint64_t*)c->mid.p : nullptr,
                                    (uint32_t)(n % (2 * (size_t)kN)), (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -877,8 +877,8 @@ spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_
     if (!c || (B && (!sel || !a || !b || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t gw = glwe_words(c->prm) * 8, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->aux, sel, B * sw);
         STAGE_IN(c->in, a, B * gw);
@@ -889,7 +889,7 @@ spf_status spf_cmux_batch(spf_ctx* c, size_t B, const double* sel, const uint64_
     spf_status s = spf_cmux_dev(c, c->stream, B, (const double*)c->aux.p, (const uint64_t*)c->in.p,
                                 (const uint64_t*)c->mid.p, (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -900,8 +900,8 @@ spf_status spf_glev_cmux_batch(spf_ctx* c, size_t B, const double* sel, const ui
     if (!c || (B && (!sel || !a || !b || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t ev = glwe_words(c->prm) * 8 * c->prm.cbs_radix_count, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->aux, sel, B * sw);
         STAGE_IN(c->in, a, B * ev);
@@ -912,7 +912,7 @@ spf_status spf_glev_cmux_batch(spf_ctx* c, size_t B, const double* sel, const ui
     spf_status s = spf_glev_cmux_dev(c, c->stream, B, (const double*)c->aux.p, (const uint64_t*)c->in.p,
                                      (const uint64_t*)c->mid.p, (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * ev, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -923,8 +923,8 @@ spf_status spf_multiply_glwe_ggsw_batch(spf_ctx* c, size_t B, const uint64_t* gl
     if (!c || (B && (!glwe || !ggsw || !out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t gw = glwe_words(c->prm) * 8, sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->aux, ggsw, B * sw);
         STAGE_IN(c->in, glwe, B * gw);
@@ -934,7 +934,7 @@ spf_status spf_multiply_glwe_ggsw_batch(spf_ctx* c, size_t B, const uint64_t* gl
     spf_status s = spf_multiply_glwe_ggsw_dev(c, c->stream, B, (const uint64_t*)c->in.p, (const double*)c->aux.p,
                                               (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -948,7 +948,7 @@ static spf_status load_fft_key(spf_ctx* c, int which, const double* src, size_t 
     void* p; size_t bytes;
     spf_status s = spf_key_blob(c, which, &p, &bytes);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     *ready = true;
     return SPF_OK;
@@ -971,8 +971,8 @@ spf_status spf_mod_switch_trace_and_rotate_batch(spf_ctx* c, size_t B, const uin
     if (!c || (B && (!glwe_in || !glev_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t gw = glwe_words(c->prm) * 8, ev = gw * c->prm.cbs_radix_count;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->in, glwe_in, B * gw);
         spf_status s = ensure(c, c->out, B * ev);
@@ -980,7 +980,7 @@ spf_status spf_mod_switch_trace_and_rotate_batch(spf_ctx* c, size_t B, const uin
     }
     spf_status s = spf_mod_switch_trace_and_rotate_dev(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(glev_out, c->out.p, B * ev, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -992,8 +992,8 @@ spf_status spf_scheme_switch_batch(spf_ctx* c, size_t B, const uint64_t* glev_in
     if (B == 0) return SPF_OK;
     const size_t ev = glwe_words(c->prm) * 8 * c->prm.cbs_radix_count;
     const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->in, glev_in, B * ev);
         spf_status s = ensure(c, c->out, B * sw);
@@ -1001,7 +1001,7 @@ spf_status spf_scheme_switch_batch(spf_ctx* c, size_t B, const uint64_t* glev_in
     }
     spf_status s = spf_scheme_switch_dev(c, c->stream, B, (const uint64_t*)c->in.p, (double*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(ggsw_out, c->out.p, B * sw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -1012,8 +1012,8 @@ spf_status spf_circuit_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe
     if (!c || (B && (!lwe0_in || !ggsw_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
     const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu); // staging buffers are shared: one caller at a time
     {
-        std::lock_guard<std::mutex> g(c->mu);
         HIPCHK(c, hipSetDevice(c->device));
         STAGE_IN(c->in, lwe0_in, B * lwe0_words(c->prm) * 8);
         spf_status s = ensure(c, c->out, B * sw);
@@ -1021,7 +1021,7 @@ spf_status spf_circuit_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe
     }
     spf_status s = spf_circuit_bootstrap_dev(c, c->stream, B, (const uint64_t*)c->in.p, (double*)c->out.p);
     if (s != SPF_OK) return s;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(ggsw_out, c->out.p, B * sw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPF_OK;
@@ -1031,7 +1031,7 @@ spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, 
 {
     if (!c || (B && (!lwe1 || !glwe_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
     if (B == 0) return SPF_OK;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     STAGE_IN(c->in, lwe1, B * lwe1_words(c->prm) * 8);
     spf_status s = ensure(c, c->mid, B * lwe0_words(c->prm) * 8);
@@ -1054,7 +1054,7 @@ spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, 
 spf_status spf_set_timing(spf_ctx* c, int enabled)
 {
     if (!c) return SPF_ERR_INVALID_ARGUMENT;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     c->timing = enabled != 0;
     return SPF_OK;
 }
@@ -1062,7 +1062,7 @@ spf_status spf_set_timing(spf_ctx* c, int enabled)
 spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, int* launches)
 {
     if (!c || !kernel || !avg_ms || !launches) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<TimedLaunch>* v = nullptr;
     if (!strcmp(kernel, "pbs")) v = &c->t_pbs;

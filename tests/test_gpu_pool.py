@@ -78,3 +78,30 @@ def test_pool_reports_errors_to_the_waiter():
     with pytest.raises(spf_amd.SpfError):
         pool.circuit_bootstrap(out, random_lwe_batch(1, 1, SMALL_N)[0])
     pool.close()
+
+
+def test_concurrent_batch_callers_on_one_context(rig):
+    """The host-pointer entry points share the context's staging buffers; calls from many threads
+    (ctypes drops the GIL) must serialise as whole calls — stage, launch, copy back — not interleave."""
+    ks, eng = rig
+    P = ks.params
+    jobs = []
+    for t in range(24):
+        B = 1 + (t * 5) % 9
+        jobs.append((t % 3, random_lwe_batch(700 + t, B, P.N * P.k), random_glwe(800 + t, B, P.glwe_len),
+                     random_glwe(900 + t, B, P.glwe_len)))
+    ggsw = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(random_lwe_batch(5, 1, P.N * P.k)))
+
+    def run(job):
+        kind, lwe1, a, b = job
+        if kind == 0:
+            return eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+        if kind == 1:
+            return eng.cmux(np.repeat(ggsw, a.shape[0], axis=0), a, b)
+        return eng.sample_extract_l1(eng.glwe_xor(a, b), 3)
+
+    expected = [run(j) for j in jobs]                      # one at a time
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        got = list(ex.map(run, jobs * 3))
+    for i, g in enumerate(got):
+        assert np.array_equal(g, expected[i % len(jobs)]), i
