@@ -72,7 +72,9 @@ typedef struct spf_ctx spf_ctx;
  * per-GPU engine (twiddle tables, scratch).  device_id is the HIP ordinal. */
 spf_status spf_create(const spf_params *params, int device_id, spf_ctx **out);
 void spf_destroy(spf_ctx *ctx);
-/* Message of the last failing call on this context (or on creation when ctx == NULL). */
+/* Message of the last failing call on this context (or, with ctx == NULL, of the last failing
+ * spf_create on the calling thread).  The returned pointer is storage of the calling thread: it
+ * stays valid until that thread calls spf_last_error again, whatever other threads do. */
 const char *spf_last_error(const spf_ctx *ctx);
 
 /* ---- keys: `ComputeKey` fields (crypto/keys.rs:306-318) ------------------------------- */

@@ -44,7 +44,8 @@ struct spf_ctx {
     spf_params prm{};
     int device = 0;
     std::recursive_mutex mu; // recursive: the host-pointer entry points hold it across the _dev calls they make
-    std::string err;
+    std::string err;               // last error message; guarded by err_mu (read and written from any thread)
+    mutable std::mutex err_mu;
     c64* d_tables = nullptr;
     c64* d_bsk = nullptr;
     size_t bsk_bytes = 0;
@@ -77,7 +78,12 @@ namespace {
 
 spf_status fail(spf_ctx* c, spf_status s, const std::string& msg)
 {
-    if (c) c->err = msg; else g_create_error = msg;
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        c->err = msg;
+    } else {
+        g_create_error = msg;
+    }
     return s;
 }
 
@@ -314,7 +320,16 @@ void spf_default_params(spf_params* o)
 
 const char* spf_version(void) { return "spf_hip 0.2 (gfx950: two-wave blind rotation, int8-MFMA keyswitch, cbs_radix cmux)"; }
 
-const char* spf_last_error(const spf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+// The text is copied into storage of the calling thread, so the pointer stays valid while other
+// threads keep using (and failing on) the same context.
+const char* spf_last_error(const spf_ctx* ctx)
+{
+    thread_local std::string copy;
+    if (!ctx) return g_create_error.c_str();
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
 {
