@@ -22,6 +22,12 @@ def build(native: bool = False) -> str:
     return os.path.join(_HERE, target)
 
 
+def library_path() -> str:
+    """Path of the built (portable) oracle library, for native tests that link it."""
+    _load()
+    return os.path.join(_HERE, "libspf_oracle.so")
+
+
 def _load(native: bool = False):
     global _LIB
     if _LIB is not None and not native:
