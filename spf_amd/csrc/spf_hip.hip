@@ -203,8 +203,13 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         const char* e = getenv("SPF_CTS_PER_WG");
         return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0;
     }();
+    // the small shapes run the two-transforms-at-once schedule (blind_rotate2w_kernel); SPF_WIDE=0 keeps
+    // the narrow schedule for A/B measurements
+    static const bool wide = [] { const char* e = getenv("SPF_WIDE"); return !(e && e[0] == '0'); }();
     const size_t n_cu = (size_t)c->n_cu;
-    const int cts = cts_override ? cts_override : (B <= n_cu ? 1 : (B <= 2 * n_cu ? 2 : 4));
+    // up to two ciphertexts per CU: the latency schedule, one ciphertext per workgroup (two such
+    // workgroups share a CU when B > #CU: 65 KiB of LDS and one wave per SIMD each)
+    const int cts = cts_override ? cts_override : (B <= 2 * n_cu ? (wide ? 1 : (B <= n_cu ? 1 : 2)) : 4);
     const size_t per_wg = variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock;
     dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? 128 * cts : 256);
     TimedLaunch tl{};
@@ -214,6 +219,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
     if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
+    else if (variant == 2 && wide && cts == 1) hipLaunchKernelGGL((blind_rotate2w_kernel<2, 16, 1>), grid, block, blind_rotate2w_lds<1>(), s, a);
     else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
     else if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 1>), grid, block, blind_rotate2_lds<1>(), s, a);
     else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, kBlindRotateLds, s, a);
@@ -394,6 +400,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<1>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2w_kernel<2, 16, 1>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2w_lds<1>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),

@@ -598,6 +598,277 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
 }
 
 // ------------------------------------------------------------------------------------------
+// blind_rotate2w_kernel: the LATENCY shape of blind_rotate2_kernel, for batches that leave most of
+// the chip idle (B <= 2 x #CU): ONE ciphertext per workgroup (two such workgroups share a CU when
+// B > #CU), one wave per SIMD, so a wave owns 512 registers and 16 KiB of LDS — enough to advance TWO
+// transforms at once.  Same split of a
+// ciphertext over two waves (sample parity), same arithmetic and results; what changes is the
+// schedule of one CMUX step:
+//   * both digits of a polynomial go through `fft512_pair` together (one transform's exchange round
+//     trip under the other's butterflies), their cross exchanges share one rendezvous, and both
+//     multiply-accumulates follow;
+//   * both output polynomials do the same on the way back;
+//   * no key ring and no workgroup barrier: so few waves share a key value that each reads its own
+//     bins straight into registers at the top of the polynomial (the LDS-DMA pieces of a ring cost a
+//     lone wave 16 % of its step just to issue); the rendezvous of the two waves does not touch
+//     vmcnt, so those loads stay in flight across it.
+// A lone wave of the narrow schedule issues only 38 % of the time (its own LDS round trips and
+// rendezvous); this schedule has two independent chains to interleave.
+template <int CTS>
+constexpr int blind_rotate2w_lds() { return kTableBytes + CTS * 2 * kWaveBufBytes; }
+
+// Rendezvous of the latency shape: one ciphertext per workgroup, so the pair IS the workgroup and
+// s_barrier does it.  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
+// loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
+__device__ __forceinline__ void pair_barrier_w()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int L, int LOGB, int CTS>
+__global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotateArgs a)
+{
+    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
+    static_assert(CTS == 1, "one ciphertext per workgroup: the pair rendezvous is s_barrier");
+    constexpr int NT = 128 * CTS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int cslot = wv >> 1;
+    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    // per ciphertext: [wave 0: image A, image B][wave 1: image A, image B], 8 KiB each
+    char* tile = smem + kTableBytes + cslot * 2 * kWaveBufBytes;
+    char* mine = tile + w * 16384;
+    char* mineB = mine + 8192;
+    char* theirs = tile + (w ^ 1) * 16384;
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
+    }
+    const uint32_t ct_raw = blockIdx.x * CTS + cslot;
+    const bool owns_output = ct_raw < a.B;
+    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
+    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
+    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
+
+    // No key ring here: with one or two ciphertexts per workgroup a key value is used by one or two
+    // waves, so each wave reads the bins it multiplies straight from L2/HBM into registers (16 x 1 KiB
+    // per digit), at the top of the polynomial, and they land while it decomposes and transforms.
+    // Key row (step, p, level L-1-j): GLEV rows are consumed in reverse.
+    auto key_row = [&](uint32_t step, int p, int j) -> const c64* {
+        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf) + 256 * w + lane;
+    };
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+
+    uint64_t acc[2][16];
+    {
+        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + bt;
+                uint64_t v = lut[p * kN + (idx & (kN - 1))];
+                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+            }
+    }
+
+    __syncthreads(); // twiddle image in place
+
+    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
+    // the twist factors and the cross-stage twiddles of a lane never change: with 512 registers they
+    // live in registers for the whole rotation (the narrow kernel re-reads them from the LDS image)
+    c64 twist[8], wc[4];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
+    uint64_t a_next = lwe[0];
+    for (uint32_t step = 0; step < a.n; step++) {
+        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
+        a_next = lwe[step + 1];
+        c64 prod[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
+
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            // [digit][output polynomial * 8 + r]: this wave's bins of the two key rows, requested now
+            c64 key[2][16];
+            auto load_key = [&](int j) {
+                const c64* row = key_row(step, p, j);
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) key[j][q * 8 + r] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+            };
+            load_key(0);
+            load_key(1);
+
+            uint32_t dig[16];
+            // partner must be done reading my region (staging and cross data live in image A): for
+            // p = 0 the rendezvous ahead of the last inverse transforms guarantees it
+            if (p == 1) pair_barrier_w();
+#pragma unroll
+            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
+            pair_barrier_w(); // both parities staged
+            // all sixteen gather reads first (left alone the compiler issues them one at a time, each
+            // with its own lgkmcnt(0))
+            uint64_t gin[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t srcc = ((uint32_t)coef2(e) + 2 * kN - at) & (kN - 1);
+                gin[e] = reinterpret_cast<const uint64_t*>(tile + (srcc & 1) * 16384)[srcc >> 1];
+            }
+            compiler_fence();
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
+                uint64_t v = gin[e];
+                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+                uint64_t diff = rot - acc[p][e];
+                constexpr int shift = 64 - L * LOGB;
+                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    uint32_t d = s & ((1u << LOGB) - 1);
+                    s >>= LOGB;
+                    s += d >> (LOGB - 1);
+                    packed |= d << (j * LOGB);
+                }
+                dig[e] = packed;
+            }
+            c64 VV[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int n1 = 0; n1 < 8; n1++) {
+                    const int sh = j * LOGB;
+                    int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                    int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                    VV[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
+                }
+            pair_barrier_w(); // partner is done gathering from my image A
+            fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
+            // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes
+            // bins with d < 4 and sends registers 4..7, wave 1 the other way round
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? VV[j][4 + i].re : VV[j][i].re,
+                                                                             w == 0 ? VV[j][4 + i].im : VV[j][i].im};
+            pair_barrier_w();
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                c64 X[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                    const c64 Ei = {w == 0 ? VV[j][i].re : in.re, w == 0 ? VV[j][i].im : in.im};
+                    const c64 Oi = {w == 0 ? in.re : VV[j][4 + i].re, w == 0 ? in.im : VV[j][4 + i].im};
+                    c64 t = cmul_tw<+1>(Oi, wc[i]);
+                    X[i] = cadd(Ei, t);
+                    X[i + 4] = csub(Ei, t);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) VV[j][r] = X[r];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const c64 k = key[j][q * 8 + r];
+                        double re = __builtin_fma(k.re, VV[j][r].re, prod[q][r].re);
+                        double im = __builtin_fma(k.re, VV[j][r].im, prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
+                    }
+            }
+        }
+
+        // ---- back to the torus, both output polynomials together
+        c64 WW[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                       // Ep: kept by wave 0
+                WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wc[i]); // Op: kept by wave 1
+            }
+        pair_barrier_w(); // partner is done with my last forward cross data
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = {w == 0 ? WW[q][4 + i].re : WW[q][i].re,
+                                                                         w == 0 ? WW[q][4 + i].im : WW[q][i].im};
+        pair_barrier_w();
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c64 in = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+                WW[q][4 + i] = {w == 0 ? in.re : WW[q][4 + i].re, w == 0 ? in.im : WW[q][4 + i].im};
+                WW[q][i] = {w == 0 ? WW[q][i].re : in.re, w == 0 ? WW[q][i].im : in.im};
+            }
+        pair_barrier_w(); // both cross reads retired before either region is overwritten
+        fft512_pair<-1>(WW[0], WW[1], mine, mineB, tab, lane);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double tv[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                c64 xs = {WW[q][n1].re * (1.0 / 1024.0), WW[q][n1].im * (1.0 / 1024.0)};
+                c64 t = cmul_nf_conj(xs, twist[n1]);
+                tv[n1] = t.re;
+                tv[8 + n1] = t.im;
+            }
+            double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+            for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+            if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[q][e] += f64_round_to_torus(tv[e]);
+            }
+        }
+    }
+
+    if (!owns_output) return;
+    uint64_t* out = a.out + (size_t)ct * a.out_stride;
+    if (!a.sample_extract) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int c = coef2(e);
+            if (c == 0) {
+                out[0] = acc[0][e];
+                out[kN] = acc[1][e];
+            } else {
+                out[kN - c] = (uint64_t)0 - acc[0][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // cmux_kernel: batched `cmux` (ops/fft_ops.rs:149-181) with a per-ciphertext GGSW selector,
 //   out = d0 + IFFT( sum_{p,j} FFT(digit_j(d1 - d0)_p) . GGSW[p][L-1-j] ),
 // the operation `KeylessEvaluation::cmux` performs for every gate of a CMUX tree (GGSW in
