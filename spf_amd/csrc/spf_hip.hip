@@ -210,15 +210,19 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     // up to two ciphertexts per CU: the latency schedule, one ciphertext per workgroup (two such
     // workgroups share a CU when B > #CU: 65 KiB of LDS and one wave per SIMD each)
     const int cts = cts_override ? cts_override : (B <= 2 * n_cu ? (wide ? 1 : (B <= n_cu ? 1 : 2)) : 4);
+    // at most one ciphertext per CU: four waves per ciphertext (blind_rotate4_kernel); SPF_QUAD=0 disables
+    static const bool quad_on = [] { const char* e = getenv("SPF_QUAD"); return !(e && e[0] == '0'); }();
+    const bool quad = variant == 2 && wide && quad_on && !cts_override && B <= n_cu;
     const size_t per_wg = variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock;
-    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? 128 * cts : 256);
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? (quad ? 256 : 128 * cts) : 256);
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
-    if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
+    if (quad) hipLaunchKernelGGL((blind_rotate4_kernel<2, 16>), grid, block, kBlindRotate4Lds, s, a);
+    else if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
     else if (variant == 2 && wide && cts == 1) hipLaunchKernelGGL((blind_rotate2w_kernel<2, 16, 1>), grid, block, blind_rotate2w_lds<1>(), s, a);
     else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
     else if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 1>), grid, block, blind_rotate2_lds<1>(), s, a);
@@ -402,6 +406,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<1>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2w_kernel<2, 16, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2w_lds<1>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),

@@ -869,6 +869,270 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
 }
 
 // ------------------------------------------------------------------------------------------
+// blind_rotate4_kernel: FOUR waves per ciphertext, one ciphertext per workgroup, one wave per SIMD —
+// the shape for batches of at most one ciphertext per CU (B <= #CU), where latency is all that
+// counts.  Wave (w, h): sample parity w (as in the two-wave kernels) and polynomial h.  The two
+// polynomials of a CMUX step are independent until the multiply-accumulate, so the pair h = 0 and
+// the pair h = 1 each rotate, decompose and transform ONE polynomial (both digits together,
+// `fft512_pair`) at the same time, and each transforms ONE output polynomial back.  The accumulation
+//   prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q          (in this order, each term 4 FMAs)
+// stays the sequential chain the reference's `glwe_ggsw_mad` defines: the h = 0 waves run the first
+// two terms from zero and pass the partial sums (both q) through LDS to the h = 1 waves, which run
+// the last two and pass prod[0] back.  Same operations in the same order on every value: same words.
+// All hand-overs are s_barrier among the four waves (nine per step); keys go straight from L2 into
+// registers as in blind_rotate2w_kernel.
+constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192;
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a)
+{
+    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 1, h = wv >> 1;
+    // region of wave (w, h): two 8 KiB images
+    auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 16384; };
+    char* mine = region(w, h);
+    char* mineB = mine + 8192;
+    char* partner = region(w ^ 1, h); // same polynomial, other parity
+    char* sibling = region(w, h ^ 1); // same parity, other polynomial
+    auto wg_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // not __syncthreads(): keep the key loads in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
+    }
+    const uint32_t ct = blockIdx.x; // grid = B
+    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
+    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+
+    uint64_t acc[16]; // polynomial h, parity w
+    {
+        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            uint32_t idx = (uint32_t)coef2(e) + bt;
+            uint64_t v = lut[h * kN + (idx & (kN - 1))];
+            acc[e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+        }
+    }
+    __syncthreads(); // twiddle image in place
+
+    c64 twist[8], wc[4];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
+
+    uint64_t a_next = lwe[0];
+    for (uint32_t step = 0; step < a.n; step++) {
+        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
+        a_next = lwe[step + 1];
+
+        // this wave's bins of the two key rows of polynomial h (levels consumed in reverse), both
+        // output polynomials: [digit][q * 8 + r]
+        c64 key[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const c64* row = a.bsk + ((size_t)step * (2 * L) + (h * L + (L - 1 - j))) * (2 * kHalf) + 256 * w + lane;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) key[j][q * 8 + r] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+        }
+
+        // ---- rotate, subtract, decompose polynomial h
+        uint64_t* stage = reinterpret_cast<uint64_t*>(mine);
+#pragma unroll
+        for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
+        wg_barrier(); // 1: both parities of both polynomials staged
+        uint32_t dig[16];
+        {
+            uint64_t gin[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t srcc = ((uint32_t)coef2(e) + 2 * kN - at) & (kN - 1);
+                gin[e] = reinterpret_cast<const uint64_t*>(region((int)(srcc & 1), h))[srcc >> 1];
+            }
+            compiler_fence();
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
+                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - gin[e] : gin[e];
+                uint64_t diff = rot - acc[e];
+                constexpr int shift = 64 - L * LOGB;
+                uint32_t sd = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    uint32_t d = sd & ((1u << LOGB) - 1);
+                    sd >>= LOGB;
+                    sd += d >> (LOGB - 1);
+                    packed |= d << (j * LOGB);
+                }
+                dig[e] = packed;
+            }
+        }
+        c64 VV[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                const int sh = j * LOGB;
+                int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                VV[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
+            }
+        wg_barrier(); // 2: everyone is done gathering; the images are free
+        fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
+        // radix-2 stage across the parities, both digits in one exchange
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? VV[j][4 + i].re : VV[j][i].re,
+                                                                         w == 0 ? VV[j][4 + i].im : VV[j][i].im};
+        wg_barrier(); // 3
+        {
+            c64 xin[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(partner)[(j * 4 + i) * 64 + lane];
+            compiler_fence();
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                c64 X[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const c64 in = xin[j][i];
+                    const c64 Ei = {w == 0 ? VV[j][i].re : in.re, w == 0 ? VV[j][i].im : in.im};
+                    const c64 Oi = {w == 0 ? in.re : VV[j][4 + i].re, w == 0 ? in.im : VV[j][4 + i].im};
+                    c64 t = cmul_tw<+1>(Oi, wc[i]);
+                    X[i] = cadd(Ei, t);
+                    X[i + 4] = csub(Ei, t);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) VV[j][r] = X[r];
+            }
+        }
+        wg_barrier(); // 4: cross reads retired; the regions can carry the partial sums
+
+        // ---- multiply-accumulate, a chain through h = 0 then h = 1
+        c64 prod[2][8];
+        auto mad_two_digits = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const c64 k = key[j][q * 8 + r];
+                        double re = __builtin_fma(k.re, VV[j][r].re, prod[q][r].re);
+                        double im = __builtin_fma(k.re, VV[j][r].im, prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
+                    }
+        };
+        if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
+            mad_two_digits();
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(q * 8 + r) * 64 + lane] = prod[q][r];
+        }
+        wg_barrier(); // 5: partial sums of rows (0, j) are in the h = 0 regions
+        if (h == 1) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) prod[q][r] = reinterpret_cast<const c64*>(sibling)[(q * 8 + r) * 64 + lane];
+            mad_two_digits();
+#pragma unroll
+            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[r * 64 + lane] = prod[0][r]; // for the h = 0 wave
+        }
+        wg_barrier(); // 6: prod[0] is in the h = 1 regions
+        c64 V[8]; // prod[h]
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const c64 mineval = prod[1][r]; // meaningful for h = 1 only
+            const c64 got = reinterpret_cast<const c64*>(sibling)[r * 64 + lane];
+            V[r] = {h == 0 ? got.re : mineval.re, h == 0 ? got.im : mineval.im};
+        }
+        wg_barrier(); // 7: the h = 0 waves have read prod[0]; regions free again
+
+        // ---- polynomial h back to the torus
+        {
+            c64 Ep[4], Op[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Ep[i] = cadd(V[i], V[i + 4]);
+                Op[i] = cmul_tw<-1>(csub(V[i], V[i + 4]), wc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
+            wg_barrier(); // 8
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+                V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
+                V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
+            }
+            wg_barrier(); // 9: cross reads retired before the images are overwritten
+        }
+        fft512_single<-1, 7>(V, mine, tab, lane);
+        double tv[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) {
+            c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+            c64 t = cmul_nf_conj(xs, twist[n1]);
+            tv[n1] = t.re;
+            tv[8 + n1] = t.im;
+        }
+        double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+        for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+        if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] += f64_bigint_to_torus(tv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] += f64_round_to_torus(tv[e]);
+        }
+        // the next step's staging writes this wave's own image A, which nobody reads after barrier 9
+    }
+
+    uint64_t* out = a.out + (size_t)ct * a.out_stride;
+    if (!a.sample_extract) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) out[h * kN + coef2(e)] = acc[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int c = coef2(e);
+            if (h == 0) {
+                if (c == 0) out[0] = acc[e]; else out[kN - c] = (uint64_t)0 - acc[e];
+            } else if (c == 0) {
+                out[kN] = acc[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // cmux_kernel: batched `cmux` (ops/fft_ops.rs:149-181) with a per-ciphertext GGSW selector,
 //   out = d0 + IFFT( sum_{p,j} FFT(digit_j(d1 - d0)_p) . GGSW[p][L-1-j] ),
 // the operation `KeylessEvaluation::cmux` performs for every gate of a CMUX tree (GGSW in

@@ -36,8 +36,9 @@ def test_circuit_bootstrap_pbs_parity(small, B):
 
 @pytest.mark.parametrize("B", [255, 257, 510, 515, 1030])
 def test_every_workgroup_shape_is_bit_equal(small, B):
-    """The bootstrap kernel runs 1, 2 or 4 ciphertexts per workgroup depending on how the batch fills
-    the chip (B <= #CU, <= 2 #CU, more); ragged last workgroups included.  Same words from each."""
+    """The bootstrap runs a different kernel depending on how the batch fills the chip: four waves per
+    ciphertext (B <= #CU), two waves with paired transforms (<= 2 #CU), and the throughput shape of four
+    ciphertexts per workgroup beyond that; ragged last workgroups included.  Same words from each."""
     ks, eng = small
     lwe = random_lwe_batch(4000 + B, B, SMALL_N)
     got = eng.circuit_bootstrap_pbs(lwe)
