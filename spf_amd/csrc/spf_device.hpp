@@ -255,73 +255,6 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 
-// fft512_pair with the two transforms half a pass apart, for a wave that has its SIMD to itself:
-// each transform's exchange (8 stores at the lone-wave rate of ~26 cycles each, then the reads)
-// travels under the other's butterflies instead of being drained in the open.  No s_waitcnt
-// between an image's stores and its reads: the LDS executes one wave's DS instructions in order;
-// the compiler's counted lgkmcnt waits on the read results are all that is needed.  Same DAG, same
-// results as fft512_pair / fft512_single.
-template <int DIR>
-__device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], char* bufE, char* bufO,
-                                                      const c64* tab, int lane)
-{
-    const int hi3 = lane >> 3, lo3 = lane & 7;
-    const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
-    auto pass1 = [&](c64 (&V)[8]) {
-        c64 tw[7];
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) tw[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
-        radix8<DIR>(V);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) V[k1] = cmul_tw<DIR>(V[k1], tw[k1 - 1]);
-    };
-    auto pass2 = [&](c64 (&V)[8]) {
-        c64 tw[7];
-#pragma unroll
-        for (int c = 1; c < 8; c++) tw[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
-        radix8<DIR>(V);
-#pragma unroll
-        for (int c = 1; c < 8; c++) V[c] = cmul_tw<DIR>(V[c], tw[c - 1]);
-    };
-    auto write1 = [&](const c64 (&V)[8], char* buf) {
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = V[k1];
-    };
-    auto write2 = [&](const c64 (&V)[8], char* buf) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = V[c];
-    };
-    auto read = [&](c64 (&V)[8], const char* buf) {
-#pragma unroll
-        for (int x = 0; x < 8; x++) V[x] = *reinterpret_cast<const c64*>(buf + 1024 * x + rd);
-    };
-    pass1(E);
-    write1(E, bufE);
-    compiler_fence();
-    pass1(O);
-    read(E, bufE);
-    compiler_fence();
-    write1(O, bufO);
-    compiler_fence();
-    pass2(E);
-    compiler_fence();
-    write2(E, bufE);
-    compiler_fence();
-    read(O, bufO);
-    compiler_fence();
-    pass2(O);
-    read(E, bufE);
-    compiler_fence();
-    write2(O, bufO);
-    compiler_fence();
-    radix8<DIR>(E);
-    compiler_fence();
-    read(O, bufO);
-    compiler_fence();
-    radix8<DIR>(O);
-    compiler_fence();
-}
-
 // round half away from zero, then reduce mod 2^64 into the torus exactly as
 // PolynomialFftRef::ifft does (entities/polynomial_fft.rs:82-99 -> simd/scalar.rs:26-35,
 // 75-119 -> `x as i64` saturating, math/torus.rs:177-192).

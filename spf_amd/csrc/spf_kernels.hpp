@@ -876,11 +876,11 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
 // the pair h = 1 each rotate, decompose and transform ONE polynomial (both digits together,
 // `fft512_pair`) at the same time, and each transforms ONE output polynomial back.  The accumulation
 //   prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q          (in this order, each term 4 FMAs)
-// stays the sequential chain the reference's `glwe_ggsw_mad` defines: the h = 0 waves run the first
-// two terms from zero and pass the partial sums (both q) through LDS to the h = 1 waves, which run
-// the last two and pass prod[0] back.  Same operations in the same order on every value: same words.
-// All hand-overs are s_barrier among the four waves (nine per step); keys go straight from L2 into
-// registers as in blind_rotate2w_kernel.
+// stays the sequential chain the reference's `glwe_ggsw_mad` defines: the two pairs swap their
+// transforms through LDS and wave (w, h) then runs the whole chain of OUTPUT polynomial q = h (its
+// own transforms for the rows of polynomial h, the sibling's for the others).  Same operations in
+// the same order on every value: same words.  All hand-overs are s_barrier among the four waves
+// (eight per step); keys go straight from L2 into registers as in blind_rotate2w_kernel.
 constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192;
 
 template <int L, int LOGB>
@@ -937,17 +937,17 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
 
-        // this wave's bins of the two key rows of polynomial h (levels consumed in reverse), both
-        // output polynomials: [digit][q * 8 + r]
-        c64 key[2][16];
+        // this wave's bins of OUTPUT polynomial h in all four key rows (levels consumed in reverse):
+        // [row polynomial p][digit j][r]
+        c64 key[2][2][8];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const c64* row = a.bsk + ((size_t)step * (2 * L) + (h * L + (L - 1 - j))) * (2 * kHalf) + 256 * w + lane;
+        for (int p = 0; p < 2; p++)
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int j = 0; j < 2; j++) {
+                const c64* row = a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf) + h * kHalf + 256 * w + lane;
 #pragma unroll
-                for (int r = 0; r < 8; r++) key[j][q * 8 + r] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
-        }
+                for (int r = 0; r < 8; r++) key[p][j][r] = row[64 * (r & 3) + 512 * (r >> 2)];
+            }
 
         // ---- rotate, subtract, decompose polynomial h
         uint64_t* stage = reinterpret_cast<uint64_t*>(mine);
@@ -1024,54 +1024,40 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
                 for (int r = 0; r < 8; r++) VV[j][r] = X[r];
             }
         }
-        wg_barrier(); // 4: cross reads retired; the regions can carry the partial sums
+        wg_barrier(); // 4: cross reads retired; the regions can carry the transforms
 
-        // ---- multiply-accumulate, a chain through h = 0 then h = 1
-        c64 prod[2][8];
-        auto mad_two_digits = [&]() {
+        // ---- multiply-accumulate.  prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q, in this
+        // order (glwe_ggsw_mad): the two pairs swap their transforms through LDS, then wave (w, h)
+        // runs the whole chain of output polynomial q = h.
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(j * 8 + r) * 64 + lane] = VV[j][r];
+        wg_barrier(); // 5: every wave's two transforms are in its region
+        c64 SX[2][8]; // the sibling's transforms: polynomial 1 - h, same parity
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) SX[j][r] = reinterpret_cast<const c64*>(sibling)[(j * 8 + r) * 64 + lane];
+        compiler_fence();
+        c64 V[8]; // prod[h]
+#pragma unroll
+        for (int r = 0; r < 8; r++) V[r] = {0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int q = 0; q < 2; q++)
-#pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const c64 k = key[j][q * 8 + r];
-                        double re = __builtin_fma(k.re, VV[j][r].re, prod[q][r].re);
-                        double im = __builtin_fma(k.re, VV[j][r].im, prod[q][r].im);
-                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
-                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
-                    }
-        };
-        if (h == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
-            mad_two_digits();
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(q * 8 + r) * 64 + lane] = prod[q][r];
-        }
-        wg_barrier(); // 5: partial sums of rows (0, j) are in the h = 0 regions
-        if (h == 1) {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) prod[q][r] = reinterpret_cast<const c64*>(sibling)[(q * 8 + r) * 64 + lane];
-            mad_two_digits();
-#pragma unroll
-            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[r * 64 + lane] = prod[0][r]; // for the h = 0 wave
-        }
-        wg_barrier(); // 6: prod[0] is in the h = 1 regions
-        c64 V[8]; // prod[h]
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const c64 mineval = prod[1][r]; // meaningful for h = 1 only
-            const c64 got = reinterpret_cast<const c64*>(sibling)[r * 64 + lane];
-            V[r] = {h == 0 ? got.re : mineval.re, h == 0 ? got.im : mineval.im};
-        }
-        wg_barrier(); // 7: the h = 0 waves have read prod[0]; regions free again
+                for (int r = 0; r < 8; r++) {
+                    const c64 k = key[p][j][r];
+                    // row polynomial p: my own transform when p == h, the sibling's otherwise
+                    const c64 x = {p == h ? VV[j][r].re : SX[j][r].re, p == h ? VV[j][r].im : SX[j][r].im};
+                    double re = __builtin_fma(k.re, x.re, V[r].re);
+                    double im = __builtin_fma(k.re, x.im, V[r].im);
+                    V[r].re = __builtin_fma(-k.im, x.im, re);
+                    V[r].im = __builtin_fma(k.im, x.re, im);
+                }
+        wg_barrier(); // 6: sibling reads retired; regions free again
 
         // ---- polynomial h back to the torus
         {
@@ -1084,14 +1070,14 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
-            wg_barrier(); // 8
+            wg_barrier(); // 7
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
                 V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
                 V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
             }
-            wg_barrier(); // 9: cross reads retired before the images are overwritten
+            wg_barrier(); // 8: cross reads retired before the images are overwritten
         }
         fft512_single<-1, 7>(V, mine, tab, lane);
         double tv[16];
@@ -1112,7 +1098,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] += f64_round_to_torus(tv[e]);
         }
-        // the next step's staging writes this wave's own image A, which nobody reads after barrier 9
+        // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
     }
 
     uint64_t* out = a.out + (size_t)ct * a.out_stride;
