@@ -410,6 +410,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux4_kernel<4, 4>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kCmux4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kTraceLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scheme_switch_kernel<15, 3>),
@@ -684,6 +686,19 @@ spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_
     return glwe_linear_dev(c, stream, B, GLWE_MUL_XN, d_in, nullptr, (uint32_t)(n % (2 * (size_t)kN)), d_out);
 }
 
+// At most one gate per CU: the four-waves-per-gate latency shape (a level of a gate graph); beyond
+// that four gates per workgroup, the streaming shape.  SPF_CMUX4=0 keeps the streaming shape.
+static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
+{
+    static const bool quad_on = [] { const char* e = getenv("SPF_CMUX4"); return !(e && e[0] == '0'); }();
+    if (quad_on && a.B <= (uint32_t)c->n_cu) {
+        hipLaunchKernelGGL((cmux4_kernel<4, 4>), dim3(a.B), dim3(256), kCmux4Lds, s, a);
+    } else {
+        dim3 grid((unsigned)((a.B + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
+        hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, s, a);
+    }
+}
+
 static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t per_ggsw, const double* d_sel,
                               const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out)
 {
@@ -696,8 +711,7 @@ static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t 
     // zero ciphertext (multiply_glwe_ggsw)
     a.ggsw = reinterpret_cast<const c64*>(d_sel); a.d0 = d_a ? d_a : d_b; a.d1 = d_b; a.out = d_out;
     a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = per_ggsw; a.d0_zero = d_a ? 0u : 1u;
-    dim3 grid((unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
-    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, s, a);
+    launch_cmux_args(c, s, a);
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }
@@ -724,8 +738,7 @@ spf_status spf_cmux_scattered_dev(spf_ctx* c, void* stream, size_t units, const 
     HIPCHK(c, hipSetDevice(c->device));
     CmuxArgs a{};
     a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = 1; a.ptrs = d_ptrs;
-    dim3 grid((unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
-    hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, (hipStream_t)stream, a);
+    launch_cmux_args(c, (hipStream_t)stream, a);
     HIPCHK(c, hipGetLastError());
     return SPF_OK;
 }

@@ -1337,6 +1337,222 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// cmux4_kernel: the LATENCY shape of cmux_kernel — four waves per gate, one gate per workgroup, for
+// the levels of a gate graph that hold at most one gate per CU (a ripple-carry chain is 1-4 gates per
+// level, and its depth, not its width, is what a run waits for).  Same split as blind_rotate4_kernel:
+// wave (w, h) = sample parity w x polynomial h.  Each pair of waves decomposes ONE polynomial of
+// d1 - d0 and pushes its four digits through two `fft512_pair`s; the pairs then publish their four
+// transforms in LDS and wave (w, h) runs the whole accumulation chain of OUTPUT polynomial h over the
+// eight rows in the reference's order (row polynomial 0 levels 3..0, then polynomial 1: fft_ops.rs:67-98
+// reversed GLEV rows) — its own transforms for the rows of polynomial h, the sibling's for the others —
+// and transforms that polynomial back.  The selector's rows of output polynomial h go straight from
+// HBM/L2 into registers: the first four are requested before anything else, the last four behind the
+// forward transforms.  Same operations in the same order on every value as cmux_kernel: same words.
+constexpr int kCmux4Lds = kTableBytes + 4 * 4 * 8192;
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
+{
+    static_assert(L == 4 && L * LOGB <= 32, "four digits, processed as two pairs");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 1, h = wv >> 1;
+    // region of wave (w, h): 32 KiB = two exchange images while transforming, then its four transforms
+    auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 32768; };
+    char* mine = region(w, h);
+    char* mineB = mine + 8192;
+    const char* partner = region(w ^ 1, h);
+    const char* sibling = region(w, h ^ 1);
+    auto wg_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // keeps the selector loads in flight (no vmcnt drain)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const uint32_t ct = blockIdx.x; // grid = units
+    const c64* ggsw;
+    const uint64_t *d0, *d1;
+    uint64_t* out_ct;
+    bool d0_zero = a.d0_zero != 0;
+    if (a.ptrs) {
+        const void* const* t = a.ptrs + 4 * (size_t)ct;
+        ggsw = static_cast<const c64*>(t[0]);
+        d1 = static_cast<const uint64_t*>(t[2]);
+        d0_zero = t[1] == nullptr;
+        d0 = d0_zero ? d1 : static_cast<const uint64_t*>(t[1]);
+        out_ct = static_cast<uint64_t*>(const_cast<void*>(t[3]));
+    } else {
+        ggsw = a.ggsw + (size_t)(ct / a.per_ggsw) * (2 * L * 2 * kHalf);
+        d0 = a.d0 + (size_t)ct * 2 * kN;
+        d1 = a.d1 + (size_t)ct * 2 * kN;
+        out_ct = a.out + (size_t)ct * 2 * kN;
+    }
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+    // selector row (p, level L-1-j), output polynomial h, this wave's bins
+    auto load_row = [&](c64 (&k)[8], int p, int j) {
+        const c64* row = ggsw + (size_t)((p * L + (L - 1 - j)) * 2 + h) * kHalf + 256 * w + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) k[r] = row[64 * (r & 3) + 512 * (r >> 2)];
+    };
+    c64 key0[L][8], key1[L][8];
+#pragma unroll
+    for (int j = 0; j < L; j++) load_row(key0[j], 0, j);
+
+    uint32_t dig[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int c = h * kN + coef2(e);
+        uint64_t diff = d1[c] - (d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+        constexpr int shift = 64 - L * LOGB;
+        uint32_t sd = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            uint32_t d = sd & ((1u << LOGB) - 1);
+            sd >>= LOGB;
+            sd += d >> (LOGB - 1);
+            packed |= d << (j * LOGB);
+        }
+        dig[e] = packed;
+    }
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
+    }
+    wg_barrier(); // twiddle image in place
+    c64 twist[8], wc[4];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
+
+    // ---- the four digit transforms of polynomial h, two at a time
+    c64 X[L][8];
+#pragma unroll
+    for (int jj = 0; jj < L; jj += 2) {
+#pragma unroll
+        for (int j = jj; j < jj + 2; j++)
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                const int sh = j * LOGB;
+                int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
+                X[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
+            }
+        if (jj) wg_barrier(); // partner is done with my last cross data
+        fft512_pair<+1>(X[jj], X[jj + 1], mine, mineB, tab, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? X[jj + j][4 + i].re : X[jj + j][i].re,
+                                                                         w == 0 ? X[jj + j][4 + i].im : X[jj + j][i].im};
+        wg_barrier();
+        c64 xin[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(partner)[(j * 4 + i) * 64 + lane];
+        compiler_fence();
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            c64 Y[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c64 in = xin[j][i];
+                const c64 Ei = {w == 0 ? X[jj + j][i].re : in.re, w == 0 ? X[jj + j][i].im : in.im};
+                const c64 Oi = {w == 0 ? in.re : X[jj + j][4 + i].re, w == 0 ? in.im : X[jj + j][4 + i].im};
+                c64 t = cmul_tw<+1>(Oi, wc[i]);
+                Y[i] = cadd(Ei, t);
+                Y[i + 4] = csub(Ei, t);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) X[jj + j][r] = Y[r];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < L; j++) load_row(key1[j], 1, j); // the last four rows, behind the transforms
+    wg_barrier(); // cross reads retired: the regions can carry the transforms
+#pragma unroll
+    for (int j = 0; j < L; j++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(j * 8 + r) * 64 + lane] = X[j][r];
+    wg_barrier(); // every wave's four transforms are in its region
+
+    // ---- accumulation chain of output polynomial h: rows (0, j = 0..3) then (1, j = 0..3)
+    c64 V[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) V[r] = {0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            // row polynomial p: my own transforms when p == h, the sibling's otherwise — both read back
+            // from LDS, so that the 128 registers of X are free for the selector rows
+            const char* src = smem + kTableBytes + ((p * 2 + w) * 32768);
+            c64 sx[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) sx[r] = reinterpret_cast<const c64*>(src)[(j * 8 + r) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const c64 k = {p == 0 ? key0[j][r].re : key1[j][r].re, p == 0 ? key0[j][r].im : key1[j][r].im};
+                const c64 x = sx[r];
+                double re = __builtin_fma(k.re, x.re, V[r].re);
+                double im = __builtin_fma(k.re, x.im, V[r].im);
+                V[r].re = __builtin_fma(-k.im, x.im, re);
+                V[r].im = __builtin_fma(k.im, x.re, im);
+            }
+        }
+    wg_barrier(); // sibling reads retired; regions free again
+
+    // ---- polynomial h back to the torus, plus d0
+    {
+        c64 Ep[4], Op[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Ep[i] = cadd(V[i], V[i + 4]);
+            Op[i] = cmul_tw<-1>(csub(V[i], V[i + 4]), wc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
+        wg_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+            V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
+            V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
+        }
+        wg_barrier(); // cross reads retired before the image is overwritten
+    }
+    fft512_single<-1, 7>(V, mine, tab, lane);
+    double tv[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) {
+        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        c64 t = cmul_nf_conj(xs, twist[n1]);
+        tv[n1] = t.re;
+        tv[8 + n1] = t.im;
+    }
+    double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+    for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+    // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180)
+    uint64_t* out = out_ct + h * kN;
+    const uint64_t* base = d0 + h * kN;
+    if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // LWE keyswitch L1 -> L0 (ops/keyswitch/lwe_keyswitch.rs:23-62; lev_ciphertext_ops.rs:18-42;
 // lwe_ciphertext_ops.rs:48-66), batched: out[ct] = (0,..,0,b) - sum_i sum_j d_{i,j} KSK[i][l-1-j].
 // A workgroup owns a tile of KS_CT ciphertexts x 256 output columns; each thread owns one

@@ -225,3 +225,26 @@ def test_cmux_random_words_parity(small):
     got = eng.cmux(g, a, b)
     for i in range(B):
         assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+
+
+@pytest.mark.parametrize("B", [255, 258, 301])
+def test_cmux_both_shapes_are_bit_equal(small, B):
+    """At most one gate per CU runs cmux4_kernel (four waves per gate), larger batches the streaming
+    cmux_kernel (four gates per workgroup, ragged tail included).  Same words from both, and from the
+    oracle on a sample."""
+    ks, eng = small
+    P = ks.params
+    nrng = np.random.default_rng(1000 + B)
+    a = random_glwe(3, B, P.glwe_len)
+    b = random_glwe(4, B, P.glwe_len)
+    n = 2 * 4 * 2 * 1024
+    g = ((nrng.standard_normal((B, n)) + 1j * nrng.standard_normal((B, n))) * 2.0 ** 60).astype(np.complex128)
+    got = eng.cmux(g, a, b)
+    for i in (0, 1, B // 2, B - 1):
+        assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+    ref = np.concatenate([eng.cmux(g[i:i + 100], a[i:i + 100], b[i:i + 100]) for i in range(0, B, 100)])
+    assert np.array_equal(got, ref)
+    # multiply_glwe_ggsw = cmux with the zero ciphertext as d0, through both shapes as well
+    m = eng.multiply_glwe_ggsw(b, g)
+    mref = np.concatenate([eng.multiply_glwe_ggsw(b[i:i + 100], g[i:i + 100]) for i in range(0, B, 100)])
+    assert np.array_equal(m, mref)
