@@ -248,3 +248,31 @@ def test_cmux_both_shapes_are_bit_equal(small, B):
     m = eng.multiply_glwe_ggsw(b, g)
     mref = np.concatenate([eng.multiply_glwe_ggsw(b[i:i + 100], g[i:i + 100]) for i in range(0, B, 100)])
     assert np.array_equal(m, mref)
+
+
+def test_every_bootstrap_shape_with_luts_and_sample_extract(small):
+    """The per-ciphertext LUT, the (log_chi, log_v, body rotation) arguments and the fused sample
+    extract go through all three bootstrap kernels: 90 ciphertexts at a time (four waves each), 300
+    (two waves, paired transforms) and 600 (throughput shape) must agree word for word."""
+    ks, eng = small
+    P = ks.params
+    B = 600
+    lwe = random_lwe_batch(77, B, SMALL_N)
+    luts = random_glwe(78, B, P.glwe_len)
+    lut1 = O.trivial_lut_glwe(O.generate_lut(P.N, [lambda x: (x + 1) % 2], 1), P)
+
+    def chunks(fn, size):
+        return np.concatenate([fn(i, min(i + size, B)) for i in range(0, B, size)])
+
+    for size in (90, 300, 600):
+        g = chunks(lambda i, j: eng.generalized_pbs(lwe[i:j], luts[i:j], 1, 1, 12345), size)
+        u = chunks(lambda i, j: eng.pbs_univariate(lwe[i:j], lut1), size)
+        if size == 90:
+            g_ref, u_ref = g, u
+            rot = lwe[7].copy()
+            rot[-1] = (int(rot[-1]) + 12345) & M64
+            assert np.array_equal(g[7], O.generalized_pbs(rot, luts[7], ks.bsk_fft, P, 1, 1))
+            assert np.array_equal(u[7], O.pbs_univariate(lwe[7], lut1, ks.bsk_fft, P))
+        else:
+            assert np.array_equal(g, g_ref), size
+            assert np.array_equal(u, u_ref), size
