@@ -292,4 +292,63 @@ __device__ __forceinline__ uint64_t f64_bigint_to_torus(double v)
     return ((uint64_t)uhi << 32) | ulo;
 }
 
+// ---- pieces shared by the latency-shape kernels (blind_rotate2w / blind_rotate4 / cmux4) ----------
+
+// RadixDecomposition of one torus word (math/radix.rs:81-113,157-162; simd/scalar.rs:52-71): round to
+// the top L*LOGB bits (add the bit below), then L digits, least significant first, each reduced to
+// [-B/2, B/2) with the carry going into the next; returned packed, LOGB bits per digit, two's
+// complement inside each field.
+template <int L, int LOGB>
+__device__ __forceinline__ uint32_t gadget_digits_packed(uint64_t x)
+{
+    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+    constexpr int shift = 64 - L * LOGB;
+    uint32_t s = (uint32_t)(x >> shift) + (uint32_t)((x >> (shift - 1)) & 1);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        uint32_t d = s & ((1u << LOGB) - 1);
+        s >>= LOGB;
+        s += d >> (LOGB - 1);
+        packed |= d << (j * LOGB);
+    }
+    return packed;
+}
+
+// complex sample of digit j: re from the packed word of coefficient c, im from that of c + N/2,
+// sign-extended, converted to f64 and twisted (entities/polynomial.rs:257-274, scalar.rs:19-23)
+template <int LOGB>
+__device__ __forceinline__ c64 twisted_digit(uint32_t packed_re, uint32_t packed_im, int j, c64 tw)
+{
+    const int sh = j * LOGB;
+    int dre = ((int)(packed_re << (32 - LOGB - sh))) >> (32 - LOGB);
+    int dim = ((int)(packed_im << (32 - LOGB - sh))) >> (32 - LOGB);
+    return cmul_nf({(double)dre, (double)dim}, tw);
+}
+
+// inverse side of a transform: (z * 1/1024) * conj(twist), then round / mod 2^64 / saturating cast
+// of the 16 values (polynomial_fft.rs:82-99): the short exact path when every value of the wave is
+// already an integer of magnitude >= 2^52, else the literal sequence; identical words either way.
+__device__ __forceinline__ void untwist_to_torus(const c64 (&V)[8], const c64 (&twist)[8], uint64_t (&t)[16])
+{
+    double tv[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) {
+        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        c64 u = cmul_nf_conj(xs, twist[n1]);
+        tv[n1] = u.re;
+        tv[8 + n1] = u.im;
+    }
+    double mn = __builtin_fabs(tv[0]);
+#pragma unroll
+    for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
+    if (__all(mn >= 4503599627370496.0)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) t[e] = f64_bigint_to_torus(tv[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) t[e] = f64_round_to_torus(tv[e]);
+    }
+}
+
 } // namespace spf

@@ -733,29 +733,13 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
                 uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
                 uint64_t v = gin[e];
                 uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                uint64_t diff = rot - acc[p][e];
-                constexpr int shift = 64 - L * LOGB;
-                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < L; j++) {
-                    uint32_t d = s & ((1u << LOGB) - 1);
-                    s >>= LOGB;
-                    s += d >> (LOGB - 1);
-                    packed |= d << (j * LOGB);
-                }
-                dig[e] = packed;
+                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
             }
             c64 VV[2][8];
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int n1 = 0; n1 < 8; n1++) {
-                    const int sh = j * LOGB;
-                    int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                    int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                    VV[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
-                }
+                for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
             pair_barrier_w(); // partner is done gathering from my image A
             fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes
@@ -826,24 +810,10 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
         fft512_pair<-1>(WW[0], WW[1], mine, mineB, tab, lane);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            double tv[16];
+            uint64_t t[16];
+            untwist_to_torus(WW[q], twist, t);
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                c64 xs = {WW[q][n1].re * (1.0 / 1024.0), WW[q][n1].im * (1.0 / 1024.0)};
-                c64 t = cmul_nf_conj(xs, twist[n1]);
-                tv[n1] = t.re;
-                tv[8 + n1] = t.im;
-            }
-            double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-            for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-            if (__all(mn >= 4503599627370496.0)) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[q][e] += f64_round_to_torus(tv[e]);
-            }
+            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
         }
     }
 
@@ -967,30 +937,14 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
             for (int e = 0; e < 16; e++) {
                 uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
                 uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - gin[e] : gin[e];
-                uint64_t diff = rot - acc[e];
-                constexpr int shift = 64 - L * LOGB;
-                uint32_t sd = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < L; j++) {
-                    uint32_t d = sd & ((1u << LOGB) - 1);
-                    sd >>= LOGB;
-                    sd += d >> (LOGB - 1);
-                    packed |= d << (j * LOGB);
-                }
-                dig[e] = packed;
+                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[e]);
             }
         }
         c64 VV[2][8];
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                const int sh = j * LOGB;
-                int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                VV[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
-            }
+            for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
         wg_barrier(); // 2: everyone is done gathering; the images are free
         fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
         // radix-2 stage across the parities, both digits in one exchange
@@ -1080,23 +1034,11 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
             wg_barrier(); // 8: cross reads retired before the images are overwritten
         }
         fft512_single<-1, 7>(V, mine, tab, lane);
-        double tv[16];
+        {
+            uint64_t t[16];
+            untwist_to_torus(V, twist, t);
 #pragma unroll
-        for (int n1 = 0; n1 < 8; n1++) {
-            c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-            c64 t = cmul_nf_conj(xs, twist[n1]);
-            tv[n1] = t.re;
-            tv[8 + n1] = t.im;
-        }
-        double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-        for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-        if (__all(mn >= 4503599627370496.0)) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] += f64_bigint_to_torus(tv[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] += f64_round_to_torus(tv[e]);
+            for (int e = 0; e < 16; e++) acc[e] += t[e];
         }
         // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
     }
@@ -1404,18 +1346,8 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const int c = h * kN + coef2(e);
-        uint64_t diff = d1[c] - (d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
-        constexpr int shift = 64 - L * LOGB;
-        uint32_t sd = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < L; j++) {
-            uint32_t d = sd & ((1u << LOGB) - 1);
-            sd >>= LOGB;
-            sd += d >> (LOGB - 1);
-            packed |= d << (j * LOGB);
-        }
-        dig[e] = packed;
+        // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168), then the gadget digits
+        dig[e] = gadget_digits_packed<L, LOGB>(d1[c] - (d0_zero ? 0 : d0[c]));
     }
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
@@ -1436,12 +1368,7 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
 #pragma unroll
         for (int j = jj; j < jj + 2; j++)
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                const int sh = j * LOGB;
-                int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                X[j][n1] = cmul_nf({(double)dre, (double)dim}, twist[n1]);
-            }
+            for (int n1 = 0; n1 < 8; n1++) X[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
         if (jj) wg_barrier(); // partner is done with my last cross data
         fft512_pair<+1>(X[jj], X[jj + 1], mine, mineB, tab, lane);
 #pragma unroll
@@ -1529,27 +1456,13 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
         wg_barrier(); // cross reads retired before the image is overwritten
     }
     fft512_single<-1, 7>(V, mine, tab, lane);
-    double tv[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) {
-        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-        c64 t = cmul_nf_conj(xs, twist[n1]);
-        tv[n1] = t.re;
-        tv[8 + n1] = t.im;
-    }
-    double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-    for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
     // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180)
+    uint64_t t[16];
+    untwist_to_torus(V, twist, t);
     uint64_t* out = out_ct + h * kN;
     const uint64_t* base = d0 + h * kN;
-    if (__all(mn >= 4503599627370496.0)) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
-    }
+    for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + t[e];
 }
 
 // ------------------------------------------------------------------------------------------
