@@ -445,30 +445,14 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
                 uint32_t srcc = idx & (kN - 1);
                 uint64_t v = reinterpret_cast<const uint64_t*>(tile + (srcc & 1) * 8192)[srcc >> 1];
                 uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                uint64_t diff = rot - acc[p][e];
-                constexpr int shift = 64 - L * LOGB;
-                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < L; j++) {
-                    uint32_t d = s & ((1u << LOGB) - 1);
-                    s >>= LOGB;
-                    s += d >> (LOGB - 1);
-                    packed |= d << (j * LOGB);
-                }
-                dig[e] = packed;
+                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
             }
 
 #pragma unroll 1
             for (int j = 0; j < L; j++, g++) {
-                const int sh = j * LOGB;
                 c64 V[8];
 #pragma unroll
-                for (int n1 = 0; n1 < 8; n1++) {
-                    int dre = ((int)(dig[n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                    int dim = ((int)(dig[8 + n1] << (32 - LOGB - sh))) >> (32 - LOGB);
-                    V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
-                }
+                for (int n1 = 0; n1 < 8; n1++) V[n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[64 * n1]);
                 pair_barrier(flags, me, partner, seq); // partner is done gathering / done with my last cross data
                 fft512_single<+1, kFftPre>(V, mine, tab, lane);
                 // radix-2 stage across the two waves: wave 0 finishes bins with d < 4, wave 1 d >= 4
