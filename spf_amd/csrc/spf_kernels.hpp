@@ -1291,7 +1291,6 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
     char* mine = region(w, h);
     char* mineB = mine + 8192;
     const char* partner = region(w ^ 1, h);
-    const char* sibling = region(w, h ^ 1);
     auto wg_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // keeps the selector loads in flight (no vmcnt drain)
         __builtin_amdgcn_s_barrier();
