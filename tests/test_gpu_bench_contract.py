@@ -1,0 +1,36 @@
+"""bench.py prints ONE JSON line with the fields the driver's contract names, and its parity sample
+(the CPU-baseline leg) agrees with the GPU word for word."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "512",
+                        "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
+        assert isinstance(d[key], typ), (key, d[key])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "PBS/s" and d["dtype"] == "f64" and "workload" in d["config"]
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] < 1.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert cpu["gpu_outputs_bit_equal_on_sample"] is True
