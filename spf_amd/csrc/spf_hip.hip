@@ -690,8 +690,8 @@ spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_
 // that four gates per workgroup, the streaming shape.  SPF_CMUX4=0 keeps the streaming shape.
 static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 {
-    static const bool quad_on = [] { const char* e = getenv("SPF_CMUX4"); return !(e && e[0] == '0'); }();
-    if (quad_on && a.B <= (uint32_t)c->n_cu) {
+    static const int quad_mode = [] { const char* e = getenv("SPF_CMUX4"); return e ? e[0] - '0' : 1; }();
+    if (quad_mode == 2 || (quad_mode == 1 && a.B <= (uint32_t)c->n_cu)) {
         hipLaunchKernelGGL((cmux4_kernel<4, 4>), dim3(a.B), dim3(256), kCmux4Lds, s, a);
     } else {
         dim3 grid((unsigned)((a.B + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
