@@ -44,7 +44,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="ciphertexts per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="ciphertexts per GPU per step (default: 4096 on one GPU = BASELINE configs[1]; 8192 per GPU "
+                         "on several = configs[3], 65536 bootstraps over 8 GPUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
@@ -66,9 +68,9 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run "
+              f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
         return 2
@@ -82,6 +84,8 @@ def main() -> int:
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.batch <= 0:
+        args.batch = 4096 if world == 1 else 8192
     P = spf_amd.DEFAULT_128
     # only one rank (re)builds the library if it is stale; the others wait for it
     if rank == 0:

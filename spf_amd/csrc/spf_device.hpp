@@ -129,6 +129,13 @@ __device__ __forceinline__ void wave_lds_fence()
 // stay ahead of the LDS writes that follow it.  The hardware needs nothing here: a wave's DS
 // instructions execute in order and all 64 lanes retire an instruction together.
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+// compiler-only as well, and stronger: no instruction of any kind is scheduled across it.  Pins the
+// source-level interleave of two transforms (and keeps their temporaries from overlapping).
+__device__ __forceinline__ void sched_fence()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // One 512-point DFT (same DAG and exchange images as fft512_pair below) held by one wave; used
 // by the two-waves-per-ciphertext kernel, where the partner wave on the SIMD hides the LDS
@@ -255,6 +262,75 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 
+// fft512_pair with ONE 8 KiB exchange image for both transforms — the form that fits two waves per
+// SIMD (blind_rotate2p_kernel: 256 registers, 8 KiB of LDS per wave).  A wave's DS instructions execute
+// in issue order, so the two transforms can take turns on the same image as long as the program
+// order is  A.write, A.read, B.write, B.read, A.write, ...: each read is issued one butterfly pass
+// ahead of its use and travels under the OTHER transform's arithmetic, each write drains under it.
+// Same DAG as fft512_single.  Exchange images (16-byte slots), chosen so that BOTH exchanges write to
+// the same eight lane addresses (8 address registers for the whole transform pair):
+//   exchange 1: writer lane (a,b) reg k1 -> 64 a + 8 k1 + (b ^ k1);  reader lane (b,k1) reg a <- 64 a + 8 k1 + (b ^ k1)
+//   exchange 2: writer lane (b,k1) reg c -> 64 b + 8 c  + (k1 ^ c);  reader lane (c,k1) reg b <- 64 b + 8 c  + (k1 ^ c)
+// i.e. writer (hi3, lo3) reg r -> ((64 hi3 + lo3) ^ r) + 8 r in both; both are conflict-free for
+// ds_write_b128 (8 distinct slots mod 8 per 8-lane group) and ds_read_b128 (16 distinct slots mod 16
+// per 16-lane group of the b128 read pattern).
+template <int DIR>
+__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    // pass 1
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
+    sched_fence();
+    // pass 2
+    radix8<DIR>(A);
+#pragma unroll
+    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+#pragma unroll
+    for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+    sched_fence();
+#pragma unroll
+    for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = B[c];
+    sched_fence();
+    // pass 3
+    radix8<DIR>(A);
+    sched_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) B[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+    radix8<DIR>(B);
+    sched_fence(); // the image's next writer stays behind these reads
+}
+
 // round half away from zero, then reduce mod 2^64 into the torus exactly as
 // PolynomialFftRef::ifft does (entities/polynomial_fft.rs:82-99 -> simd/scalar.rs:26-35,
 // 75-119 -> `x as i64` saturating, math/torus.rs:177-192).
@@ -290,6 +366,49 @@ __device__ __forceinline__ uint64_t f64_bigint_to_torus(double v)
     uhi = quirk ? 0x7FFFFFFFu : uhi;
     ulo = quirk ? 0xFFFFFFFFu : ulo;
     return ((uint64_t)uhi << 32) | ulo;
+}
+
+// Integer form of f64_bigint_to_torus: for an integer-valued v with 2^52 <= |v| < 2^116 the low 64
+// bits of v in two's complement are (mantissa << (exponent - 1075)), negated for v < 0 — nine 32-bit
+// VALU instructions instead of seven f64 ones and two conversions.  `sh_or` collects the shift
+// amounts (the caller checks once per wave that every one is in [0, 64): that IS the magnitude
+// test), `quirk_min` becomes 0 if some value hits the saturating-cast quirk (v < 0 and low 64 bits
+// == 2^63, which `as i64` turns into 0x7FFF...F): the caller then redoes the wave's values with the
+// literal sequence.  Same words as f64_round_to_torus whenever the two checks pass.
+__device__ __forceinline__ uint64_t f64_bigint_to_torus_bits(double v, uint32_t& sh_or, uint32_t& quirk_min)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t hi = (uint32_t)(b >> 32), lo = (uint32_t)b;
+    const uint32_t sh = ((hi >> 20) & 0x7FFu) - 1075u;
+    sh_or |= sh;
+    const uint64_t m = ((uint64_t)((hi & 0xFFFFFu) | 0x100000u) << 32) | lo;
+    uint64_t r = m << (sh & 63u);
+    const uint32_t s32 = (uint32_t)((int32_t)hi >> 31);
+    const uint64_t s = ((uint64_t)s32 << 32) | s32;
+    r = (r ^ s) - s;
+    const uint32_t q = (uint32_t)r | ((uint32_t)(r >> 32) ^ 0x80000000u) | ~s32;
+    quirk_min = q < quirk_min ? q : quirk_min;
+    return r;
+}
+
+// untwist_to_torus with the integer conversion on the fast path
+__device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64* twist_lds, uint64_t (&t)[16])
+{
+    double tv[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) {
+        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        c64 u = cmul_nf_conj(xs, twist_lds[64 * n1]);
+        tv[n1] = u.re;
+        tv[8 + n1] = u.im;
+    }
+    uint32_t sh_or = 0, qmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < 16; e++) t[e] = f64_bigint_to_torus_bits(tv[e], sh_or, qmin);
+    if (!__all(sh_or < 64u && qmin != 0u)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) t[e] = f64_round_to_torus(tv[e]);
+    }
 }
 
 // ---- pieces shared by the latency-shape kernels (blind_rotate2w / blind_rotate4 / cmux4) ----------

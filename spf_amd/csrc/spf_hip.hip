@@ -221,7 +221,10 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
+    // SPF_PAIRED=0 keeps the one-digit-at-a-time throughput kernel (blind_rotate2_kernel) for A/B runs
+    static const bool paired = [] { const char* e = getenv("SPF_PAIRED"); return !(e && e[0] == '0'); }();
     if (quad) hipLaunchKernelGGL((blind_rotate4_kernel<2, 16>), grid, block, kBlindRotate4Lds, s, a);
+    else if (variant == 2 && cts == 4 && paired) hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16>), grid, block, kBlindRotate2pLds, s, a);
     else if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
     else if (variant == 2 && wide && cts == 1) hipLaunchKernelGGL((blind_rotate2w_kernel<2, 16, 1>), grid, block, blind_rotate2w_lds<1>(), s, a);
     else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
@@ -400,6 +403,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),

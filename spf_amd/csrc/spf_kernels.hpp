@@ -83,6 +83,22 @@ __device__ __forceinline__ void bsk_slot_dma(const c64* src, char* slot, int tid
     }
 }
 
+// One LDS-DMA piece in the scalar-base form: 64 lanes x 16 bytes from `sbase + voff` (sbase wave-uniform
+// in an SGPR pair, voff this lane's 32-bit byte offset) to LDS bytes [lds, lds + 1024) (lds wave-uniform,
+// lane l lands at lds + 16 l).  Written out because the builtin, given `base + k * stride + lane offset`,
+// keeps one 64-bit per-lane address per piece live (16 VGPRs for an 8-piece refill).  M0 is written
+// here and not declared (hipcc rejects it as a clobber): a kernel that uses this must not use the
+// LDS-DMA builtin or any other M0 consumer (s_movrel, sendmsg, GDS) beside it.
+__device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p)
+{
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 template <int L, int LOGB> // gadget: L digits of LOGB bits, L*LOGB <= 32
 __global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
 {
@@ -796,6 +812,276 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
         for (int q = 0; q < 2; q++) {
             uint64_t t[16];
             untwist_to_torus(WW[q], twist, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
+        }
+    }
+
+    if (!owns_output) return;
+    uint64_t* out = a.out + (size_t)ct * a.out_stride;
+    if (!a.sample_extract) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int c = coef2(e);
+            if (c == 0) {
+                out[0] = acc[0][e];
+                out[kN] = acc[1][e];
+            } else {
+                out[kN - c] = (uint64_t)0 - acc[0][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// blind_rotate2p_kernel: the THROUGHPUT shape with the paired schedule.  Same split as
+// blind_rotate2_kernel (two waves per ciphertext by sample parity, four ciphertexts per 512-thread
+// workgroup, two waves per SIMD, key ring in LDS) and the same arithmetic on every value; what
+// changes is the schedule of a CMUX step:
+//   * both digits of a polynomial are decomposed, twisted and transformed TOGETHER (`fft512_pair1`:
+//     one 8 KiB image, the two transforms taking turns on it), so inside a wave one transform's
+//     exchange travels under the other's butterflies, the pass twiddles / twist factors are read
+//     once for two transforms, and one cross exchange (8 KiB) serves both digits;
+//   * the ring holds the two key rows of the CURRENT polynomial (64 KiB contiguous in the reference
+//     layout: rows (p, level 0), (p, level 1)); it is refilled by LDS-DMA once per polynomial, issued
+//     right before the transform pair of the next polynomial and waited for at that polynomial's
+//     cross-exchange barrier;
+//   * both output polynomials go back through one transform pair as well.
+// Per step: 4 workgroup barriers (2 of them right behind each other's MADs) and 6 pair rendezvous,
+// against 4 and 12 in blind_rotate2_kernel.
+constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes + 64;
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
+{
+    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
+    constexpr int NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values live in SGPRs
+    const int cslot = wv >> 1;
+    const int w = wv & 1;
+    char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
+    char* mine = tile + w * 8192;
+    char* theirs = tile + (w ^ 1) * 8192;
+    char* bskring = smem + kTableBytes + 4 * kWaveBufBytes;
+    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(bskring + 2 * kBskSlotBytes);
+    uint32_t seq = 0;
+    const int me = wv, partner = me ^ 1;
+
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
+        if (tid < 8) flags[tid] = 0;
+    }
+
+    const uint32_t ct_raw = blockIdx.x * 4 + cslot;
+    const bool owns_output = ct_raw < a.B;
+    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
+    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
+    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
+
+    // chunk c = 2 step + p: the 64 KiB [level 0 row | level 1 row] of polynomial p of step `step`,
+    // copied as it lies: digit j (level L-1-j) is the ring half 1-j
+    const uint32_t total_chunks = 2 * a.n;
+    const uint32_t dma_voff = (uint32_t)tid * 16u;                   // this lane's bytes inside an 8 KiB piece row
+    const uint32_t dma_dst = lds_address(bskring) + wv * 1024;        // this wave's 1 KiB of each piece row
+    auto ring_dma = [&](uint32_t chunk) {
+        const char* src = reinterpret_cast<const char*>(a.bsk) +
+                          (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes); // uniform
+#pragma unroll
+        for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
+            lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
+    };
+    ring_dma(0);
+
+    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+
+    uint64_t acc[2][16];
+    {
+        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                uint32_t idx = (uint32_t)coef2(e) + bt;
+                uint64_t v = lut[p * kN + (idx & (kN - 1))];
+                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+            }
+    }
+    __syncthreads();
+
+    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
+    const c64* twist = tab + kTWOff + w * 512 + lane;   // e^{+i pi (2n'+w)/2048}, n' = 64 n1 + lane
+    const c64* wc = tab + kWCOff + 256 * w + lane;       // W1024^{lane + 64 (4w + i)}
+    uint64_t a_next = lwe[0];
+    uint32_t chunk = 0;
+    for (uint32_t step = 0; step < a.n; step++) {
+        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
+        a_next = lwe[step + 1];
+
+        // bins lane + 64 (4w + i) + 512 s at index i + 4 s; starts at zero, which the first row's FMAs
+        // take as a literal (no zeroed registers live across polynomial 0's transforms)
+        c64 prod[2][8];
+
+#pragma unroll
+        for (int p = 0; p < 2; p++, chunk++) {
+            // my region is free: for p = 0 the partner's last reads of it (inverse cross data) were
+            // followed by a rendezvous, for p = 1 by the workgroup barrier behind the MADs
+#pragma unroll
+            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
+            pair_barrier(flags, me, partner, seq); // both parities staged
+            uint32_t dig[16];
+            {
+                // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024
+                // for e >= 8): region (parity) and the low address bits do not depend on e
+                const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
+                const char* region = tile + (t0 & 1) * 8192;
+                uint64_t gin[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
+                    gin[e] = *reinterpret_cast<const uint64_t*>(region + ((t << 2) & 0x1FF8u));
+                }
+                compiler_fence();
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
+                    const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
+                    const uint64_t rot = (gin[e] ^ sgn) - sgn;
+                    dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
+                }
+            }
+            c64 VV[2][8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                const c64 tw = twist[64 * n1];
+                VV[0][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 0, tw);
+                VV[1][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 1, tw);
+            }
+            pair_barrier(flags, me, partner, seq); // partner is done gathering from my region
+            // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
+            // of polynomial 0 were requested ahead of the previous step's inverse transforms)
+            if (p == 1) ring_dma(chunk);
+            fft512_pair1<+1>(VV[0], VV[1], mine, tab, lane);
+            // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
+            // d < 4 and sends registers 4..7, wave 1 the other way round
+            if (w == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][4 + i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
+            __syncthreads();
+            // X[i] = E[i] + W^k O[i], X[i+4] = E[i] - W^k O[i]: wave 0 holds E and receives O, wave 1 the reverse
+            if (w == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                        const c64 t = cmul_tw<+1>(in, wc[64 * i]);
+                        const c64 Ei = VV[j][i];
+                        VV[j][i] = cadd(Ei, t);
+                        VV[j][i + 4] = csub(Ei, t);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const c64 Ei = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                        const c64 t = cmul_tw<+1>(VV[j][4 + i], wc[64 * i]);
+                        VV[j][i] = cadd(Ei, t);
+                        VV[j][i + 4] = csub(Ei, t);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const c64* row = reinterpret_cast<const c64*>(bskring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
+                c64 kb[3][2];
+                auto key2 = [&](int grp, c64 (&dst)[2]) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                    }
+                };
+                key2(0, kb[0]);
+                key2(1, kb[1]);
+#pragma unroll
+                for (int grp = 0; grp < 8; grp++) {
+                    if (grp + 2 < 8) key2(grp + 2, kb[(grp + 2) % 3]);
+                    compiler_fence();
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        const c64 k = kb[grp % 3][i];
+                        const bool first = p == 0 && j == 0;
+                        double re = __builtin_fma(k.re, VV[j][r].re, first ? 0.0 : prod[q][r].re);
+                        double im = __builtin_fma(k.re, VV[j][r].im, first ? 0.0 : prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
+                    }
+                }
+            }
+            __syncthreads(); // every wave is done with the ring and with its partner's cross data
+        }
+
+        // ---- back to the torus, both output polynomials together
+        c64 WW[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c64 wci = wc[64 * i];
+                WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                      // Ep: kept by wave 0
+                WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wci); // Op: kept by wave 1
+            }
+        if (w == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
+        }
+        pair_barrier(flags, me, partner, seq);
+        if (w == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+        }
+        pair_barrier(flags, me, partner, seq); // both cross reads retired before either region is overwritten
+        if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
+        fft512_pair1<-1>(WW[0], WW[1], mine, tab, lane);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint64_t t[16];
+            untwist_to_torus_bits(WW[q], twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[q][e] += t[e];
         }

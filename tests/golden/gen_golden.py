@@ -48,6 +48,16 @@ def main():
     x = (rng.standard_normal(1024) + 1j * rng.standard_normal(1024)) * 2.0 ** 40
     np.savez_compressed(os.path.join(HERE, "fft1024.npz"), x=x, fwd=O.fft1024(x, +1), inv=O.fft1024(x, -1),
                         twist=np.array([O.root_of_unity(j, 4096) for j in range(1024)]))
+    # 5. DEFAULT_128 (n = 637): three ciphertexts in / out.  The 83 MB key is not stored: it is re-derived
+    #    from the seed recipe (O.gen_keyset(key_seed, DEFAULT_128)), pinned by a checksum of its bits.
+    P128 = O.DEFAULT_128
+    k128 = O.gen_keyset(0x5EED0001, P128, with_ksk=False)
+    lwe128 = O.encrypt_bits_l0(0x5EED0200, k128, [0, 1, 1])
+    lwe128[2] = rng.integers(0, 1 << 64, P128.lwe_n + 1, dtype=np.uint64)   # and one arbitrary word vector
+    out128 = np.stack([O.cbs_pbs(x, k128.bsk_fft, P128) for x in lwe128])
+    np.savez_compressed(os.path.join(HERE, "pbs_default128.npz"), key_seed=np.uint64(0x5EED0001),
+                        lwe_n=np.uint32(P128.lwe_n), lwe=lwe128, cbs_out=out128,
+                        bsk_checksum=k128.bsk_fft.view(np.uint64).sum(dtype=np.uint64))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -43,6 +43,14 @@ def test_oracle_reproduces_fft_fixture(golden_dir):
     assert np.array_equal(tw, z["twist"])  # same libm => same tables on this image
 
 
+def test_oracle_reproduces_default128_fixture(golden_dir):
+    z = _load(golden_dir, "pbs_default128.npz")
+    ks = O.gen_keyset(int(z["key_seed"]), O.DEFAULT_128.replace(lwe_n=int(z["lwe_n"])), with_ksk=False)
+    assert int(ks.bsk_fft.view(np.uint64).sum(dtype=np.uint64)) == int(z["bsk_checksum"])
+    for i, x in enumerate(z["lwe"]):
+        assert np.array_equal(O.cbs_pbs(x, ks.bsk_fft, ks.params), z["cbs_out"][i])
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_golden_fixtures(golden_dir):
     import spf_amd

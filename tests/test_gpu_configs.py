@@ -1,0 +1,135 @@
+"""GPU parity at the sizes BASELINE.json's configs name (task 1): the kernels the bench runs
+must meet the oracle at DEFAULT_128 inside the -m gpu suite, not only inside bench.py.
+
+  config 2  "Batch of 4096 independent programmable bootstraps, default params, 1xMI355X":
+            B = 4096 at n = 637 through spf_circuit_bootstrap_pbs_batch (throughput kernel), every
+            ciphertext compared with the oracle; ragged B = 1031 on a sample; keyswitch at B = 4096
+            (int8-MFMA path, 32 row tiles); streaming cmux_kernel at B > 256.
+  noise     SURVEY §8(c)(ii): one external product at the PBS shape on the GPU against the exact
+            integer negacyclic product, normalised torus distance bounded (method of
+            parasol_runtime/examples/op_noise/noise.rs:15-38).
+  golden    a DEFAULT_128 fixture (tests/golden/pbs_default128.npz: inputs + expected outputs, key
+            re-derived from the seed recipe stored beside them).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import spf_amd
+from tests.util import M64, keyset, random_glwe, random_lwe_batch, to_engine_params
+
+pytestmark = pytest.mark.gpu
+
+HOST_THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def full():
+    ks = keyset(0x5EED0001, 637)
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    return ks, eng
+
+
+def test_config2_batch_4096_pbs_default128_every_ciphertext(full):
+    """BASELINE configs[1]: all 4096 outputs of the throughput kernel equal the oracle's, word for word."""
+    ks, eng = full
+    B = 4096
+    lwe = random_lwe_batch(0xC0F2, B, 637)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    _, exp = O.bench_cbs_pbs(lwe, ks.bsk_fft, ks.params, HOST_THREADS, native=False)
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} ciphertexts differ, first {bad[:8]}"
+
+
+def test_config2_ragged_batch_1031_default128(full):
+    """Ragged last workgroup (1031 = 257 workgroups of four + 3) at n = 637: first / last ciphertext of
+    a workgroup and the tail against the oracle."""
+    ks, eng = full
+    B = 1031
+    lwe = random_lwe_batch(0xC0F3, B, 637)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    for i in (0, 3, 4, 515, 1023, 1027, 1028, 1029, 1030):
+        assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
+
+
+def test_config2_keyswitch_4096_default128(full):
+    """The int8-MFMA keyswitch over 32 row tiles x 5 column tiles: sampled rows against the oracle, and the
+    whole batch against the same rows keyswitched 100 at a time (other tile boundaries)."""
+    ks, eng = full
+    P = ks.params
+    B = 4096
+    lwe1 = random_lwe_batch(0xC0F4, B, P.N)
+    got = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+    for i in (0, 1, 127, 128, 129, 2047, 2048, 4000, 4094, 4095):
+        exp = O.keyswitch_lwe(lwe1[i], ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count)
+        assert np.array_equal(got[i], exp), i
+    ref = np.concatenate([eng.keyswitch_lwe_l1_lwe_l0(lwe1[i:i + 100]) for i in range(0, B, 100)])
+    assert np.array_equal(got, ref)
+
+
+def test_config3_streaming_cmux_515(full):
+    """cmux_kernel (the streaming shape, B > #CU) with a ragged tail: a sample against the oracle."""
+    ks, eng = full
+    P = ks.params
+    B = 515
+    nrng = np.random.default_rng(515)
+    a = random_glwe(31, B, P.glwe_len)
+    b = random_glwe(32, B, P.glwe_len)
+    n = 2 * 4 * 2 * 1024
+    g = ((nrng.standard_normal((B, n)) + 1j * nrng.standard_normal((B, n))) * 2.0 ** 60).astype(np.complex128)
+    got = eng.cmux(g, a, b)
+    for i in (0, 3, 4, 257, 511, 512, 513, 514):
+        assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+
+
+def _torus_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    d = (a.astype(np.uint64) - b.astype(np.uint64)).astype(np.int64)
+    return np.abs(d.astype(np.float64)) / 2.0 ** 64
+
+
+def test_external_product_fft_noise_at_pbs_shape():
+    """One GGSW (x) GLWE external product at the PBS shape (N = 2048, k = 1, 2 x 16 bits) on the GPU — a
+    one-step blind rotation — against the EXACT integer result: digits x time-domain GGSW rows by the
+    u64 negacyclic product (spfo_negacyclic_mul_exact).  The only difference is the f64 FFT round trip;
+    its normalised torus distance must stay at the reference's FFT error scale (53-bit mantissa against
+    products of magnitude 2^15 * 2^64 * sqrt(4 * 2048) ~ 2^85.5: error ~ 2^-31 of the torus)."""
+    P = O.DEFAULT_128.replace(lwe_n=1)
+    rng = np.random.default_rng(0xE47)
+    N = P.N
+    # time-domain GGSW rows, uniform torus words (what an encrypted GGSW looks like): [row p][level][q][N]
+    G = rng.integers(0, 1 << 64, (2, 2, 2, N), dtype=np.uint64)
+    bsk = np.stack([O.poly_fft(G[p, lvl, q]) for p in range(2) for lvl in range(2) for q in range(2)]).reshape(-1)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(bsk)
+    a_t = 37
+    lwe = np.array([[np.uint64(a_t << 52), 0]], dtype=np.uint64)     # a~ = 37, b~ = 0
+    d0 = rng.integers(0, 1 << 64, 2 * N, dtype=np.uint64)
+    got = eng.generalized_pbs(lwe, d0)[0]
+    assert np.array_equal(got, O.generalized_pbs(lwe[0], d0, bsk, P))  # the oracle computes the same words
+    # exact: acc + sum_p sum_j digit_j(X^a acc_p - acc_p) * G[p][L-1-j][q]   (fft_ops.rs:23-98, radix.rs:157-162)
+    rot = np.concatenate([O.poly_mul_pos_monomial(d0[:N], a_t), O.poly_mul_pos_monomial(d0[N:], a_t)])
+    diff = rot - d0
+    exact = d0.copy()
+    for p in range(2):
+        digs = O.decompose_poly(diff[p * N:(p + 1) * N], P.pbs_radix_log, P.pbs_count)  # least significant first
+        for j in range(2):
+            for q in range(2):
+                exact[q * N:(q + 1) * N] += O.negacyclic_mul_exact(digs[j], G[p, 1 - j, q])
+    dist = _torus_distance(got, exact)
+    assert dist.max() < 2.0 ** -26, dist.max()
+    assert dist.max() > 0.0          # it IS a floating-point transform: not exact, just small
+    assert np.sqrt((dist ** 2).mean()) < 2.0 ** -29
+
+
+def test_golden_default128_fixture(golden_dir):
+    """DEFAULT_128 fixture: ciphertexts in / out as committed data, key re-derived from the stored seed."""
+    z = np.load(os.path.join(golden_dir, "pbs_default128.npz"))
+    ks = keyset(int(z["key_seed"]), int(z["lwe_n"]))
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    assert np.array_equal(eng.circuit_bootstrap_pbs(z["lwe"]), z["cbs_out"])
+    assert int(ks.bsk_fft.view(np.uint64).sum(dtype=np.uint64)) == int(z["bsk_checksum"]), "key recipe drifted"

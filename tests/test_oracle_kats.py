@@ -320,3 +320,30 @@ def test_can_circuit_bootstrap_via_trace_ss(small_keys, tail_keys):
         out = O.cmux(d[0], d[1], g, P.N, P.k, P.cbs_radix_log, P.cbs_count)
         dec = [O.decode(int(v), 3) for v in O.decrypt_glwe_raw(out, small_keys.glwe_sk, P.N, P.k)]
         assert dec == [O.decode(int(v), 3) for v in m[bit]]
+
+
+def test_external_product_fft_error_at_cryptographic_magnitude():
+    """SURVEY §8(c)(ii) on the CPU side: a one-step blind rotation (= one GGSW (x) GLWE external product
+    at the PBS shape) with uniform 64-bit GGSW rows, against the exact integer negacyclic product.  The
+    f64 FFT round trip must stay at the reference's error scale (~2^-30 of the torus); the same check
+    runs against the HIP output in tests/test_gpu_configs.py."""
+    P = O.DEFAULT_128.replace(lwe_n=1)
+    rng = np.random.default_rng(0xE47)
+    N = P.N
+    G = rng.integers(0, 1 << 64, (2, 2, 2, N), dtype=np.uint64)
+    bsk = np.stack([O.poly_fft(G[p, lvl, q]) for p in range(2) for lvl in range(2) for q in range(2)]).reshape(-1)
+    a_t = 37
+    lwe = np.array([np.uint64(a_t << 52), 0], dtype=np.uint64)
+    d0 = rng.integers(0, 1 << 64, 2 * N, dtype=np.uint64)
+    got = O.generalized_pbs(lwe, d0, bsk, P)
+    rot = np.concatenate([O.poly_mul_pos_monomial(d0[:N], a_t), O.poly_mul_pos_monomial(d0[N:], a_t)])
+    diff = rot - d0
+    exact = d0.copy()
+    for p in range(2):
+        digs = O.decompose_poly(diff[p * N:(p + 1) * N], P.pbs_radix_log, P.pbs_count)
+        for j in range(2):
+            for q in range(2):
+                exact[q * N:(q + 1) * N] += O.negacyclic_mul_exact(digs[j], G[p, 1 - j, q])
+    dist = np.abs((got - exact).astype(np.int64).astype(np.float64)) / 2.0 ** 64
+    assert 0.0 < dist.max() < 2.0 ** -26
+    assert np.sqrt((dist ** 2).mean()) < 2.0 ** -29
