@@ -262,6 +262,65 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 
+// ---- register <-> lane transposition without LDS ------------------------------------------------
+// Swap the three bits of the register index r (V[r], r = 4 r2 + 2 r1 + r0) with lane bits 5, 4, 3:
+// afterwards lane (h2 h1 h0 | lo3) register (r2 r1 r0) holds what lane (r2 r1 r0 | lo3) register
+// (h2 h1 h0) held.  Bit 5 and bit 4 are one `v_permlane32_swap` / `v_permlane16_swap` per dword and
+// register pair (the instruction IS the 2x2 block transpose: upper half of the first operand <->
+// lower half of the second), bit 3 has no swap instruction: a copy and two bank-masked DPP moves
+// (row_ror:8 reaches lane ^ 8 inside a row of 16).  16 + 16 + 48 32-bit VALU instructions for the eight
+// complex registers, no LDS traffic and no waitcnt.
+__device__ __forceinline__ void swap_halves32(double& a, double& b)
+{
+    uint32_t al = (uint32_t)__double2loint(a), ah = (uint32_t)__double2hiint(a);
+    uint32_t bl = (uint32_t)__double2loint(b), bh = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap_rows16(double& a, double& b)
+{
+    uint32_t al = (uint32_t)__double2loint(a), ah = (uint32_t)__double2hiint(a);
+    uint32_t bl = (uint32_t)__double2loint(b), bh = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap_lane8(double& a, double& b)
+{
+    // a: lanes with bit 3 set take b from lane ^ 8; b: lanes with bit 3 clear take (the old) a from lane ^ 8
+    constexpr int kRowRor8 = 0x128; // DPP row_ror:8
+    int al = __double2loint(a), ah = __double2hiint(a);
+    int bl = __double2loint(b), bh = __double2hiint(b);
+    int nal = __builtin_amdgcn_update_dpp(al, bl, kRowRor8, 0xF, 0xC, false);
+    int nah = __builtin_amdgcn_update_dpp(ah, bh, kRowRor8, 0xF, 0xC, false);
+    int nbl = __builtin_amdgcn_update_dpp(bl, al, kRowRor8, 0xF, 0x3, false);
+    int nbh = __builtin_amdgcn_update_dpp(bh, ah, kRowRor8, 0xF, 0x3, false);
+    a = __hiloint2double(nah, nal);
+    b = __hiloint2double(nbh, nbl);
+}
+__device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // register bit 2 <-> lane bit 5
+        swap_halves32(V[r].re, V[r + 4].re);
+        swap_halves32(V[r].im, V[r + 4].im);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) { // register bit 1 <-> lane bit 4
+        if (r & 2) continue;
+        swap_rows16(V[r].re, V[r + 2].re);
+        swap_rows16(V[r].im, V[r + 2].im);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) { // register bit 0 <-> lane bit 3
+        swap_lane8(V[r].re, V[r + 1].re);
+        swap_lane8(V[r].im, V[r + 1].im);
+    }
+}
+
 // fft512_pair with ONE 8 KiB exchange image for both transforms — the form that fits two waves per
 // SIMD (blind_rotate2p_kernel: 256 registers, 8 KiB of LDS per wave).  A wave's DS instructions execute
 // in issue order, so the two transforms can take turns on the same image as long as the program
@@ -274,9 +333,22 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
 // i.e. writer (hi3, lo3) reg r -> ((64 hi3 + lo3) ^ r) + 8 r in both; both are conflict-free for
 // ds_write_b128 (8 distinct slots mod 8 per 8-lane group) and ds_read_b128 (16 distinct slots mod 16
 // per 16-lane group of the b128 read pattern).
-template <int DIR>
-__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
+// XP = 1: exchange 2 (registers c <-> lane bits 5..3 = b, the lanes are (b, k1) before and (c, k1) after:
+// exactly `lane_transpose_hi3`) stays in registers; only exchange 1 goes through the image.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// XP: which transforms keep exchange 2 in registers (registers c <-> lane bits 5..3 = b; the lanes are
+// (b, k1) before and (c, k1) after: exactly `lane_transpose_hi3`) instead of sending it through the
+// image: 0 none, 1 both, 2 only B (balances the LDS store path against the VALU).
+// `before_first_write` runs right before the first store into the image (a deferred "the image is free"
+// wait goes there, behind the first butterfly pass); `tick(k)` runs at segment boundary k = 0..7.
+template <int DIR, int XP = 0, class Hook = NoHook, class Tick = NoHook>
+__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane,
+                                             Hook before_first_write = Hook(), Tick tick = Tick())
 {
+    constexpr bool XA = XP == 1, XB = XP == 1 || XP == 2;
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
     const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
@@ -288,9 +360,11 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     radix8<DIR>(A);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    before_first_write();
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
     sched_fence();
+    tick(0);
     radix8<DIR>(B);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
@@ -301,7 +375,8 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
     sched_fence();
-    // pass 2
+    tick(1);
+    // pass 2 of A; B's exchange-1 reads travel under it
     radix8<DIR>(A);
 #pragma unroll
     for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
@@ -309,25 +384,41 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
 #pragma unroll
     for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
     sched_fence();
+    if constexpr (XA) {
+        lane_transpose_hi3(A);
+        radix8<DIR>(A); // pass 3 of A
+    } else {
 #pragma unroll
-    for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+    }
     sched_fence();
+    tick(2);
     radix8<DIR>(B);
 #pragma unroll
     for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
     sched_fence();
+    if constexpr (!XA) {
 #pragma unroll
-    for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
-    sched_fence();
+        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        sched_fence();
+    }
+    if constexpr (XB) {
+        lane_transpose_hi3(B);
+        tick(3);
+        if constexpr (!XA) radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
+        radix8<DIR>(B);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = B[c];
-    sched_fence();
-    // pass 3
-    radix8<DIR>(A);
-    sched_fence();
+        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = B[c];
+        sched_fence();
+        tick(3);
+        // pass 3
+        radix8<DIR>(A);
+        sched_fence();
 #pragma unroll
-    for (int b = 0; b < 8; b++) B[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
-    radix8<DIR>(B);
+        for (int b = 0; b < 8; b++) B[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        radix8<DIR>(B);
+    }
     sched_fence(); // the image's next writer stays behind these reads
 }
 

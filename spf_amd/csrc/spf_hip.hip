@@ -221,10 +221,28 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         if (st != SPF_OK) return st;
         HIPCHK(c, hipEventRecord(tl.start, s));
     }
+#ifdef SPF_STAMPS
+    static uint64_t* d_stamps = nullptr;
+    const size_t n_stamp = (size_t)grid.x * 8 * 16;
+    if (cts == 4) {
+        if (d_stamps) (void)hipFree(d_stamps);
+        HIPCHK(c, hipMalloc(&d_stamps, n_stamp * 8));
+        HIPCHK(c, hipMemsetAsync(d_stamps, 0, n_stamp * 8, s));
+        a.stamps = d_stamps;
+    }
+#endif
     // SPF_PAIRED=0 keeps the one-digit-at-a-time throughput kernel (blind_rotate2_kernel) for A/B runs
     static const bool paired = [] { const char* e = getenv("SPF_PAIRED"); return !(e && e[0] == '0'); }();
     if (quad) hipLaunchKernelGGL((blind_rotate4_kernel<2, 16>), grid, block, kBlindRotate4Lds, s, a);
-    else if (variant == 2 && cts == 4 && paired) hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16>), grid, block, kBlindRotate2pLds, s, a);
+    else if (variant == 2 && cts == 4 && paired) {
+        static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 2; }();
+        switch (p_opt) {
+#define SPF_P_CASE(O) case O: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, O>), grid, block, kBlindRotate2pLds, s, a); break;
+        SPF_P_CASE(0) SPF_P_CASE(1) SPF_P_CASE(4) SPF_P_CASE(6)
+#undef SPF_P_CASE
+        default: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, 2>), grid, block, kBlindRotate2pLds, s, a); break;
+        }
+    }
     else if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
     else if (variant == 2 && wide && cts == 1) hipLaunchKernelGGL((blind_rotate2w_kernel<2, 16, 1>), grid, block, blind_rotate2w_lds<1>(), s, a);
     else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
@@ -235,6 +253,36 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         HIPCHK(c, hipEventRecord(tl.stop, s));
         c->t_pbs.push_back(tl);
     }
+#ifdef SPF_STAMPS
+    if (a.stamps) { // diagnostic build: median over waves of the per-phase cycle sums, per CMUX step
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::vector<uint64_t> h(n_stamp);
+        HIPCHK(c, hipMemcpy(h.data(), a.stamps, n_stamp * 8, hipMemcpyDeviceToHost));
+        static const char* names[12] = {"stage+rendezvous", "gather+decomp+twist", "rendezvous(gathered)", "fwd transform pair",
+            "cross write+key barrier", "cross read+combine", "MAD x2", "ring barrier", "inverse cross exchange",
+            "inv transform pair", "untwist+convert+acc", "step head"};
+        double total = 0;
+        std::vector<double> med(12), med_old(12), med_young(12);
+        for (int i = 0; i < 12; i++) {
+            std::vector<uint64_t> v, vo, vy;
+            for (size_t wv = 0; wv < (size_t)grid.x * 8; wv++) {
+                v.push_back(h[wv * 16 + i]);
+                ((wv & 7) < 4 ? vo : vy).push_back(h[wv * 16 + i]);
+            }
+            std::sort(v.begin(), v.end());
+            std::sort(vo.begin(), vo.end());
+            std::sort(vy.begin(), vy.end());
+            med[i] = (double)v[v.size() / 2] / a.n;
+            med_old[i] = (double)vo[vo.size() / 2] / a.n;
+            med_young[i] = (double)vy[vy.size() / 2] / a.n;
+            total += med[i];
+        }
+        fprintf(stderr, "[stamps] per CMUX step, median over %zu waves (cycles, share | waves 0-3 | waves 4-7)\n", (size_t)grid.x * 8);
+        for (int i = 0; i < 12; i++)
+            fprintf(stderr, "[stamps] %-26s %8.0f %5.1f%% | %8.0f | %8.0f\n", names[i], med[i], 100.0 * med[i] / total, med_old[i], med_young[i]);
+        fprintf(stderr, "[stamps] %-26s %8.0f\n", "total", total);
+    }
+#endif
     return SPF_OK;
 }
 
@@ -403,8 +451,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
+#define SPF_P_ATTR(O) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, O>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
+    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(4); SPF_P_ATTR(6);
+#undef SPF_P_ATTR
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),

@@ -37,6 +37,7 @@ struct BlindRotateArgs {
     uint32_t log_chi, log_v;
     uint64_t body_rotate;
     uint32_t sample_extract;  // 0: write GLWE (2N words), 1: write LWE (N+1 words), index 0
+    uint64_t* stamps;         // diagnostic builds (-DSPF_STAMPS) only: [workgroup][wave][16] cycle sums per phase
 };
 
 // modulus_switch (ops/ciphertext/lwe_ciphertext_ops.rs:130-142) to 2N = 4096
@@ -350,6 +351,16 @@ __device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, i
     asm volatile("" ::: "memory");
 }
 
+// Rendezvous of the latency shape: one ciphertext per workgroup, so the pair IS the workgroup and
+// s_barrier does it.  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
+// loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
+__device__ __forceinline__ void pair_barrier_w()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 //
 // CTS = ciphertexts per workgroup (4, 2 or 1; 128 CTS threads).  Four fill the CU (two waves per
 // SIMD) and share each key slot four ways: the throughput shape.  For batches that do not fill
@@ -617,16 +628,6 @@ __global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel
 template <int CTS>
 constexpr int blind_rotate2w_lds() { return kTableBytes + CTS * 2 * kWaveBufBytes; }
 
-// Rendezvous of the latency shape: one ciphertext per workgroup, so the pair IS the workgroup and
-// s_barrier does it.  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
-// loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
-__device__ __forceinline__ void pair_barrier_w()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 template <int L, int LOGB, int CTS>
 __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotateArgs a)
 {
@@ -854,33 +855,40 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
 //   * both output polynomials go back through one transform pair as well.
 // Per step: 4 workgroup barriers (2 of them right behind each other's MADs) and 6 pair rendezvous,
 // against 4 and 12 in blind_rotate2_kernel.
-constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes + 64;
+constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes;
 
-template <int L, int LOGB>
-__global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
+// OPT (A/B switches, SPF_P_OPT): bit 0 = exchange 2 of BOTH transforms of a pair in registers
+// (lane_transpose_hi3), bit 1 = of the second transform only (default: balances the LDS store path against
+// the VALU), bit 2 = the SIMD partners alternate priority segment by segment inside the transform pairs.
+template <int L, int LOGB, int OPT, int W>
+__device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
+    constexpr int XP = (OPT & 1) ? 1 : ((OPT & 2) ? 2 : 0);
+#ifdef SPF_STAMPS
+    // per-phase wall cycles of this wave (diagnostic build; s_memtime drains lgkmcnt: ~5 % overhead)
+    uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
     static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
     constexpr int NT = 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values live in SGPRs
     const int cslot = wv >> 1;
-    const int w = wv & 1;
+    constexpr int w = W; // sample parity of this wave: compile-time, the kernel runs one copy of the body per parity
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
     char* bskring = smem + kTableBytes + 4 * kWaveBufBytes;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(bskring + 2 * kBskSlotBytes);
-    uint32_t seq = 0;
-    const int me = wv, partner = me ^ 1;
 
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
-        if (tid < 8) flags[tid] = 0;
     }
 
     const uint32_t ct_raw = blockIdx.x * 4 + cslot;
@@ -918,6 +926,32 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
             }
     }
     __syncthreads();
+    const uint32_t young = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 8); // 1 for waves 4..7
+    uint32_t opaque_zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+    constexpr bool ALT = (OPT & 4) != 0;
+    // s_setprio takes an immediate; the wave-uniform choice is made inside ONE asm statement so that the
+    // compiler's control-flow graph does not change (a C++ branch here tripled the kernel's scratch use).
+    // Branch operands are dword offsets from the next instruction (each instruction here is one dword).
+    auto set_prio = [&](uint32_t hi) {
+        asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc0 2\n\ts_setprio 1\n\ts_branch 1\n\ts_setprio 0"
+                     :: "s"(hi) : "scc");
+    };
+    auto tick = [&](int kseg) {
+        if constexpr (ALT) set_prio(young ^ (uint32_t)(kseg & 1) ^ 1u);
+    };
+    // Every hand-over between the two waves of a ciphertext is a bare s_barrier of the whole workgroup
+    // (LDS queue drained, vmcnt NOT: key rows stay in flight across it).  The four ciphertexts are tied
+    // together by the key ring twice per polynomial anyway, and the hardware barrier costs a few dozen
+    // cycles where a flat-polled word per wave pair cost ~2 000 (store -> visible -> load round trips
+    // through the vector-memory path): 50.0 -> 47.8 ms per 4096.  The loop never repeats (opaque_zero is
+    // 0, which the compiler cannot know); it gives each phase its own basic block — as one straight-line
+    // region the step spills three times as much.
+    auto rendezvous = [&]() {
+        do {
+            pair_barrier_w();
+        } while (opaque_zero != 0);
+    };
 
     uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
     const c64* twist = tab + kTWOff + w * 512 + lane;   // e^{+i pi (2n'+w)/2048}, n' = 64 n1 + lane
@@ -927,6 +961,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
     for (uint32_t step = 0; step < a.n; step++) {
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
+        STAMP(11);
 
         // bins lane + 64 (4w + i) + 512 s at index i + 4 s; starts at zero, which the first row's FMAs
         // take as a literal (no zeroed registers live across polynomial 0's transforms)
@@ -938,7 +973,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
             // followed by a rendezvous, for p = 1 by the workgroup barrier behind the MADs
 #pragma unroll
             for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
-            pair_barrier(flags, me, partner, seq); // both parities staged
+            rendezvous(); // both parities staged
+            STAMP(0);
             uint32_t dig[16];
             {
                 // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024
@@ -967,14 +1003,18 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
                 VV[0][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 0, tw);
                 VV[1][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 1, tw);
             }
-            pair_barrier(flags, me, partner, seq); // partner is done gathering from my region
+            STAMP(1);
+            rendezvous(); // partner is done gathering from my region
+            STAMP(2);
             // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
             // of polynomial 0 were requested ahead of the previous step's inverse transforms)
             if (p == 1) ring_dma(chunk);
-            fft512_pair1<+1>(VV[0], VV[1], mine, tab, lane);
+            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane, NoHook(), tick);
+            if constexpr (ALT) __builtin_amdgcn_s_setprio(0);
+            STAMP(3);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
             // d < 4 and sends registers 4..7, wave 1 the other way round
-            if (w == 0) {
+            if constexpr (w == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -987,8 +1027,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
             __syncthreads();
+            STAMP(4);
             // X[i] = E[i] + W^k O[i], X[i+4] = E[i] - W^k O[i]: wave 0 holds E and receives O, wave 1 the reverse
-            if (w == 0) {
+            if constexpr (w == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -1010,6 +1051,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
                         VV[j][i + 4] = csub(Ei, t);
                     }
             }
+            STAMP(5);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const c64* row = reinterpret_cast<const c64*>(bskring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
@@ -1039,7 +1081,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
                     }
                 }
             }
+            STAMP(6);
             __syncthreads(); // every wave is done with the ring and with its partner's cross data
+            STAMP(7);
         }
 
         // ---- back to the torus, both output polynomials together
@@ -1052,7 +1096,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
                 WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                      // Ep: kept by wave 0
                 WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wci); // Op: kept by wave 1
             }
-        if (w == 0) {
+        if constexpr (w == 0) {
 #pragma unroll
             for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -1063,8 +1107,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
 #pragma unroll
                 for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
         }
-        pair_barrier(flags, me, partner, seq);
-        if (w == 0) {
+        rendezvous();
+        if constexpr (w == 0) {
 #pragma unroll
             for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -1075,9 +1119,12 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
 #pragma unroll
                 for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
         }
-        pair_barrier(flags, me, partner, seq); // both cross reads retired before either region is overwritten
+        rendezvous(); // both cross reads retired before either region is overwritten
+        STAMP(8);
         if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
-        fft512_pair1<-1>(WW[0], WW[1], mine, tab, lane);
+        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane, NoHook(), tick);
+        if constexpr (ALT) __builtin_amdgcn_s_setprio(0);
+        STAMP(9);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             uint64_t t[16];
@@ -1085,7 +1132,15 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[q][e] += t[e];
         }
+        STAMP(10);
     }
+#ifdef SPF_STAMPS
+    if (a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 8 + wv) * 16 + i] = st_acc[i];
+    }
+#endif
+#undef STAMP
 
     if (!owns_output) return;
     uint64_t* out = a.out + (size_t)ct * a.out_stride;
@@ -1106,6 +1161,18 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
             }
         }
     }
+}
+
+
+// The body is instantiated once per sample parity (w = 0 / 1): every parity-dependent choice (which half
+// of the cross exchange a wave keeps, table offsets) is then static — no value selects, no branches that
+// merge register arrays (those end up in scratch), parity-dependent LDS offsets as immediates.
+template <int L, int LOGB, int OPT>
+__global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
