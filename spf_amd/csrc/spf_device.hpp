@@ -335,18 +335,11 @@ __device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8])
 // per 16-lane group of the b128 read pattern).
 // XP = 1: exchange 2 (registers c <-> lane bits 5..3 = b, the lanes are (b, k1) before and (c, k1) after:
 // exactly `lane_transpose_hi3`) stays in registers; only exchange 1 goes through the image.
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-    __device__ __forceinline__ void operator()(int) const {}
-};
 // XP: which transforms keep exchange 2 in registers (registers c <-> lane bits 5..3 = b; the lanes are
 // (b, k1) before and (c, k1) after: exactly `lane_transpose_hi3`) instead of sending it through the
 // image: 0 none, 1 both, 2 only B (balances the LDS store path against the VALU).
-// `before_first_write` runs right before the first store into the image (a deferred "the image is free"
-// wait goes there, behind the first butterfly pass); `tick(k)` runs at segment boundary k = 0..7.
-template <int DIR, int XP = 0, class Hook = NoHook, class Tick = NoHook>
-__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane,
-                                             Hook before_first_write = Hook(), Tick tick = Tick())
+template <int DIR, int XP = 0>
+__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
 {
     constexpr bool XA = XP == 1, XB = XP == 1 || XP == 2;
     const int hi3 = lane >> 3, lo3 = lane & 7;
@@ -360,11 +353,9 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     radix8<DIR>(A);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
-    before_first_write();
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
     sched_fence();
-    tick(0);
     radix8<DIR>(B);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
@@ -375,7 +366,6 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
     sched_fence();
-    tick(1);
     // pass 2 of A; B's exchange-1 reads travel under it
     radix8<DIR>(A);
 #pragma unroll
@@ -392,7 +382,6 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
         for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
     }
     sched_fence();
-    tick(2);
     radix8<DIR>(B);
 #pragma unroll
     for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
@@ -404,14 +393,12 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     }
     if constexpr (XB) {
         lane_transpose_hi3(B);
-        tick(3);
         if constexpr (!XA) radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
         radix8<DIR>(B);
     } else {
 #pragma unroll
         for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = B[c];
         sched_fence();
-        tick(3);
         // pass 3
         radix8<DIR>(A);
         sched_fence();

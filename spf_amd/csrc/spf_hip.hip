@@ -238,7 +238,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 2; }();
         switch (p_opt) {
 #define SPF_P_CASE(O) case O: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, O>), grid, block, kBlindRotate2pLds, s, a); break;
-        SPF_P_CASE(0) SPF_P_CASE(1) SPF_P_CASE(4) SPF_P_CASE(6) SPF_P_CASE(5)
+        SPF_P_CASE(0) SPF_P_CASE(1)
 #undef SPF_P_CASE
         default: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, 2>), grid, block, kBlindRotate2pLds, s, a); break;
         }
@@ -453,7 +453,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
 #define SPF_P_ATTR(O) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, O>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
-    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(4); SPF_P_ATTR(5); SPF_P_ATTR(6);
+    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2);
 #undef SPF_P_ATTR
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));

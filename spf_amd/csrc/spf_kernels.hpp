@@ -95,52 +95,6 @@ __device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t voff, 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
-// The eight 8 KiB piece rows of one 64 KiB key refill (this wave's 1 KiB of each), issued iff `cond`.
-// The test is INSIDE the asm statement: a wave-uniform C++ branch in the body of the blind-rotation loop
-// makes hipcc keep the loop's register arrays in scratch (1.6 KB per lane measured), an opaque statement
-// does not.  Piece k: LDS row lds + k * 0x2000, source sbase + voff + k * 0x2000.
-__device__ __forceinline__ void lds_dma_chunk_if(uint32_t cond, const void* sbase, uint32_t voff, uint32_t lds)
-{
-    uint32_t tv;
-    asm volatile("s_cmp_eq_u32 %[c], 0\n\t"
-                 "s_cbranch_scc1 .Lspf_dma_skip_%=\n\t"
-                 "s_mov_b32 m0, %[lds]\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[v]\n\t"
-                 "global_load_lds_dwordx4 %[v], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n\t"
-                 "s_add_u32 m0, m0, 0x2000\n\t"
-                 "v_add_u32_e32 %[tv], 0x2000, %[tv]\n\t"
-                 "global_load_lds_dwordx4 %[tv], %[s]\n"
-                 ".Lspf_dma_skip_%=:"
-                 : [tv] "=&v"(tv)
-                 : [c] "s"(cond), [s] "s"(sbase), [v] "v"(voff), [lds] "s"(lds)
-                 : "memory", "scc");
-}
-// `count` s_barriers iff cond (same reason for the asm-internal test)
-__device__ __forceinline__ void three_barriers_if(uint32_t cond)
-{
-    asm volatile("s_cmp_eq_u32 %0, 0\n\t"
-                 "s_cbranch_scc1 .Lspf_bar_skip_%=\n\t"
-                 "s_barrier\n\ts_barrier\n\ts_barrier\n"
-                 ".Lspf_bar_skip_%=:" :: "s"(cond) : "memory", "scc");
-}
 __device__ __forceinline__ uint32_t lds_address(const void* p)
 {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
@@ -904,23 +858,10 @@ __global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotat
 constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes;
 
 // OPT (A/B switches, SPF_P_OPT): bit 0 = exchange 2 of BOTH transforms of a pair in registers
-// (lane_transpose_hi3), bit 1 = of the second transform only (balances the LDS store path against the
-// VALU), bit 2 = PING-PONG: the two ciphertext groups of a workgroup (waves 0..3 / waves 4..7 — each SIMD
-// hosts one wave of each) run the same program ONE SLOT apart.  A CMUX step is six slots, alternately
-// LDS-heavy and VALU-heavy:
-//     Sc  untwist / convert / acc += (previous step), stage, rotate-gather, decompose, twist   (polynomial 0)
-//     L1  forward transform pair + cross-exchange write
-//     Sa  cross read, radix-2 combine, 2 x MAD (key rows of polynomial 0), stage, gather, decompose, twist (1)
-//     L2  forward transform pair + cross-exchange write
-//     Sb  combine, 2 x MAD (polynomial 1), inverse radix-2 split, cross exchange
-//     L3  inverse transform pair
-// so while one group's waves are in a transform pair (exchanges through LDS) their SIMD partners
-// decompose / multiply-accumulate / convert (f64 and integer VALU), and the LDS bursts of a transform
-// come from four waves instead of eight.  The offset is kept by barrier counting: every slot holds exactly
-// three s_barriers (the S slots' hand-overs; two dummy ones inside each transform pair and one in Sc),
-// waves 4..7 execute three extra barriers before the loop and waves 0..3 three after it.  The key ring is
-// refilled behind the SECOND group's MADs: that group requests its pieces right there, the first group
-// at the first dummy barrier of the transform pair it is in at that moment.
+// (lane_transpose_hi3), bit 1 = of the second transform only (default: balances the LDS store path against
+// the VALU).  Tried on this kernel and rejected (numbers in profiles/r02_experiments_blind_rotate.md): static and
+// alternating s_setprio for the younger SIMD partners, flat-polled and deferred pair rendezvous, and a
+// ping-pong schedule of the two ciphertext groups one slot apart.
 template <int L, int LOGB, int OPT, int W>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
@@ -970,12 +911,6 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
         for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
             lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
     };
-    // the same refill, issued iff cond (no C++ branch: see lds_dma_chunk_if)
-    auto ring_dma_if = [&](uint32_t cond, uint32_t chunk) {
-        const char* src = reinterpret_cast<const char*>(a.bsk) +
-                          (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes);
-        lds_dma_chunk_if(cond, src, dma_voff, dma_dst);
-    };
     ring_dma(0);
 
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
@@ -993,25 +928,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
     }
     __syncthreads();
-    const uint32_t young = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 8); // 1 for waves 4..7
     uint32_t opaque_zero;
     asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
-    constexpr bool PP = (OPT & 4) != 0;
-    const uint32_t group = young;
-    // a barrier that only keeps the count (no data handed over: nothing to drain)
-    auto dummy_barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
-    // inside a transform pair (ping-pong only): dummy barriers at segment boundaries 1 and 2, the ring
-    // refill of the first group behind the first of them
-    uint32_t tick_dma = 0, tick_chunk = 0;
-    auto tick = [&](int kseg) {
-        if constexpr (PP) {
-            if (kseg == 1) {
-                dummy_barrier();
-                ring_dma_if(tick_dma, tick_chunk);
-            }
-            if (kseg == 2) dummy_barrier();
-        }
-    };
     // Every hand-over between the two waves of a ciphertext is a bare s_barrier of the whole workgroup
     // (LDS queue drained, vmcnt NOT: key rows stay in flight across it).  The four ciphertexts are tied
     // together by the key ring twice per polynomial anyway, and the hardware barrier costs a few dozen
@@ -1030,27 +948,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
     const c64* wc = tab + kWCOff + 256 * w + lane;       // W1024^{lane + 64 (4w + i)}
     uint64_t a_next = lwe[0];
     uint32_t chunk = 0;
-    c64 WW[2][8]; // the inverse transforms' output (ping-pong: converted at the top of the next step's first slot)
-    auto to_torus = [&]() {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            uint64_t t[16];
-            untwist_to_torus_bits(WW[q], twist, t);
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
-        }
-    };
     auto stage = [&](int p) {
 #pragma unroll
         for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
     };
-    if constexpr (PP) {
-        three_barriers_if(group); // second group: one slot behind
-        // the loop is rotated: polynomial 0 is staged at the END of the previous step (first slot = convert
-        // the previous step's result, stage, hand over, gather ...), so the first staging happens here
-        stage(0);
-        rendezvous();
-    }
     for (uint32_t step = 0; step < a.n; step++) {
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
@@ -1064,10 +965,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
         for (int p = 0; p < 2; p++, chunk++) {
             // my region is free: for p = 0 the partner's last reads of it (inverse cross data) were
             // followed by a rendezvous, for p = 1 by the workgroup barrier behind the MADs
-            if (!(PP && p == 0)) {
-                stage(p);
-                rendezvous(); // both parities staged
-            }
+            stage(p);
+            rendezvous(); // both parities staged
             STAMP(0);
             uint32_t dig[16];
             {
@@ -1098,23 +997,12 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 VV[1][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 1, tw);
             }
             STAMP(1);
-            if constexpr (PP) {
-                if (p == 0) dummy_barrier(); // slot Sc holds one hand-over only
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my pieces of a refill requested in this slot
-            }
             rendezvous(); // partner is done gathering from my region
             STAMP(2);
-            if constexpr (PP) {
-                // polynomial 1's rows: the second group asked behind its MADs (below), the first asks now — at
-                // the first dummy barrier of this transform pair, which IS the barrier behind those MADs
-                tick_dma = p == 1 ? (group ^ 1u) : 0u;
-                tick_chunk = chunk;
-            } else {
-                // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
-                // of polynomial 0 were requested ahead of the previous step's inverse transforms)
-                if (p == 1) ring_dma(chunk);
-            }
-            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane, NoHook(), tick);
+            // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
+            // of polynomial 0 were requested ahead of the previous step's inverse transforms)
+            if (p == 1) ring_dma(chunk);
+            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
             STAMP(3);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
             // d < 4 and sends registers 4..7, wave 1 the other way round
@@ -1188,13 +1076,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             STAMP(6);
             __syncthreads(); // every wave is done with the ring and with its partner's cross data
             STAMP(7);
-            if constexpr (PP) {
-                // second group: both groups are done with these rows now (the first multiplied one slot ago)
-                ring_dma_if(group & (uint32_t)(chunk + 1 < total_chunks), chunk + 1);
-            }
         }
 
         // ---- back to the torus, both output polynomials together
+        c64 WW[2][8];
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -1228,24 +1113,17 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
         }
         rendezvous(); // both cross reads retired before either region is overwritten
         STAMP(8);
-        if constexpr (PP) {
-            tick_dma = (group ^ 1u) & (uint32_t)(chunk < total_chunks); // rows of the next step's polynomial 0
-            tick_chunk = chunk;
-        } else {
-            if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
-        }
-        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane, NoHook(), tick);
+        if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
+        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
         STAMP(9);
-        if constexpr (PP) dummy_barrier(); // slot boundary behind L3
-        to_torus();
-        if constexpr (PP) {
-            stage(0); // next step's polynomial 0 (after the last step: unused)
-            rendezvous();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint64_t t[16];
+            untwist_to_torus_bits(WW[q], twist, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
         }
         STAMP(10);
-    }
-    if constexpr (PP) {
-        three_barriers_if(group ^ 1u); // first group: the second's last slot
     }
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
