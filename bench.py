@@ -49,11 +49,15 @@ def main() -> int:
                          "on several = configs[3], 65536 bootstraps over 8 GPUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-keyswitch", action="store_true", help="also time the fused gate (keyswitch + PBS)")
-    ap.add_argument("--with-cmux", action="store_true", help="also time the batched cbs_radix CMUX kernel")
-    ap.add_argument("--with-cbs", action="store_true", help="also time Evaluation::circuit_bootstrap end to end")
-    ap.add_argument("--with-add32", type=int, default=0, metavar="K",
-                    help="also time K independent 32-bit encrypted additions as ONE gate graph (BASELINE config 3)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline step: skip the gate / CMUX / circuit-bootstrap / 32-bit-add / host-pointer legs "
+                         "that the default run appends to the line (a few seconds)")
+    ap.add_argument("--with-keyswitch", action="store_true", help="(default on) time the fused gate (keyswitch + PBS)")
+    ap.add_argument("--with-cmux", action="store_true", help="(default on) time the batched cbs_radix CMUX kernel")
+    ap.add_argument("--with-cbs", action="store_true", help="(default on) time Evaluation::circuit_bootstrap end to end")
+    ap.add_argument("--with-add32", type=int, default=-1, metavar="K",
+                    help="time K independent 32-bit encrypted additions as ONE gate graph (BASELINE config 3); "
+                         "default 1 on a single GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -86,6 +90,12 @@ def main() -> int:
 
     if args.batch <= 0:
         args.batch = 4096 if world == 1 else 8192
+    extras = not args.no_extras
+    args.with_keyswitch = args.with_keyswitch or extras
+    args.with_cmux = args.with_cmux or extras
+    args.with_cbs = args.with_cbs or extras
+    if args.with_add32 < 0:
+        args.with_add32 = 1 if (extras and world == 1) else 0
     P = spf_amd.DEFAULT_128
     # only one rank (re)builds the library if it is stale; the others wait for it
     if rank == 0:
@@ -94,29 +104,34 @@ def main() -> int:
         dist.barrier(device_ids=[local_dev]) if args.backend == "nccl" else dist.barrier()
     eng = spf_amd.Engine(P, device=local_dev)
 
-    # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob
+    # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob.
+    # All four ComputeKey fields (bootstrap, keyswitch, automorphism, scheme switch: crypto/keys.rs:306-318).
     t_keys0 = time.time()
     blobs = []
-    for which in (0, 1):
+    for which in (0, 1, 2, 3):
         ptr, nbytes = eng.key_blob(which)
         blobs.append(torch.as_tensor(_DevArray(ptr, nbytes), device=dev))
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0001)
     if rank == 0:
-        g = torch.Generator(device=dev)
-        g.manual_seed(0x5EED0001)
         # BSK-FFT magnitudes of a real key: DFT of 1024 uniform 64-bit words ~ N(0, (2^63)^2*1024/3)
         bsk = torch.randn(P.bsk_complex * 2, generator=g, device=dev, dtype=torch.float64) * (2.0 ** 67)
         blobs[0].copy_(bsk.view(torch.uint8))
         ksk = torch.randint(-(2 ** 63), 2 ** 63 - 1, (P.ksk_words,), generator=g, device=dev, dtype=torch.int64)
         blobs[1].copy_(ksk.view(torch.uint8))
         del bsk, ksk
+        for which in (2, 3):
+            n64 = blobs[which].numel() // 8
+            blobs[which].copy_((torch.randn(n64, generator=g, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
     torch.cuda.synchronize()
     t_bcast0 = time.time()
     if world > 1:
-        broadcast_keys(blobs, dist, src=0)   # RCCL over xGMI, once
+        broadcast_keys(blobs, dist, src=0)   # RCCL over xGMI, once: 146 MB + 63 MB + 2.2 MB + 0.5 MB
         torch.cuda.synchronize()
     t_bcast = time.time() - t_bcast0
-    eng.key_blob_commit(0)
-    eng.key_blob_commit(1)
+    key_bytes = sum(int(b.numel()) for b in blobs)
+    for which in (0, 1, 2, 3):
+        eng.key_blob_commit(which)
 
     # ---- synthetic ciphertext batch (uniform torus words; throughput is value-independent)
     B = args.batch
@@ -147,9 +162,12 @@ def main() -> int:
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = eng.last_kernel_ms("pbs")
+    kernel_name = eng.last_blind_rotate_kernel()
     eng.set_timing(False)
+    kernel_ms_minmax = [kernel_ms, kernel_ms]
     if world > 1:
         dt = max_over_ranks(dt, dist, device=dev)
+        kernel_ms_minmax = [-max_over_ranks(-kernel_ms, dist, device=dev), max_over_ranks(kernel_ms, dist, device=dev)]
 
     gate = None
     if args.with_keyswitch:
@@ -168,10 +186,14 @@ def main() -> int:
             gate_step()
         barrier()
         tg = time.perf_counter() - tg
+        if world > 1:
+            tg = max_over_ranks(tg, dist, device=dev)
         ks_ms, _ = eng.last_kernel_ms("keyswitch")
         eng.last_kernel_ms("pbs")
         eng.set_timing(False)
-        gate = {"gates_per_s": world * B * args.steps / tg, "keyswitch_kernel_ms": ks_ms}
+        ks_ops = 2.0 * B * (P.glwe_size * P.polynomial_degree * P.ks_radix_count) * P.lwe0_words * 8   # int8 MACs x 2 over the 8 byte planes
+        gate = {"gates_per_s": round(world * B * args.steps / tg, 1), "keyswitch_kernel_ms": round(ks_ms, 4),
+                "keyswitch_int8_mfma_frac": round(ks_ops / (ks_ms * 1e-3) / 5.0e15, 4) if ks_ms else None}
         # leave glwe_out holding the plain-PBS result for the parity sample below
         step()
         torch.cuda.synchronize()
@@ -179,15 +201,6 @@ def main() -> int:
     cbs = None
     if args.with_cbs:
         # Evaluation::circuit_bootstrap end to end: PBS -> trace (4 x 11 GLWE keyswitches) -> scheme switch
-        for which, scale in ((2, 2.0 ** 67), (3, 2.0 ** 67)):
-            ptr, nbytes = eng.key_blob(which)
-            t = torch.as_tensor(_DevArray(ptr, nbytes), device=dev)
-            if rank == 0:
-                t.copy_((torch.randn(nbytes // 8, generator=g, device=dev, dtype=torch.float64) * scale).view(torch.uint8))
-            if world > 1:
-                broadcast_keys([t], dist, src=0)
-            torch.cuda.synchronize()
-            eng.key_blob_commit(which)
         ggsw = torch.empty((B, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
         eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
         barrier()
@@ -205,7 +218,7 @@ def main() -> int:
 
     add32 = None
     if args.with_add32 > 0 and rank == 0:
-        add32 = _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, args.with_cbs)
+        add32 = _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, True)
         step()
         torch.cuda.synchronize()
 
@@ -239,24 +252,62 @@ def main() -> int:
     per_launch_s = kernel_ms * 1e-3 if launches else float("nan")
     achieved_tflops = FLOP_PER_PBS * B / per_launch_s / 1e12
     alg_bytes = P.bsk_complex * 16 + B * (P.lwe0_words * 8 + P.glwe_words * 8)
-    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate runs; FETCH_SIZE
-    # doubled per the gfx950 correction) — written by tools_summarize_prof.py, only valid for B = 4096
-    traffic, traffic_detail = None, None
-    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    if B == 4096 and os.path.exists(tpath):
+    # HBM bytes per launch and the SQ busy counters come from rocprofv3 PMC passes of this same command (separate
+    # runs, scripts_profile.sh; FETCH_SIZE doubled per the gfx950 correction) stored by tools_summarize_prof.py:
+    # they are NOT measured by this run, and are only attached when the stored profile is of the same kernel and batch
+    traffic, stored = None, None
+    tpath = os.path.join(ROOT, "profiles", "latest_counters.json")
+    if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic_detail = json.load(f)
-        traffic = traffic_detail.get("total_bytes")
+            stored = json.load(f)
+        if stored.get("kernel") != kernel_name or stored.get("batch") != B:
+            stored = {"note": f"stored profile is of {stored.get('kernel')} at batch {stored.get('batch')}: not attached"}
+        else:
+            traffic = stored.get("hbm_bytes_per_launch")
     roofline = {
-        "bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "bound": "fp64", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-        "traffic_detail": traffic_detail, "kernel": "blind_rotate2_kernel<2,16,4>", "kernel_ms": round(kernel_ms, 3), "launches": launches,
+        "issue_bound_frac": (stored or {}).get("valu_busy_frac"),
+        "stored_profile": stored, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 3),
+        "kernel_ms_min_max_over_ranks": [round(x, 3) for x in kernel_ms_minmax], "launches": launches,
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
-        "note": "f64 work runs on the VALU (v_fma_f64); MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and "
-                "MFMA alike, so the MFMA-f64 peak is the compute roof",
+        "note": "the f64 butterflies and MADs run on the VALU (v_fma_f64 / v_add_f64 / v_mul_f64, zero MFMA instructions); "
+                "MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and MFMA alike; issue_bound_frac = share of the kernel's "
+                "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / time), from the stored profile",
         "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": round(alg_bytes / per_launch_s / 1e9, 2),
                 "peak_GBs": HBM_PEAK_GBS},
     }
+
+    # ---- the host-pointer path (what the Rust shim of INTEGRATION.md calls): numpy arrays in, numpy arrays out,
+    # PCIe both ways inside the timed region.  Never `value`.
+    pcie = None
+    if extras and rank == 0:
+        lwe_h = lwe0.cpu().numpy().view(np.uint64)
+        # caller-allocated, reused output buffer (what the C ABI's caller holds); the first call also grows
+        # the context's staging buffers and touches the pages, outside the timed calls
+        out_h = np.zeros((B, P.glwe_words), dtype=np.uint64)
+        eng.circuit_bootstrap_pbs(lwe_h, out=out_h)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.circuit_bootstrap_pbs(lwe_h, out=out_h)
+        t_h = (time.perf_counter() - t0) / reps
+        same = bool(np.array_equal(out_h, glwe_out.cpu().numpy().view(np.uint64)))
+        lwe1_h = np.random.default_rng(7).integers(0, 1 << 64, size=(B, P.lwe1_words), dtype=np.uint64)
+        eng.gate_bootstrap(lwe1_h, out=out_h)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.gate_bootstrap(lwe1_h, out=out_h)
+        t_g = (time.perf_counter() - t0) / reps
+        pcie = {"pbs_per_s": round(B / t_h, 1), "ms_per_batch": round(t_h * 1e3, 3),
+                "frac_of_device_resident": round((B / t_h) / (B / (dt / args.steps)), 4),
+                "gates_per_s": round(B / t_g, 1), "gate_ms_per_batch": round(t_g * 1e3, 3),
+                "bytes_in": int(lwe_h.nbytes), "bytes_out": int(out_h.nbytes),
+                "note": "spf_circuit_bootstrap_pbs_batch / spf_gate_bootstrap_batch with pageable host arrays: H2D, kernels "
+                        "and D2H inside the timed call; outputs leave in slices of one chip round (1024 ciphertexts) under "
+                        "the next slice's kernel",
+                "same_words_as_device_path": same}
+        del out_h
 
     # ---- CPU baseline: the oracle (a port of the sunscreen_tfhe algorithm), rank 0 at N=1 only
     cpu = None
@@ -292,6 +343,8 @@ def main() -> int:
             "roofline": roofline,
             "cpu_baseline": cpu,
             "key_broadcast_s": round(t_bcast, 4) if world > 1 else None,
+            "key_broadcast_bytes": key_bytes,
+            "pcie_inclusive": pcie,
             "setup_s": round(t_bcast0 - t_keys0, 2),
         }
         if gate:

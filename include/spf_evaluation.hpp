@@ -39,10 +39,16 @@ class Evaluation {
     Evaluation(const ComputeKey& key, const spf_params& params, int device = 0) : params_(params)
     {
         check(spf_create(&params, device, &ctx_), nullptr);
-        check(spf_load_bootstrap_key(ctx_, key.bs_key, key.bs_key_complex), ctx_);
-        if (key.ks_key) check(spf_load_keyswitch_key(ctx_, key.ks_key, key.ks_key_words), ctx_);
-        if (key.auto_key) check(spf_load_automorphism_key(ctx_, key.auto_key, key.auto_key_complex), ctx_);
-        if (key.ss_key) check(spf_load_scheme_switch_key(ctx_, key.ss_key, key.ss_key_complex), ctx_);
+        try { // a throw from here on would skip the destructor: release the context (keys in HBM, stream) first
+            check(spf_load_bootstrap_key(ctx_, key.bs_key, key.bs_key_complex), ctx_);
+            if (key.ks_key) check(spf_load_keyswitch_key(ctx_, key.ks_key, key.ks_key_words), ctx_);
+            if (key.auto_key) check(spf_load_automorphism_key(ctx_, key.auto_key, key.auto_key_complex), ctx_);
+            if (key.ss_key) check(spf_load_scheme_switch_key(ctx_, key.ss_key, key.ss_key_complex), ctx_);
+        } catch (...) {
+            spf_destroy(ctx_);
+            ctx_ = nullptr;
+            throw;
+        }
     }
     // Evaluation::with_default_params (evaluation.rs:200-204)
     static Evaluation with_default_params(const ComputeKey& key, int device = 0)

@@ -188,6 +188,11 @@ spf_status spf_multiply_glwe_ggsw_batch(spf_ctx *ctx, size_t B, const uint64_t *
  * lwe1_in: B x (k*N+1); glwe_out: B x (k+1)*N. */
 spf_status spf_gate_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1_in,
                                     uint64_t *glwe_out);
+/* B x (FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap) with the whole circuit bootstrap
+ * (`Evaluation::keyswitch_lwe_l1_lwe_l0` then `Evaluation::circuit_bootstrap`, crypto/evaluation.rs:211-266):
+ * L1 LWE in, L1 GGSW-FFT out (cbs radix); the level-0 LWE in between stays in HBM. */
+spf_status spf_keyswitch_circuit_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1_in,
+                                                 double *ggsw_fft_out);
 
 /* ---- device-pointer forms (inputs/outputs resident in HBM, asynchronous on `stream`) ----- */
 
@@ -243,7 +248,13 @@ spf_status spf_pool_submit_keyswitch_circuit_bootstrap(spf_pool *pool, const uin
 /* `KeylessEvaluation::cmux` for one gate */
 spf_status spf_pool_submit_cmux(spf_pool *pool, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
                                 uint64_t *out, uint64_t *ticket);
+/* Blocks until the operation has run; each ticket can be collected exactly once (an unknown or already
+ * collected ticket is SPF_ERR_INVALID_ARGUMENT, never a hang). */
 spf_status spf_pool_wait(spf_pool *pool, uint64_t ticket);
+/* Flow control (the reference bounds its in-flight operations with a token channel,
+ * circuit_processor/mod.rs:139): a submit blocks while `max_inflight` tickets are submitted and not yet
+ * collected.  Default 4 x max_batch. */
+spf_status spf_pool_set_max_inflight(spf_pool *pool, size_t max_inflight);
 /* operations completed and batches launched so far (ops / launches = achieved batch size) */
 spf_status spf_pool_stats(spf_pool *pool, uint64_t *ops, uint64_t *launches);
 
@@ -316,6 +327,10 @@ spf_status spf_gather_rows_dev(spf_ctx *ctx, void *stream, size_t rows, size_t w
 spf_status spf_set_timing(spf_ctx *ctx, int enabled);
 spf_status spf_last_kernel_ms(spf_ctx *ctx, const char *kernel /* "pbs" | "keyswitch" */,
                               double *avg_ms, int *launches);
+/* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
+ * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
+ * shape).  For measurement records; never NULL. */
+const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
 
 /* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */
 const char *spf_version(void);

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("spf_glev_cmux_dev", _I, [_P, _P, _SZ, _P, _P, _P, _P]),
     ("spf_multiply_glwe_ggsw_dev", _I, [_P, _P, _SZ, _P, _P, _P]),
     ("spf_gate_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_keyswitch_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_keyswitch_lwe_l1_lwe_l0_dev", _I, [_P, _P, _SZ, _P, _P]),
     ("spf_generalized_pbs_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
     ("spf_pbs_univariate_dev", _I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("spf_pool_submit_keyswitch_circuit_bootstrap", _I, [_P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_submit_cmux", _I, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_wait", _I, [_P, _U64]),
+    ("spf_pool_set_max_inflight", _I, [_P, _SZ]),
     ("spf_pool_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spf_graph_create", _I, [_P, C.POINTER(_P)]),
     ("spf_graph_destroy", None, [_P]),
@@ -98,6 +100,7 @@ SYMBOLS = [
     ("spf_gather_rows_dev", _I, [_P, _P, _SZ, _SZ, _P, _P]),
     ("spf_set_timing", _I, [_P, _I]),
     ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
+    ("spf_last_blind_rotate_kernel", C.c_char_p, [_P]),
     ("spf_version", C.c_char_p, []),
 ]
 
@@ -131,6 +134,30 @@ def _u64(a, shape=None) -> np.ndarray:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _same_rows(what: str, *arrays):
+    """the C side copies B * row_size bytes of every operand: a batch mismatch would be an out-of-bounds
+    host read (the reference panics in assert_is_valid instead)"""
+    rows = {a.shape[0] for a in arrays}
+    if len(rows) != 1:
+        raise SpfError(-2, f"{what}: operand batches differ in size {[a.shape[0] for a in arrays]}")
+
+
+def _out(what: str, output, dtype, words: int) -> np.ndarray:
+    """caller-allocated output of a pool call: right dtype, C-contiguous, exactly `words` elements"""
+    if not isinstance(output, np.ndarray) or output.dtype != np.dtype(dtype) or not output.flags["C_CONTIGUOUS"] \
+            or not output.flags["WRITEABLE"] or output.size != words:
+        raise SpfError(-2, f"{what}: output must be a writable C-contiguous {np.dtype(dtype).name} array of {words} "
+                           f"elements, got {getattr(output, 'dtype', type(output))} x {getattr(output, 'size', '?')}")
+    return output
+
+
+def _in(what: str, a, dtype, words: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.size != words:
+        raise SpfError(-2, f"{what}: input has {a.size} elements, expected {words}")
+    return a
 
 
 class Engine:
@@ -227,9 +254,14 @@ class Engine:
                                                     _ptr(out)))
         return out
 
-    def circuit_bootstrap_pbs(self, lwe0) -> np.ndarray:
+    def circuit_bootstrap_pbs(self, lwe0, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """`out`: caller-allocated (B, glwe_words) uint64 array, as the C ABI's caller does — a fresh np.empty is
+        untouched memory, and its first-touch page faults land inside the device-to-host copy"""
         x = _u64(lwe0).reshape(-1, self.params.lwe0_words)
-        out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        if out is None:
+            out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        else:
+            _out("circuit_bootstrap_pbs", out, np.uint64, x.shape[0] * self.params.glwe_words)
         self._ck(self._lib.spf_circuit_bootstrap_pbs_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
         return out
 
@@ -283,6 +315,7 @@ class Engine:
         g = np.ascontiguousarray(sel_ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
         a = _u64(a).reshape(-1, self.params.glwe_words)
         b = _u64(b).reshape(-1, self.params.glwe_words)
+        _same_rows("cmux", g, a, b)
         out = np.empty_like(a)
         self._ck(self._lib.spf_cmux_batch(self._h, a.shape[0], _ptr(g), _ptr(a), _ptr(b), _ptr(out)))
         return out
@@ -292,6 +325,7 @@ class Engine:
         g = np.ascontiguousarray(sel_ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
         a = _u64(a).reshape(-1, n)
         b = _u64(b).reshape(-1, n)
+        _same_rows("glev_cmux", g, a, b)
         out = np.empty_like(a)
         self._ck(self._lib.spf_glev_cmux_batch(self._h, a.shape[0], _ptr(g), _ptr(a), _ptr(b), _ptr(out)))
         return out
@@ -299,13 +333,24 @@ class Engine:
     def multiply_glwe_ggsw(self, glwe, ggsw_fft) -> np.ndarray:
         g = np.ascontiguousarray(ggsw_fft, dtype=np.complex128).reshape(-1, self.params.cbs_ggsw_complex)
         x = _u64(glwe).reshape(-1, self.params.glwe_words)
+        _same_rows("multiply_glwe_ggsw", g, x)
         out = np.empty_like(x)
         self._ck(self._lib.spf_multiply_glwe_ggsw_batch(self._h, x.shape[0], _ptr(x), _ptr(g), _ptr(out)))
         return out
 
-    def gate_bootstrap(self, lwe1) -> np.ndarray:
+    def keyswitch_circuit_bootstrap(self, lwe1) -> np.ndarray:
+        """KeyswitchL1toL0 -> CircuitBootstrap (L1 LWE in, L1 GGSW-FFT out); the L0 LWE stays on the device"""
         x = _u64(lwe1).reshape(-1, self.params.lwe1_words)
-        out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        out = np.empty((x.shape[0], self.params.cbs_ggsw_complex), dtype=np.complex128)
+        self._ck(self._lib.spf_keyswitch_circuit_bootstrap_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+    def gate_bootstrap(self, lwe1, out: Optional[np.ndarray] = None) -> np.ndarray:
+        x = _u64(lwe1).reshape(-1, self.params.lwe1_words)
+        if out is None:
+            out = np.empty((x.shape[0], self.params.glwe_words), dtype=np.uint64)
+        else:
+            _out("gate_bootstrap", out, np.uint64, x.shape[0] * self.params.glwe_words)
         self._ck(self._lib.spf_gate_bootstrap_batch(self._h, x.shape[0], _ptr(x), _ptr(out)))
         return out
 
@@ -345,6 +390,9 @@ class Engine:
     def set_timing(self, enabled: bool):
         self._ck(self._lib.spf_set_timing(self._h, 1 if enabled else 0))
 
+    def last_blind_rotate_kernel(self) -> str:
+        return (self._lib.spf_last_blind_rotate_kernel(self._h) or b"").decode()
+
     def last_kernel_ms(self, kernel: str = "pbs"):
         ms, n = C.c_double(), C.c_int()
         self._ck(self._lib.spf_last_kernel_ms(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
@@ -376,6 +424,29 @@ class Pool:
         except Exception:
             pass
 
+    def set_max_inflight(self, n: int):
+        st = self._lib.spf_pool_set_max_inflight(self._h, n)
+        if st != 0:
+            raise SpfError(st, "spf_pool_set_max_inflight failed")
+
+    def submit_keyswitch(self, output: np.ndarray, input: np.ndarray) -> int:
+        """asynchronous form: returns the ticket; buffers must stay alive until wait(ticket) returns"""
+        t = C.c_uint64()
+        x = _in("pool keyswitch", input, np.uint64, self.engine.params.lwe1_words)
+        _out("pool keyswitch", output, np.uint64, self.engine.params.lwe0_words)
+        st = self._lib.spf_pool_submit_keyswitch(self._h, _ptr(x), _ptr(output), C.byref(t))
+        if st != 0:
+            raise SpfError(st, "submit failed")
+        self._keep = getattr(self, "_keep", {})
+        self._keep[t.value] = (x, output)
+        return t.value
+
+    def wait(self, ticket: int):
+        try:
+            self._wait(ticket)
+        finally:
+            getattr(self, "_keep", {}).pop(ticket, None)
+
     def _wait(self, ticket):
         st = self._lib.spf_pool_wait(self._h, ticket)
         if st != 0:
@@ -383,7 +454,8 @@ class Pool:
 
     def keyswitch_lwe_l1_lwe_l0(self, output: np.ndarray, input: np.ndarray):
         t = C.c_uint64()
-        x = _u64(input)
+        x = _in("pool keyswitch", input, np.uint64, self.engine.params.lwe1_words)
+        _out("pool keyswitch", output, np.uint64, self.engine.params.lwe0_words)
         st = self._lib.spf_pool_submit_keyswitch(self._h, _ptr(x), _ptr(output), C.byref(t))
         if st != 0:
             raise SpfError(st, "submit failed")
@@ -391,7 +463,8 @@ class Pool:
 
     def circuit_bootstrap(self, output: np.ndarray, input: np.ndarray):
         t = C.c_uint64()
-        x = _u64(input)
+        x = _in("pool circuit_bootstrap", input, np.uint64, self.engine.params.lwe0_words)
+        _out("pool circuit_bootstrap", output, np.complex128, self.engine.params.cbs_ggsw_complex)
         st = self._lib.spf_pool_submit_circuit_bootstrap(self._h, _ptr(x), _ptr(output), C.byref(t))
         if st != 0:
             raise SpfError(st, "submit failed")
@@ -399,7 +472,8 @@ class Pool:
 
     def keyswitch_circuit_bootstrap(self, output: np.ndarray, input_l1: np.ndarray):
         t = C.c_uint64()
-        x = _u64(input_l1)
+        x = _in("pool keyswitch_circuit_bootstrap", input_l1, np.uint64, self.engine.params.lwe1_words)
+        _out("pool keyswitch_circuit_bootstrap", output, np.complex128, self.engine.params.cbs_ggsw_complex)
         st = self._lib.spf_pool_submit_keyswitch_circuit_bootstrap(self._h, _ptr(x), _ptr(output), C.byref(t))
         if st != 0:
             raise SpfError(st, "submit failed")
@@ -407,7 +481,10 @@ class Pool:
 
     def cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
         t = C.c_uint64()
-        s_, a_, b_ = np.ascontiguousarray(sel, dtype=np.complex128), _u64(a), _u64(b)
+        P = self.engine.params
+        s_ = _in("pool cmux", sel, np.complex128, P.cbs_ggsw_complex)
+        a_, b_ = _in("pool cmux", a, np.uint64, P.glwe_words), _in("pool cmux", b, np.uint64, P.glwe_words)
+        _out("pool cmux", output, np.uint64, P.glwe_words)
         st = self._lib.spf_pool_submit_cmux(self._h, _ptr(s_), _ptr(a_), _ptr(b_), _ptr(output), C.byref(t))
         if st != 0:
             raise SpfError(st, "submit failed")

@@ -67,6 +67,9 @@ struct spf_ctx {
     DevBuf cbs_glwe, cbs_glev;      // circuit-bootstrap intermediates (lo-noise GLWE, GLEV)
     int n_cu = 256;                // compute units of the device (picks the blind-rotation shape)
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
+    const char* last_pbs_kernel = "";  // name of the blind-rotation kernel the last launch used
+    hipStream_t copy_stream = nullptr; // device-to-host copies of finished slices, under the next slice's kernel
+    std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
     bool timing = false;
     std::vector<TimedLaunch> t_pbs, t_ks;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -233,21 +236,23 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
 #endif
     // SPF_PAIRED=0 keeps the one-digit-at-a-time throughput kernel (blind_rotate2_kernel) for A/B runs
     static const bool paired = [] { const char* e = getenv("SPF_PAIRED"); return !(e && e[0] == '0'); }();
-    if (quad) hipLaunchKernelGGL((blind_rotate4_kernel<2, 16>), grid, block, kBlindRotate4Lds, s, a);
+#define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
+    if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16>), kBlindRotate4Lds);
     else if (variant == 2 && cts == 4 && paired) {
         static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 2; }();
         switch (p_opt) {
-#define SPF_P_CASE(O) case O: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, O>), grid, block, kBlindRotate2pLds, s, a); break;
-        SPF_P_CASE(0) SPF_P_CASE(1)
-#undef SPF_P_CASE
-        default: hipLaunchKernelGGL((blind_rotate2p_kernel<2, 16, 2>), grid, block, kBlindRotate2pLds, s, a); break;
+        case 0: SPF_LAUNCH("blind_rotate2p_kernel<2,16,0>", (blind_rotate2p_kernel<2, 16, 0>), kBlindRotate2pLds); break;
+        case 1: SPF_LAUNCH("blind_rotate2p_kernel<2,16,1>", (blind_rotate2p_kernel<2, 16, 1>), kBlindRotate2pLds); break;
+        case 6: SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6>), kBlindRotate2pLds); break;
+        default: SPF_LAUNCH("blind_rotate2p_kernel<2,16,2>", (blind_rotate2p_kernel<2, 16, 2>), kBlindRotate2pLds); break;
         }
     }
-    else if (variant == 2 && cts == 4) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 4>), grid, block, blind_rotate2_lds<4>(), s, a);
-    else if (variant == 2 && wide && cts == 1) hipLaunchKernelGGL((blind_rotate2w_kernel<2, 16, 1>), grid, block, blind_rotate2w_lds<1>(), s, a);
-    else if (variant == 2 && cts == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 2>), grid, block, blind_rotate2_lds<2>(), s, a);
-    else if (variant == 2) hipLaunchKernelGGL((blind_rotate2_kernel<2, 16, 1>), grid, block, blind_rotate2_lds<1>(), s, a);
-    else hipLaunchKernelGGL((blind_rotate_kernel<2, 16>), grid, block, kBlindRotateLds, s, a);
+    else if (variant == 2 && cts == 4) SPF_LAUNCH("blind_rotate2_kernel<2,16,4>", (blind_rotate2_kernel<2, 16, 4>), blind_rotate2_lds<4>());
+    else if (variant == 2 && wide && cts == 1) SPF_LAUNCH("blind_rotate2w_kernel<2,16,1>", (blind_rotate2w_kernel<2, 16, 1>), blind_rotate2w_lds<1>());
+    else if (variant == 2 && cts == 2) SPF_LAUNCH("blind_rotate2_kernel<2,16,2>", (blind_rotate2_kernel<2, 16, 2>), blind_rotate2_lds<2>());
+    else if (variant == 2) SPF_LAUNCH("blind_rotate2_kernel<2,16,1>", (blind_rotate2_kernel<2, 16, 1>), blind_rotate2_lds<1>());
+    else SPF_LAUNCH("blind_rotate_kernel<2,16>", (blind_rotate_kernel<2, 16>), kBlindRotateLds);
+#undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
@@ -417,6 +422,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     } while (0)
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     {
         int cu = 0;
         CK(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id));
@@ -453,7 +459,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
 #define SPF_P_ATTR(O) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, O>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
-    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2);
+    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(6);
 #undef SPF_P_ATTR
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
@@ -488,6 +494,8 @@ void spf_destroy(spf_ctx* c)
                     c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -520,8 +528,9 @@ spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
 
 spf_status spf_key_blob_commit(spf_ctx* c, int which)
 {
-    if (!c) return SPF_ERR_INVALID_ARGUMENT;
+    if (!c) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null context");
     std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device)); // the byte planes are allocated and built on THIS context's GPU
     if (which == 0 && c->d_bsk) c->bsk_ready = true;
     else if (which == 1 && c->d_ksk) {
         spf_status st = build_ks_planes(c);
@@ -863,6 +872,45 @@ spf_status spf_keyswitch_lwe_l1_lwe_l0_batch(spf_ctx* c, size_t B, const uint64_
     return SPF_OK;
 }
 
+// Bootstrap a device-resident batch and bring the outputs to the caller's host buffer, in SLICES of one
+// full round of the chip (4 ciphertexts x #CU): all slices are enqueued on the compute stream at once,
+// each followed by an event; the copy stream waits for slice k's event and copies it out while slices
+// k+1.. run.  The output is 32 KiB per ciphertext (134 MB per 4096): in one piece behind the kernel it
+// added 10-15 % to a call, sliced only the last slice's copy is exposed.  (A pageable destination makes
+// hipMemcpyAsync block the host until that copy is done — which is why every kernel is enqueued first.)
+// SPF_HOST_SLICES=0 restores the single copy (A/B).
+static spf_status bootstrap_sliced_to_host(spf_ctx* c, size_t B, const uint64_t* d_lwe, const uint64_t* d_lut,
+                                           size_t lut_stride, uint32_t log_chi, uint32_t log_v, uint64_t rot, size_t ow,
+                                           bool extract, uint64_t* host_out)
+{
+    static const bool sliced = [] { const char* e = getenv("SPF_HOST_SLICES"); return !(e && e[0] == '0'); }();
+    const size_t lw = lwe0_words(c->prm);
+    const size_t round = 4 * (size_t)c->n_cu;
+    const size_t slice = (sliced && B > round) ? round : B;
+    const size_t n_slices = (B + slice - 1) / slice;
+    while (c->slice_ev.size() < n_slices) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->slice_ev.push_back(e);
+    }
+    uint64_t* d_out = (uint64_t*)c->out.p;
+    for (size_t k = 0; k < n_slices; k++) {
+        const size_t off = k * slice, n = std::min(slice, B - off);
+        spf_status s = launch_blind_rotate(c, c->stream, n, d_lwe + off * lw, d_lut + off * lut_stride, lut_stride, log_chi,
+                                           log_v, rot, d_out + off * ow, ow, extract);
+        if (s != SPF_OK) return s;
+        HIPCHK(c, hipEventRecord(c->slice_ev[k], c->stream));
+    }
+    for (size_t k = 0; k < n_slices; k++) {
+        const size_t off = k * slice, n = std::min(slice, B - off);
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->slice_ev[k], 0));
+        HIPCHK(c, hipMemcpyAsync(host_out + off * ow, d_out + off * ow, n * ow * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
 static spf_status pbs_host(spf_ctx* c, size_t B, const uint64_t* lwe, const uint64_t* lut, size_t lut_stride,
                            uint32_t log_chi, uint32_t log_v, uint64_t rot, uint64_t* out, bool extract)
 {
@@ -882,12 +930,8 @@ static spf_status pbs_host(spf_ctx* c, size_t B, const uint64_t* lwe, const uint
     size_t ow = extract ? lwe1_words(c->prm) : glwe_words(c->prm);
     spf_status s = ensure(c, c->out, B * ow * 8);
     if (s != SPF_OK) return s;
-    s = launch_blind_rotate(c, c->stream, B, (const uint64_t*)c->in.p, d_lut, lut ? lut_stride : 0, log_chi, log_v, rot,
-                            (uint64_t*)c->out.p, ow, extract);
-    if (s != SPF_OK) return s;
-    HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * ow * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SPF_OK;
+    return bootstrap_sliced_to_host(c, B, (const uint64_t*)c->in.p, d_lut, lut ? lut_stride : 0, log_chi, log_v, rot, ow,
+                                    extract, out);
 }
 
 spf_status spf_generalized_pbs_batch(spf_ctx* c, size_t B, const uint64_t* lwe, const uint64_t* lut, size_t lut_stride,
@@ -1124,6 +1168,27 @@ spf_status spf_circuit_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe
     return SPF_OK;
 }
 
+spf_status spf_keyswitch_circuit_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1_in, double* ggsw_out)
+{
+    if (!c || (B && (!lwe1_in || !ggsw_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (B == 0) return SPF_OK;
+    const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    std::lock_guard<std::recursive_mutex> whole(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    STAGE_IN(c->in, lwe1_in, B * lwe1_words(c->prm) * 8);
+    spf_status s = ensure(c, c->mid, B * lwe0_words(c->prm) * 8); // the level-0 LWE never leaves the device
+    if (s != SPF_OK) return s;
+    s = ensure(c, c->out, B * sw);
+    if (s != SPF_OK) return s;
+    s = launch_keyswitch(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->mid.p);
+    if (s != SPF_OK) return s;
+    s = spf_circuit_bootstrap_dev(c, c->stream, B, (const uint64_t*)c->mid.p, (double*)c->out.p);
+    if (s != SPF_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(ggsw_out, c->out.p, B * sw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPF_OK;
+}
+
 spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, uint64_t* glwe_out)
 {
     if (!c || (B && (!lwe1 || !glwe_out))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
@@ -1137,13 +1202,8 @@ spf_status spf_gate_bootstrap_batch(spf_ctx* c, size_t B, const uint64_t* lwe1, 
     if (s != SPF_OK) return s;
     s = launch_keyswitch(c, c->stream, B, (const uint64_t*)c->in.p, (uint64_t*)c->mid.p);
     if (s != SPF_OK) return s;
-    s = launch_blind_rotate(c, c->stream, B, (const uint64_t*)c->mid.p, c->d_cbs_lut, 0, 0,
-                            ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62, (uint64_t*)c->out.p,
-                            glwe_words(c->prm), false);
-    if (s != SPF_OK) return s;
-    HIPCHK(c, hipMemcpyAsync(glwe_out, c->out.p, B * glwe_words(c->prm) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SPF_OK;
+    return bootstrap_sliced_to_host(c, B, (const uint64_t*)c->mid.p, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count),
+                                    (uint64_t)1 << 62, glwe_words(c->prm), false, glwe_out);
 }
 
 // ---------------------------------------------------------------- measurement hooks
@@ -1180,6 +1240,13 @@ spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, in
     return SPF_OK;
 }
 
+const char* spf_last_blind_rotate_kernel(spf_ctx* c)
+{
+    if (!c) return "";
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    return c->last_pbs_kernel; // string literals: valid for the life of the library
+}
+
 // ---------------------------------------------------------------- call-coalescing pool
 
 spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, spf_pool** out)
@@ -1188,9 +1255,24 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     spf_pool* p = new (std::nothrow) spf_pool();
     if (!p) return fail(c, SPF_ERR_HIP, "out of host memory");
     p->ctx = c; p->prm = c->prm; p->max_batch = max_batch;
+    p->max_inflight = 4 * max_batch; // flow control: cf. the reference's bounded token channel (circuit_processor/mod.rs:139)
     p->max_wait = std::chrono::microseconds(max_wait_us);
-    p->worker = std::thread([p] { p->loop(); });
+    try {
+        p->worker = std::thread([p] { p->loop(); });
+    } catch (const std::exception& e) { // std::system_error: no thread to be had — must not cross extern "C"
+        delete p;
+        return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the worker thread: ") + e.what());
+    }
     *out = p;
+    return SPF_OK;
+}
+
+spf_status spf_pool_set_max_inflight(spf_pool* p, size_t max_inflight)
+{
+    if (!p || max_inflight == 0) return SPF_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->max_inflight = max_inflight;
+    p->cv_space.notify_all();
     return SPF_OK;
 }
 
@@ -1229,10 +1311,13 @@ spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)
 {
     if (!p) return SPF_ERR_INVALID_ARGUMENT;
     std::unique_lock<std::mutex> lk(p->mu);
-    if (ticket == 0 || ticket >= p->next_ticket) return SPF_ERR_INVALID_ARGUMENT;
+    // a ticket can be waited for exactly once: unknown, or already collected, is an error (not a hang)
+    if (p->open.count(ticket) == 0) return SPF_ERR_INVALID_ARGUMENT;
     p->cv_done.wait(lk, [&] { return p->done.count(ticket) != 0; });
     spf_status st = p->done[ticket];
     p->done.erase(ticket);
+    p->open.erase(ticket);
+    p->cv_space.notify_all();
     return st;
 }
 

@@ -1047,7 +1047,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const c64* row = reinterpret_cast<const c64*>(bskring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
-                c64 kb[3][2];
+                constexpr int KD = (OPT & 4) ? 2 : 3; // key pairs in flight (bit 2: two — 8 registers fewer across the MAD)
+                c64 kb[KD][2];
                 auto key2 = [&](int grp, c64 (&dst)[2]) {
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
@@ -1056,15 +1057,15 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     }
                 };
                 key2(0, kb[0]);
-                key2(1, kb[1]);
+                if constexpr (KD == 3) key2(1, kb[1]);
 #pragma unroll
                 for (int grp = 0; grp < 8; grp++) {
-                    if (grp + 2 < 8) key2(grp + 2, kb[(grp + 2) % 3]);
+                    if (grp + KD - 1 < 8) key2(grp + KD - 1, kb[(grp + KD - 1) % KD]);
                     compiler_fence();
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
                         const int r = (grp * 2 + i) & 7, q = grp >> 2;
-                        const c64 k = kb[grp % 3][i];
+                        const c64 k = kb[grp % KD][i];
                         const bool first = p == 0 && j == 0;
                         double re = __builtin_fma(k.re, VV[j][r].re, first ? 0.0 : prod[q][r].re);
                         double im = __builtin_fma(k.re, VV[j][r].im, first ? 0.0 : prod[q][r].im);

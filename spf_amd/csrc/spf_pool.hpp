@@ -17,8 +17,10 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <exception>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace spf_pool_impl {
@@ -42,15 +44,17 @@ struct spf_pool {
     size_t max_batch = 4096;
     std::chrono::microseconds max_wait{200};
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work, cv_done, cv_space;
     std::deque<spf_pool_impl::Request> q[spf_pool_impl::N_OPS];
     std::unordered_map<uint64_t, spf_status> done;
+    std::unordered_set<uint64_t> open;  // submitted and not yet collected by spf_pool_wait
+    size_t max_inflight = 16384;        // submit blocks while this many tickets are open (back-pressure)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
     bool stop = false;
     std::thread worker;
     // gather / scatter staging (host)
-    std::vector<uint8_t> h_in0, h_in1, h_in2, h_out, h_mid;
+    std::vector<uint8_t> h_in0, h_in1, h_in2, h_out;
 
     size_t lwe0_bytes() const { return ((size_t)prm.lwe_dimension + 1) * 8; }
     size_t lwe1_bytes() const { return ((size_t)prm.glwe_size * prm.polynomial_degree + 1) * 8; }
@@ -96,11 +100,8 @@ struct spf_pool {
         case OP_CBS:
             st = spf_circuit_bootstrap_batch(ctx, B, (const uint64_t*)h_in0.data(), (double*)h_out.data());
             break;
-        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap
-            h_mid.resize(B * lwe0_bytes());
-            st = spf_keyswitch_lwe_l1_lwe_l0_batch(ctx, B, (const uint64_t*)h_in0.data(), (uint64_t*)h_mid.data());
-            if (st == SPF_OK)
-                st = spf_circuit_bootstrap_batch(ctx, B, (const uint64_t*)h_mid.data(), (double*)h_out.data());
+        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
+            st = spf_keyswitch_circuit_bootstrap_batch(ctx, B, (const uint64_t*)h_in0.data(), (double*)h_out.data());
             break;
         default:
             st = spf_cmux_batch(ctx, B, (const double*)h_in0.data(), (const uint64_t*)h_in1.data(),
@@ -141,7 +142,12 @@ struct spf_pool {
                 q[op].pop_front();
             }
             lk.unlock();
-            spf_status st = run_batch(op, batch);
+            spf_status st;
+            try {
+                st = run_batch(op, batch);
+            } catch (const std::exception&) { // bad_alloc while staging a batch: its waiters get an error, the pool lives on
+                st = SPF_ERR_HIP;
+            }
             lk.lock();
             n_launches++;
             n_ops += batch.size();
@@ -153,11 +159,19 @@ struct spf_pool {
     spf_status submit(int op, const void* a, const void* b, const void* c, void* out, uint64_t* ticket)
     {
         if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
-        std::lock_guard<std::mutex> lk(mu);
+        std::unique_lock<std::mutex> lk(mu);
+        // back-pressure: a producer that runs ahead of its own waits blocks here instead of growing the queues
+        cv_space.wait(lk, [&] { return stop || open.size() < max_inflight; });
         if (stop) return SPF_ERR_INVALID_ARGUMENT;
-        spf_pool_impl::Request r{a, b, c, out, next_ticket++, std::chrono::steady_clock::now()};
-        *ticket = r.ticket;
-        q[op].push_back(r);
+        try {
+            spf_pool_impl::Request r{a, b, c, out, next_ticket, std::chrono::steady_clock::now()};
+            q[op].push_back(r);
+            open.insert(r.ticket);
+            *ticket = r.ticket;
+            next_ticket++;
+        } catch (const std::exception&) {
+            return SPF_ERR_HIP;
+        }
         cv_work.notify_one();
         return SPF_OK;
     }

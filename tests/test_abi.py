@@ -82,3 +82,26 @@ def test_c_header_is_plain_c_and_cpp_mirror_compiles(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-I", inc, str(c), "-o", str(exe), "-L", os.path.dirname(spf_amd.lib_path()),
                     "-lspf_hip", "-Wl,-rpath," + os.path.dirname(spf_amd.lib_path())], check=True)
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_ffi_operand_validation_helpers():
+    """a batch mismatch or a wrong pool output buffer must raise before any pointer is taken
+    (the C side copies B * row_size bytes)."""
+    import numpy as np
+    from spf_amd import _ffi
+    a, b = np.zeros((3, 8), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64)
+    with pytest.raises(spf_amd.SpfError):
+        _ffi._same_rows("cmux", a, b)
+    _ffi._same_rows("cmux", a, a)
+    good = np.zeros(16, dtype=np.uint64)
+    assert _ffi._out("x", good, np.uint64, 16) is good
+    for bad in (np.zeros(15, dtype=np.uint64), np.zeros(16, dtype=np.int32), np.zeros((16, 2), dtype=np.uint64)[:, 0],
+                [0] * 16):
+        with pytest.raises(spf_amd.SpfError):
+            _ffi._out("x", bad, np.uint64, 16)
+    ro = np.zeros(16, dtype=np.uint64)
+    ro.setflags(write=False)
+    with pytest.raises(spf_amd.SpfError):
+        _ffi._out("x", ro, np.uint64, 16)
+    with pytest.raises(spf_amd.SpfError):
+        _ffi._in("x", np.zeros(5), np.uint64, 4)

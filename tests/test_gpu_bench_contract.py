@@ -27,7 +27,13 @@ def test_bench_line_has_the_contract_fields():
     roof = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] < 1.0
+    # "fp64": the f64 work runs on the VALU, whose peak equals the MFMA-f64 peak (VERDICT r1 asked for the relabel)
+    assert roof["bound"] in ("hbm", "mfma", "fp64") and 0.0 < roof["frac"] < 1.0
+    # the kernel named is the one that ran: 512 ciphertexts take the paired latency shape, not the throughput kernel
+    assert roof["kernel"].startswith("blind_rotate2w_kernel"), roof["kernel"]
+    for leg in ("gate", "cmux", "circuit_bootstrap", "add32", "pcie_inclusive"):
+        assert isinstance(d.get(leg), dict), leg
+    assert d["pcie_inclusive"]["same_words_as_device_path"] is True
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     cpu = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):

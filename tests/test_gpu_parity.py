@@ -276,3 +276,19 @@ def test_every_bootstrap_shape_with_luts_and_sample_extract(small):
         else:
             assert np.array_equal(g, g_ref), size
             assert np.array_equal(u, u_ref), size
+
+
+def test_host_pointer_path_slices_equal_unsliced(small):
+    """The host-pointer bootstrap copies finished slices (one round of the chip each) out under the next
+    slice's kernel; a batch of several slices plus a ragged rest must equal the same ciphertexts sent in
+    single-slice calls.  (VERDICT r1 task 5.)"""
+    ks, eng = small
+    B = 2 * 1024 + 333
+    lwe = random_lwe_batch(0x511CE, B, SMALL_N)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    ref = np.concatenate([eng.circuit_bootstrap_pbs(lwe[i:i + 700]) for i in range(0, B, 700)])
+    assert np.array_equal(got, ref)
+    luts = random_glwe(79, B, ks.params.glwe_len)
+    g = eng.generalized_pbs(lwe, luts, 1, 1, 777)
+    gref = np.concatenate([eng.generalized_pbs(lwe[i:i + 700], luts[i:i + 700], 1, 1, 777) for i in range(0, B, 700)])
+    assert np.array_equal(g, gref)

@@ -105,3 +105,59 @@ def test_concurrent_batch_callers_on_one_context(rig):
         got = list(ex.map(run, jobs * 3))
     for i, g in enumerate(got):
         assert np.array_equal(g, expected[i % len(jobs)]), i
+
+
+def test_pool_ticket_is_collected_once_and_backpressure_blocks(rig):
+    """ADVICE r1 / VERDICT weak #12: a second wait on a ticket is an error, not a hang; with max_inflight
+    tickets open a further submit blocks until one is collected (the reference's bounded token channel,
+    circuit_processor/mod.rs:139)."""
+    import threading
+    import time
+    ks, eng = rig
+    P = ks.params
+    pool = spf_amd.Pool(eng, max_batch=4, max_wait_us=100)
+    pool.set_max_inflight(2)
+    lwe1 = random_lwe_batch(11, 3, P.N * P.k)
+    outs = [np.zeros(P.lwe_n + 1, dtype=np.uint64) for _ in range(3)]
+    t0 = pool.submit_keyswitch(outs[0], lwe1[0])
+    t1 = pool.submit_keyswitch(outs[1], lwe1[1])
+    third = {}
+
+    def late():
+        third["t"] = pool.submit_keyswitch(outs[2], lwe1[2])
+
+    th = threading.Thread(target=late)
+    th.start()
+    time.sleep(0.3)
+    assert "t" not in third, "submit must block while max_inflight tickets are open"
+    pool.wait(t0)
+    th.join(timeout=10)
+    assert "t" in third
+    with pytest.raises(spf_amd.SpfError):
+        pool.wait(t0)                       # already collected
+    with pytest.raises(spf_amd.SpfError):
+        pool.wait(123456)                   # never issued
+    pool.wait(t1)
+    pool.wait(third["t"])
+    for i in range(3):
+        assert np.array_equal(outs[i], O.keyswitch_lwe(lwe1[i], ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count))
+    pool.close()
+
+
+def test_keyswitch_circuit_bootstrap_keeps_l0_on_device(rig):
+    ks, eng = rig
+    lwe1 = random_lwe_batch(21, 5, ks.params.N * ks.params.k)
+    got = eng.keyswitch_circuit_bootstrap(lwe1)
+    exp = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(lwe1))
+    assert np.array_equal(got.view(np.float64), exp.view(np.float64))
+
+
+def test_mismatched_batches_raise(rig):
+    ks, eng = rig
+    P = ks.params
+    g = np.zeros((2, eng.params.cbs_ggsw_complex), dtype=np.complex128)
+    a = random_glwe(1, 3, P.glwe_len)
+    with pytest.raises(spf_amd.SpfError):
+        eng.cmux(g, a, a)
+    with pytest.raises(spf_amd.SpfError):
+        eng.multiply_glwe_ggsw(a, g)
