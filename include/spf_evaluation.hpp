@@ -62,6 +62,11 @@ class Evaluation {
     Evaluation& operator=(const Evaluation&) = delete;
     ~Evaluation() { spf_destroy(ctx_); }
 
+    // Evaluation::l1ggsw_zero / l1ggsw_one (:254-262): the circuit bootstraps of the trivial L0 LWE of 0 / 1 that
+    // Evaluation::new precomputes (:161-197); here made on the GPU at first use and cached in HBM per key set
+    void l1ggsw_zero(double* ggsw_fft_out) const { check(spf_l1ggsw_constant(ctx_, 0, ggsw_fft_out), ctx_); }
+    void l1ggsw_one(double* ggsw_fft_out) const { check(spf_l1ggsw_constant(ctx_, 1, ggsw_fft_out), ctx_); }
+
     const spf_params& params() const { return params_; }
     spf_ctx* raw() const { return ctx_; }
 

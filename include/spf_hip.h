@@ -301,7 +301,9 @@ spf_status spf_graph_create(spf_ctx *ctx, spf_graph **out);
 void spf_graph_destroy(spf_graph *graph);
 /* FheOp::Input{Lwe0,Lwe1,Glwe1,Ggsw1,Glev1} */
 spf_status spf_graph_add_input(spf_graph *graph, spf_value_kind kind, const void *host, uint32_t *node);
-/* FheOp::{Zero,One}{Lwe0,Glwe1}: trivial encryption of a bit (also LWE1) */
+/* FheOp::{Zero,One}{Lwe0,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116; also LWE1): trivial encryption of a bit;
+ * the GGSW constants are the context's circuit bootstraps of the trivial L0 LWE (Evaluation::l1ggsw_zero /
+ * l1ggsw_one, crypto/evaluation.rs:161-197, 254-262) and need the bootstrap, automorphism and scheme-switch keys */
 spf_status spf_graph_add_trivial(spf_graph *graph, spf_value_kind kind, uint64_t bit, uint32_t *node);
 spf_status spf_graph_add_op(spf_graph *graph, spf_graph_op op, const uint32_t *inputs, size_t n_inputs,
                             uint64_t param, uint32_t *node);
@@ -330,6 +332,22 @@ spf_status spf_last_kernel_ms(spf_ctx *ctx, const char *kernel /* "pbs" | "keysw
 /* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
  * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
  * shape).  For measurement records; never NULL. */
+/* `generate_lut` (sunscreen_tfhe ops/bootstrapping/programmable_bootstrapping.rs:129-185) for
+ * `programmable_bootstrap_univariate`: map_tables[f * 2^bits + x] = f(x) for n_maps functions over a
+ * plaintext space of 2^bits values (the reference takes closures; a table is their C form).  Writes the trivial
+ * GLWE (zero mask, body = the rotated, half-negated table polynomial), (k+1)*N words.  No GPU involved; ctx-free.
+ * A value >= 2^bits is SPF_ERR_INVALID_ARGUMENT (the reference asserts). */
+spf_status spf_generate_lut(const spf_params *params, const uint64_t *map_tables, size_t n_maps,
+                            uint32_t plaintext_bits, uint64_t *lut_glwe_out);
+/* `safe_bincode::deserialize::<ComputeKey>` + upload (parasol_runtime/src/safe_bincode.rs:16-28,
+ * crypto/keys.rs:294-318): `bytes` is what the Rust side wrote with bincode DefaultOptions +
+ * with_fixint_encoding — four sequences (u64 LE count, elements) in the order bs_key, ks_key, ss_key, auto_key.
+ * Every count is checked against the context's parameters before anything is loaded; trailing bytes are allowed. */
+spf_status spf_load_compute_key_bincode(spf_ctx *ctx, const uint8_t *bytes, size_t len);
+/* `Evaluation::l1ggsw_zero()` / `l1ggsw_one()` (crypto/evaluation.rs:254-262): the GGSW (cbs radix, FFT domain,
+ * (k+1)*l_cbs*(k+1)*N/2 complex) that `Evaluation::new` obtains by circuit-bootstrapping the trivial L0 LWE of
+ * the bit (:161-197).  Computed on first use after the keys were (re)loaded, cached in HBM. */
+spf_status spf_l1ggsw_constant(spf_ctx *ctx, int bit, double *ggsw_fft_out);
 const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
 
 /* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */

@@ -101,6 +101,9 @@ SYMBOLS = [
     ("spf_set_timing", _I, [_P, _I]),
     ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
     ("spf_last_blind_rotate_kernel", C.c_char_p, [_P]),
+    ("spf_l1ggsw_constant", _I, [_P, _I, _P]),
+    ("spf_generate_lut", _I, [C.POINTER(_CParams), _P, _SZ, _U32, _P]),
+    ("spf_load_compute_key_bincode", _I, [_P, _P, _SZ]),
     ("spf_version", C.c_char_p, []),
 ]
 
@@ -158,6 +161,20 @@ def _in(what: str, a, dtype, words: int) -> np.ndarray:
     if a.size != words:
         raise SpfError(-2, f"{what}: input has {a.size} elements, expected {words}")
     return a
+
+
+def generate_lut(maps, plaintext_bits: int, params: Params = DEFAULT_128) -> np.ndarray:
+    """`generate_lut` (programmable_bootstrapping.rs:129-185) as the trivial GLWE `pbs_univariate` takes.
+    `maps`: callables x -> f(x) on [0, 2^plaintext_bits), or already tabulated rows.  Host only, no GPU."""
+    lib = load_library()
+    p = 1 << plaintext_bits
+    table = np.array([[m(x) for x in range(p)] if callable(m) else list(m) for m in maps], dtype=np.uint64).reshape(len(maps), p)
+    out = np.empty(params.glwe_words, dtype=np.uint64)
+    cp = _CParams(*[getattr(params, n) for n, _ in _CParams._fields_])
+    st = lib.spf_generate_lut(C.byref(cp), _ptr(table), len(maps), plaintext_bits, _ptr(out))
+    if st != 0:
+        raise SpfError(st, (lib.spf_last_error(None) or b"").decode())
+    return out
 
 
 class Engine:
@@ -389,6 +406,17 @@ class Engine:
     # -- measurement
     def set_timing(self, enabled: bool):
         self._ck(self._lib.spf_set_timing(self._h, 1 if enabled else 0))
+
+    def load_compute_key_bincode(self, blob: bytes):
+        """the bytes `bincode` wrote for a parasol_runtime::ComputeKey (safe_bincode.rs:16-28), all four keys"""
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        self._ck(self._lib.spf_load_compute_key_bincode(self._h, _ptr(buf), buf.size))
+
+    def l1ggsw_constant(self, bit: int) -> np.ndarray:
+        """Evaluation::l1ggsw_zero / l1ggsw_one: circuit bootstrap of the trivial L0 LWE of `bit` (cached per key set)"""
+        out = np.empty(self.params.cbs_ggsw_complex, dtype=np.complex128)
+        self._ck(self._lib.spf_l1ggsw_constant(self._h, int(bit), _ptr(out)))
+        return out
 
     def last_blind_rotate_kernel(self) -> str:
         return (self._lib.spf_last_blind_rotate_kernel(self._h) or b"").decode()

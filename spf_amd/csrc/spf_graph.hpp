@@ -243,7 +243,14 @@ inline spf_status run(spf_graph* g)
     for (const auto& n : g->nodes) {
         if (n.op == -1) {
             std::memcpy(g->h_inputs.data() + n.off, n.host, g->value_bytes(n.kind));
-        } else if (n.op == -2) {
+        } else if (n.op == -2 && n.kind == SPF_VAL_GLEV1) {
+            // trivial_glev_l1_{zero,one} (crypto/encryption.rs:434-451 -> trivially_encrypt_glev_ciphertext,
+            // ops/encryption/glev_encryption.rs:23-80): GLWE j = zero mask, body = bit * q / B^(j+1) at coefficient 0
+            uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
+            std::memset(v, 0, g->value_bytes(n.kind));
+            for (size_t j = 0; j < g->prm.cbs_radix_count; j++)
+                v[j * (k + 1) * N + k * N] = (n.param & 1) << (64 - g->prm.cbs_radix_log * (j + 1));
+        } else if (n.op == -2 && n.kind != SPF_VAL_GGSW1) {
             // trivial_lwe / trivial_glwe of a bit at one plaintext bit (crypto/encryption.rs:345-412):
             // zero mask, body (coefficient 0) = bit << 63
             uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
@@ -253,6 +260,15 @@ inline spf_status run(spf_graph* g)
         }
     }
     if (g->inputs_bytes) HIPCHK(c, hipMemcpyAsync(g->d_arena, g->h_inputs.data(), g->inputs_bytes, hipMemcpyHostToDevice, s));
+    // FheOp::{Zero,One}Ggsw1: the context's circuit-bootstrapped constants (Evaluation::l1ggsw_zero / _one), device to device
+    for (const auto& n : g->nodes)
+        if (n.op == -2 && n.kind == SPF_VAL_GGSW1) {
+            spf_status st = ensure_ggsw_constants(c);
+            if (st != SPF_OK) return st;
+            const size_t sw = g->value_bytes(SPF_VAL_GGSW1);
+            HIPCHK(c, hipMemcpyAsync(g->d_arena + n.off, (const char*)c->d_ggsw_const + (size_t)(n.param & 1) * sw, sw,
+                                     hipMemcpyDeviceToDevice, s));
+        }
     g->n_launches = 0;
     for (const auto& gr : g->groups) {
         OpInfo info{};
@@ -352,8 +368,8 @@ spf_status spf_graph_add_input(spf_graph* g, spf_value_kind kind, const void* ho
 spf_status spf_graph_add_trivial(spf_graph* g, spf_value_kind kind, uint64_t bit, uint32_t* node)
 {
     if (!g) return SPF_ERR_INVALID_ARGUMENT;
-    if (!node || (kind != SPF_VAL_LWE0 && kind != SPF_VAL_LWE1 && kind != SPF_VAL_GLWE1) || bit > 1)
-        return fail(g->ctx, SPF_ERR_INVALID_ARGUMENT, "graph constant: LWE0 / LWE1 / GLWE1 of bit 0 or 1");
+    if (!node || g->value_bytes(kind) == 0 || bit > 1)
+        return fail(g->ctx, SPF_ERR_INVALID_ARGUMENT, "graph constant: LWE0 / LWE1 / GLWE1 / GGSW1 / GLEV1 of bit 0 or 1");
     spf_graph::Node n{};
     n.op = -2; n.kind = kind; n.param = bit;
     *node = (uint32_t)g->nodes.size();

@@ -65,6 +65,8 @@ struct spf_ctx {
     size_t ssk_bytes = 0;
     bool ssk_ready = false;
     DevBuf cbs_glwe, cbs_glev;      // circuit-bootstrap intermediates (lo-noise GLWE, GLEV)
+    double* d_ggsw_const = nullptr; // l1ggsw_zero | l1ggsw_one (Evaluation::new, evaluation.rs:161-197), built on first use
+    bool ggsw_const_ready = false;  // reset whenever a key of the circuit bootstrap changes
     int n_cu = 256;                // compute units of the device (picks the blind-rotation shape)
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
     const char* last_pbs_kernel = "";  // name of the blind-rotation kernel the last launch used
@@ -494,6 +496,7 @@ void spf_destroy(spf_ctx* c)
                     c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->d_ggsw_const) (void)hipFree(c->d_ggsw_const);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
     delete c;
@@ -531,14 +534,14 @@ spf_status spf_key_blob_commit(spf_ctx* c, int which)
     if (!c) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null context");
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device)); // the byte planes are allocated and built on THIS context's GPU
-    if (which == 0 && c->d_bsk) c->bsk_ready = true;
+    if (which == 0 && c->d_bsk) c->bsk_ready = true, c->ggsw_const_ready = false;
     else if (which == 1 && c->d_ksk) {
         spf_status st = build_ks_planes(c);
         if (st != SPF_OK) return st;
         c->ksk_ready = true;
     }
-    else if (which == 2 && c->d_ak) c->ak_ready = true;
-    else if (which == 3 && c->d_ssk) c->ssk_ready = true;
+    else if (which == 2 && c->d_ak) c->ak_ready = true, c->ggsw_const_ready = false;
+    else if (which == 3 && c->d_ssk) c->ssk_ready = true, c->ggsw_const_ready = false;
     else return fail(c, SPF_ERR_INVALID_ARGUMENT, "blob not allocated");
     return SPF_OK;
 }
@@ -554,7 +557,7 @@ spf_status spf_load_bootstrap_key(spf_ctx* c, const double* bsk_fft, size_t n_co
     if (s != SPF_OK) return s;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, bsk_fft, bytes, hipMemcpyHostToDevice));
-    c->bsk_ready = true;
+    c->bsk_ready = true, c->ggsw_const_ready = false;
     return SPF_OK;
 }
 
@@ -1092,6 +1095,7 @@ static spf_status load_fft_key(spf_ctx* c, int which, const double* src, size_t 
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     *ready = true;
+    c->ggsw_const_ready = false;
     return SPF_OK;
 }
 
@@ -1237,6 +1241,102 @@ spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, in
     v->clear();
     *avg_ms = n ? total / n : 0.0;
     *launches = n;
+    return SPF_OK;
+}
+
+// ---------------------------------------------------------------- host helpers without a GPU call
+
+// `generate_lut` (ops/bootstrapping/programmable_bootstrapping.rs:129-185) as the trivial GLWE that
+// `programmable_bootstrap_univariate` takes (zero mask, body = the table polynomial).  Closed form of the
+// reference's fill / negate / rotate: with p = 2^bits inputs, stride = N / p coefficients per input and
+// h = stride / 2, body[i] = sign * (f_id(x) << (64 - bits)) for m = (i + h) mod N, x = m / stride,
+// id = (m % stride) % 2^ceil(log2 #maps) (0 when id >= #maps), sign = -1 for m < h.
+spf_status spf_generate_lut(const spf_params* prm, const uint64_t* map_tables, size_t n_maps, uint32_t plaintext_bits,
+                            uint64_t* lut_glwe_out)
+{
+    if (!prm || !map_tables || !lut_glwe_out || n_maps == 0)
+        return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_generate_lut: null argument or no map");
+    const size_t N = prm->polynomial_degree, k = prm->glwe_size;
+    if (plaintext_bits == 0 || plaintext_bits >= 64 || ((size_t)1 << plaintext_bits) > N)
+        return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_generate_lut: needs 1 <= plaintext_bits and 2^plaintext_bits <= N");
+    const size_t p = (size_t)1 << plaintext_bits, stride = N / p, h = stride / 2;
+    size_t ceil_v = 1;
+    while (ceil_v < n_maps) ceil_v <<= 1;
+    for (size_t i = 0; i < n_maps * p; i++)
+        if (map_tables[i] >= p) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_generate_lut: a map value is not below 2^plaintext_bits");
+    std::memset(lut_glwe_out, 0, k * N * sizeof(uint64_t));
+    uint64_t* body = lut_glwe_out + k * N;
+    for (size_t i = 0; i < N; i++) {
+        const size_t m = (i + h) % N, x = m / stride, id = (m % stride) % ceil_v;
+        const uint64_t v = id < n_maps ? map_tables[id * p + x] << (64 - plaintext_bits) : 0;
+        body[i] = m < h ? (uint64_t)0 - v : v;
+    }
+    return SPF_OK;
+}
+
+// `safe_bincode::deserialize::<ComputeKey>` (parasol_runtime/src/safe_bincode.rs:16-28, crypto/keys.rs:294-318):
+// bincode DefaultOptions + fixint: per field a u64 little-endian element count, then the elements
+// (Complex<f64> = two LE f64, Torus<u64> = one LE u64); fields in declaration order bs_key, ks_key, ss_key,
+// auto_key; trailing bytes allowed; every count must be exactly what the parameters need (the reference
+// bounds the read by GetSize and then runs check_is_valid) — checked for ALL fields before any key is touched.
+spf_status spf_load_compute_key_bincode(spf_ctx* c, const uint8_t* bytes, size_t len)
+{
+    if (!c || !bytes) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    struct Field { const char* name; size_t want, elem; const uint8_t* data; };
+    Field f[4] = {{"bs_key", (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count), 16, nullptr},
+                  {"ks_key", (size_t)c->prm.glwe_size * c->prm.polynomial_degree * c->prm.ks_radix_count * lwe0_words(c->prm), 8, nullptr},
+                  {"ss_key", ssk_complex(c->prm), 16, nullptr},
+                  {"auto_key", ak_complex(c->prm), 16, nullptr}};
+    size_t off = 0;
+    for (auto& x : f) {
+        if (len - off < 8) return fail(c, SPF_ERR_INVALID_ARGUMENT, std::string("ComputeKey: truncated before the length of ") + x.name);
+        uint64_t n = 0;
+        for (int b = 7; b >= 0; b--) n = (n << 8) | bytes[off + b]; // little-endian, any alignment
+        off += 8;
+        if (n != x.want)
+            return fail(c, SPF_ERR_INVALID_ARGUMENT, std::string("ComputeKey: ") + x.name + " has " + std::to_string(n) +
+                                                         " elements, the parameters need " + std::to_string(x.want));
+        if ((len - off) / x.elem < x.want) return fail(c, SPF_ERR_INVALID_ARGUMENT, std::string("ComputeKey: truncated inside ") + x.name);
+        x.data = bytes + off;
+        off += x.want * x.elem;
+    }
+    // the loaders only memcpy from these (possibly unaligned) pointers; x86-64 little-endian host = wire order
+    spf_status st = spf_load_bootstrap_key(c, reinterpret_cast<const double*>(f[0].data), f[0].want);
+    if (st == SPF_OK) st = spf_load_keyswitch_key(c, reinterpret_cast<const uint64_t*>(f[1].data), f[1].want);
+    if (st == SPF_OK) st = spf_load_scheme_switch_key(c, reinterpret_cast<const double*>(f[2].data), f[2].want);
+    if (st == SPF_OK) st = spf_load_automorphism_key(c, reinterpret_cast<const double*>(f[3].data), f[3].want);
+    return st;
+}
+
+// l1ggsw_zero / l1ggsw_one as `Evaluation::new` makes them (crypto/evaluation.rs:161-197): the circuit bootstrap
+// of the trivial level-0 LWE of the bit, under the loaded keys.  Built once per key set, kept in HBM.
+static spf_status ensure_ggsw_constants(spf_ctx* c)
+{
+    if (c->ggsw_const_ready) return SPF_OK;
+    const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16, lw = lwe0_words(c->prm);
+    if (!c->d_ggsw_const) HIPCHK(c, hipMalloc((void**)&c->d_ggsw_const, 2 * sw));
+    std::vector<uint64_t> triv(2 * lw, 0);
+    triv[2 * lw - 1] = (uint64_t)1 << 63; // trivial_lwe(1, l0, 1 plaintext bit): zero mask, body = 1 << 63
+    spf_status st = ensure(c, c->aux, 2 * lw * 8);
+    if (st != SPF_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(c->aux.p, triv.data(), 2 * lw * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // `triv` goes out of scope
+    st = spf_circuit_bootstrap_dev(c, c->stream, 2, (const uint64_t*)c->aux.p, c->d_ggsw_const);
+    if (st != SPF_OK) return st;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ggsw_const_ready = true;
+    return SPF_OK;
+}
+
+spf_status spf_l1ggsw_constant(spf_ctx* c, int bit, double* ggsw_fft_out)
+{
+    if (!c || !ggsw_fft_out || (bit != 0 && bit != 1)) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument or bit not 0/1");
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    spf_status st = ensure_ggsw_constants(c);
+    if (st != SPF_OK) return st;
+    const size_t sw = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * 16;
+    HIPCHK(c, hipMemcpy(ggsw_fft_out, (const char*)c->d_ggsw_const + (size_t)bit * sw, sw, hipMemcpyDeviceToHost));
     return SPF_OK;
 }
 

@@ -29,8 +29,8 @@ class ComputeKey:
 
 class Evaluation:
     def __init__(self, compute_key: ComputeKey, params: Params = DEFAULT_128, device: int = 0):
-        # Evaluation::new (evaluation.rs:161-197) minus the two CBS runs that precompute
-        # l1ggsw_zero/one, which need the trace / scheme-switch tail.
+        # Evaluation::new (evaluation.rs:161-197): load the keys; the two circuit bootstraps that give
+        # l1ggsw_zero / l1ggsw_one run on the GPU at first use (they need all of bs / auto / ss keys)
         self.params = params
         self.engine = Engine(params, device)
         self.engine.load_bootstrap_key(compute_key.bs_key)
@@ -40,6 +40,13 @@ class Evaluation:
             self.engine.load_automorphism_key(compute_key.auto_key)
         if compute_key.ss_key is not None:
             self.engine.load_scheme_switch_key(compute_key.ss_key)
+
+    # Evaluation::l1ggsw_zero / l1ggsw_one (evaluation.rs:254-262)
+    def l1ggsw_zero(self) -> np.ndarray:
+        return self.engine.l1ggsw_constant(0)
+
+    def l1ggsw_one(self) -> np.ndarray:
+        return self.engine.l1ggsw_constant(1)
 
     @staticmethod
     def _store(output: np.ndarray, result: np.ndarray):

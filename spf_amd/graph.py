@@ -76,7 +76,7 @@ class FheCircuit:
         self._eng._ck(self._lib.spf_graph_add_input(self._g, int(kind), _ptr(a), C.byref(node)))
         return node.value
 
-    # FheOp::{Zero,One}{Lwe0,Glwe1}
+    # FheOp::{Zero,One}{Lwe0,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116)
     def add_trivial(self, kind: ValueKind, bit: int) -> int:
         node = C.c_uint32()
         self._eng._ck(self._lib.spf_graph_add_trivial(self._g, int(kind), bit, C.byref(node)))

@@ -105,3 +105,16 @@ def test_ffi_operand_validation_helpers():
         _ffi._out("x", ro, np.uint64, 16)
     with pytest.raises(spf_amd.SpfError):
         _ffi._in("x", np.zeros(5), np.uint64, 4)
+
+
+def test_generate_lut_matches_the_oracle_and_rejects_out_of_range_maps():
+    """a4': `generate_lut` (programmable_bootstrapping.rs:129-185) on the product side, host only."""
+    import numpy as np
+    import oracle as O
+    P = O.DEFAULT_128
+    for bits, fns in [(1, [lambda x: (x + 1) % 2]), (3, [lambda x: (x + 3) % 8]), (4, [lambda x: (5 * x + 1) % 16]),
+                      (2, [lambda x: x, lambda x: (3 * x) % 4, lambda x: (x + 1) % 4])]:
+        got = spf_amd.generate_lut(fns, bits)
+        assert np.array_equal(got, O.trivial_lut_glwe(O.generate_lut(P.N, fns, bits), P)), (bits, len(fns))
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.generate_lut([lambda x: 8], 3)

@@ -125,7 +125,7 @@ def test_malformed_graphs_are_rejected_when_built(rig):
     with pytest.raises(spf_amd.SpfError):
         g.add_input(ValueKind.LWE0, np.zeros(3, dtype=np.uint64))
     with pytest.raises(spf_amd.SpfError):
-        g.add_trivial(ValueKind.GGSW1, 1)
+        g.add_trivial(ValueKind.GGSW1, 2)                     # a constant is a bit
     cb = g.add_op(FheOp.CircuitBootstrap, [l0])               # the graph is still usable
     out = g.add_output(cb, ValueKind.GGSW1)
     g.run()
@@ -183,3 +183,47 @@ def test_encrypted_add_32_as_one_graph():
     assert got == (a + b) & 0xFFFFFFFF
     assert O.decode(int(O.decrypt_glwe_raw(carry_out, ks.glwe_sk, P.N, P.k)[0]), 1) == ((a + b) >> 32) & 1
     g.close()
+
+
+def test_graph_ggsw_and_glev_constants(full_rig=None):
+    """FheOp::{Zero,One}Ggsw1 / {Zero,One}Glev1 (fhe_circuit.rs:96-116): the GGSW constants are the context's
+    circuit bootstraps of the trivial L0 LWE (Evaluation::new, evaluation.rs:161-197), the GLEV ones the
+    trivial gadget encryptions (encryption.rs:434-451).  Checked against the oracle and by what they select."""
+    import oracle as O
+    from tests.util import keyset, random_glwe, to_engine_params
+    ks = keyset(0x5EED0001, 12)
+    P = ks.params
+    r = O.Rng(0x7A11)
+    eng = spf_amd.Engine(to_engine_params(P))
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    triv = [np.zeros(P.lwe_n + 1, dtype=np.uint64) for _ in range(2)]
+    triv[1][-1] = np.uint64(1 << 63)
+    for bit in (0, 1):
+        exp = O.circuit_bootstrap(triv[bit], ks.bsk_fft, ak, ssk, P)
+        assert np.array_equal(eng.l1ggsw_constant(bit).view(np.float64), np.asarray(exp).view(np.float64)), bit
+    a, b = random_glwe(5, 1, P.glwe_len)[0], random_glwe(6, 1, P.glwe_len)[0]
+    g = spf_amd.FheCircuit(eng)
+    na, nb = g.add_input(ValueKind.GLWE1, a), g.add_input(ValueKind.GLWE1, b)
+    outs = []
+    for bit in (0, 1):
+        sel = g.add_trivial(ValueKind.GGSW1, bit)
+        outs.append(g.add_output(g.add_op(FheOp.CMux, [sel, na, nb]), ValueKind.GLWE1))
+        glev = g.add_trivial(ValueKind.GLEV1, bit)
+        outs.append(g.add_output(g.add_op(FheOp.SchemeSwitch, [glev]), ValueKind.GGSW1))
+    g.run()
+    for bit in (0, 1):
+        ggsw = eng.l1ggsw_constant(bit)
+        assert np.array_equal(outs[2 * bit], eng.cmux(ggsw[None], a[None], b[None])[0])
+        glev = np.zeros((P.cbs_count, 2, P.N), dtype=np.uint64)
+        for j in range(P.cbs_count):
+            glev[j, 1, 0] = np.uint64(bit << (64 - P.cbs_radix_log * (j + 1)))
+        exp = O.scheme_switch_fft(glev.reshape(-1), ssk, P)
+        assert np.array_equal(outs[2 * bit + 1].view(np.float64), np.asarray(exp).view(np.float64)), bit
+    g.close()
+    # keys loaded again => constants are rebuilt (a different key must not serve stale constants)
+    eng.load_scheme_switch_key(ssk)
+    assert np.array_equal(eng.l1ggsw_constant(1).view(np.float64),
+                          np.asarray(O.circuit_bootstrap(triv[1], ks.bsk_fft, ak, ssk, P)).view(np.float64))

@@ -41,3 +41,37 @@ def test_size_guards():
         parse_compute_key(buf[: len(buf) // 2], P)           # truncated
     with pytest.raises(KeyFormatError):
         parse_compute_key(b"\x01\x00", P)
+
+
+@pytest.mark.gpu
+def test_bincode_loader_behind_the_c_abi_equals_field_by_field_loading():
+    """f4: `spf_load_compute_key_bincode` (safe_bincode.rs:16-28): one blob -> all four keys; same gate output as
+    loading the fields one by one; wrong counts / truncation rejected before anything is touched."""
+    import struct
+    import oracle as O
+    import spf_amd
+    from spf_amd.keys import serialize_compute_key
+    from tests.util import keyset, random_lwe_batch, to_engine_params
+    ks = keyset(0x5EED0001, 12)
+    P = ks.params
+    r = O.Rng(0x7A11)
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    blob = serialize_compute_key(spf_amd.ComputeKey(bs_key=ks.bsk_fft, ks_key=ks.ksk, ss_key=ssk, auto_key=ak))
+    ref = spf_amd.Engine(to_engine_params(P))
+    ref.load_bootstrap_key(ks.bsk_fft)
+    ref.load_keyswitch_key(ks.ksk)
+    ref.load_automorphism_key(ak)
+    ref.load_scheme_switch_key(ssk)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_compute_key_bincode(blob + b"trailing bytes are allowed")
+    lwe1 = random_lwe_batch(3, 4, P.N * P.k)
+    assert np.array_equal(eng.keyswitch_circuit_bootstrap(lwe1).view(np.float64),
+                          ref.keyswitch_circuit_bootstrap(lwe1).view(np.float64))
+    bad = bytearray(blob)
+    bad[0:8] = struct.pack("<Q", ks.bsk_fft.size + 1)
+    fresh = spf_amd.Engine(to_engine_params(P))
+    for broken in (bytes(bad), blob[:-9], blob[:4]):
+        with pytest.raises(spf_amd.SpfError):
+            fresh.load_compute_key_bincode(broken)
+    with pytest.raises(spf_amd.SpfError):           # nothing was loaded by the failed attempts
+        fresh.keyswitch_circuit_bootstrap(lwe1)
