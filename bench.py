@@ -222,6 +222,12 @@ def main() -> int:
         step()
         torch.cuda.synchronize()
 
+    mul8 = None
+    if extras:
+        mul8 = _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch)
+        step()
+        torch.cuda.synchronize()
+
     cmux = None
     if args.with_cmux:
         # KeylessEvaluation::cmux over a batch: every ciphertext brings its own 256 KiB GGSW
@@ -355,10 +361,48 @@ def main() -> int:
             line["circuit_bootstrap"] = cbs
         if add32:
             line["add32"] = add32
+        if mul8:
+            line["mul8_gate_pool"] = mul8
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=8):
+    """BASELINE config 5's shape: a pool of independent multiplications through the reference's 8 x 8 multiplier
+    block (mux_circuits `unsigned_multiplier(8, 8)`: 3 228 CMUX in 126 levels + 16 bit conversions each), `per_gpu`
+    jobs per GPU (weak scaling), dealt to the ranks by spf_amd.gate_pool, each rank's jobs lowered into ONE gate
+    graph on its own GPU; synthetic ciphertexts (timing is value-independent; correctness of the same graph is
+    tests/test_gpu_multiply.py).  Reports whole-pool multiplications/s and gates/s."""
+    from spf_amd.gate_pool import lpt_shards, multiply_jobs_as_one_graph
+    from spf_amd.mux_circuits import parse_mux_circuit
+    path = os.path.join(ROOT, "tests", "golden", "mux_multiplier_n8_m8.bincode")
+    if not os.path.exists(path):
+        return None
+    circuit = parse_mux_circuit(open(path, "rb").read())
+    n_jobs = per_gpu * world
+    mine = lpt_shards([circuit.metrics()["mux_gates"]] * n_jobs, world)[rank]
+    rng = np.random.default_rng(0x8008 + rank)
+    cts = rng.integers(0, 1 << 64, size=(len(mine), 16, P.glwe_words), dtype=np.uint64)
+    g, _ = multiply_jobs_as_one_graph(eng, circuit, cts)
+    g.run()                       # plans, allocates, warms up
+    if world > 1:
+        dist.barrier()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.run()
+    dt = (time.perf_counter() - t0) / reps
+    st = g.stats()
+    g.close()
+    if world > 1:
+        dt = max_over_ranks(dt, dist, device=dev)
+    gates = n_jobs * (circuit.metrics()["mux_gates"] + 16)
+    return {"multiplications": n_jobs, "per_gpu": per_gpu, "ms_per_pool_run": round(dt * 1e3, 3),
+            "multiplications_per_s": round(n_jobs / dt, 2), "gates_per_s": round(gates / dt, 1),
+            "levels": st["levels"], "launches_per_rank": st["launches"],
+            "block": "mux_circuits unsigned_multiplier(8,8): 3228 CMUX, depth 126, 16 circuit bootstraps"}
 
 
 def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):

@@ -54,6 +54,12 @@ struct spf_graph {
     char* d_stage[2] = {nullptr, nullptr};
     void** d_ptrs = nullptr;
     uint32_t n_levels = 0, n_launches = 0;
+    // hipGraph of the planned launch sequence (everything between the input copy and the output copies; opt-in,
+    // SPF_GRAPH_CAPTURE=1): captured on the second run after planning (the first one sizes the context's scratch buffers),
+    // replayed afterwards; dropped when the graph is re-planned or a captured scratch buffer moved
+    hipGraphExec_t exec = nullptr;
+    uint64_t exec_epoch = 0;
+    uint32_t runs_since_plan = 0, captured_launches = 0;
 
     size_t value_bytes(int kind) const
     {
@@ -67,8 +73,15 @@ struct spf_graph {
         default: return 0;
         }
     }
+    void drop_exec()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
+    }
     void release()
     {
+        drop_exec();
+        runs_since_plan = 0;
         if (d_arena) (void)hipFree(d_arena);
         if (d_stage[0]) (void)hipFree(d_stage[0]);
         if (d_stage[1]) (void)hipFree(d_stage[1]);
@@ -226,45 +239,13 @@ inline spf_status plan(spf_graph* g)
     return SPF_OK;
 }
 
-inline spf_status run(spf_graph* g)
+// Everything a run puts on the stream between the input copy and the output copies: the GGSW constants
+// (device to device) and one launch per group.  No allocation, no synchronisation: capturable.
+inline spf_status enqueue(spf_graph* g, hipStream_t s)
 {
     spf_ctx* c = g->ctx;
-    // one graph at a time per context: the _dev calls below share the context's scratch buffers and
-    // stream, and a run must not interleave its launches with another run's
-    std::lock_guard<std::recursive_mutex> whole(c->mu);
-    if (!g->planned) {
-        spf_status st = plan(g);
-        if (st != SPF_OK) return st;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const size_t k = g->prm.glwe_size, N = g->prm.polynomial_degree;
-    // inputs: read the callers' buffers now (they may have changed since the last run)
-    for (const auto& n : g->nodes) {
-        if (n.op == -1) {
-            std::memcpy(g->h_inputs.data() + n.off, n.host, g->value_bytes(n.kind));
-        } else if (n.op == -2 && n.kind == SPF_VAL_GLEV1) {
-            // trivial_glev_l1_{zero,one} (crypto/encryption.rs:434-451 -> trivially_encrypt_glev_ciphertext,
-            // ops/encryption/glev_encryption.rs:23-80): GLWE j = zero mask, body = bit * q / B^(j+1) at coefficient 0
-            uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
-            std::memset(v, 0, g->value_bytes(n.kind));
-            for (size_t j = 0; j < g->prm.cbs_radix_count; j++)
-                v[j * (k + 1) * N + k * N] = (n.param & 1) << (64 - g->prm.cbs_radix_log * (j + 1));
-        } else if (n.op == -2 && n.kind != SPF_VAL_GGSW1) {
-            // trivial_lwe / trivial_glwe of a bit at one plaintext bit (crypto/encryption.rs:345-412):
-            // zero mask, body (coefficient 0) = bit << 63
-            uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
-            std::memset(v, 0, g->value_bytes(n.kind));
-            const size_t body = n.kind == SPF_VAL_LWE0 ? g->prm.lwe_dimension : k * N;
-            v[body] = (n.param & 1) << 63;
-        }
-    }
-    if (g->inputs_bytes) HIPCHK(c, hipMemcpyAsync(g->d_arena, g->h_inputs.data(), g->inputs_bytes, hipMemcpyHostToDevice, s));
-    // FheOp::{Zero,One}Ggsw1: the context's circuit-bootstrapped constants (Evaluation::l1ggsw_zero / _one), device to device
     for (const auto& n : g->nodes)
         if (n.op == -2 && n.kind == SPF_VAL_GGSW1) {
-            spf_status st = ensure_ggsw_constants(c);
-            if (st != SPF_OK) return st;
             const size_t sw = g->value_bytes(SPF_VAL_GGSW1);
             HIPCHK(c, hipMemcpyAsync(g->d_arena + n.off, (const char*)c->d_ggsw_const + (size_t)(n.param & 1) * sw, sw,
                                      hipMemcpyDeviceToDevice, s));
@@ -323,6 +304,83 @@ inline spf_status run(spf_graph* g)
         }
         if (st != SPF_OK) return st;
         g->n_launches++;
+    }
+    return SPF_OK;
+}
+
+inline spf_status run(spf_graph* g)
+{
+    spf_ctx* c = g->ctx;
+    // one graph at a time per context: the _dev calls below share the context's scratch buffers and
+    // stream, and a run must not interleave its launches with another run's
+    std::lock_guard<std::recursive_mutex> whole(c->mu);
+    if (!g->planned) {
+        spf_status st = plan(g);
+        if (st != SPF_OK) return st;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t k = g->prm.glwe_size, N = g->prm.polynomial_degree;
+    // inputs: read the callers' buffers now (they may have changed since the last run)
+    for (const auto& n : g->nodes) {
+        if (n.op == -1) {
+            std::memcpy(g->h_inputs.data() + n.off, n.host, g->value_bytes(n.kind));
+        } else if (n.op == -2 && n.kind == SPF_VAL_GLEV1) {
+            // trivial_glev_l1_{zero,one} (crypto/encryption.rs:434-451 -> trivially_encrypt_glev_ciphertext,
+            // ops/encryption/glev_encryption.rs:23-80): GLWE j = zero mask, body = bit * q / B^(j+1) at coefficient 0
+            uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
+            std::memset(v, 0, g->value_bytes(n.kind));
+            for (size_t j = 0; j < g->prm.cbs_radix_count; j++)
+                v[j * (k + 1) * N + k * N] = (n.param & 1) << (64 - g->prm.cbs_radix_log * (j + 1));
+        } else if (n.op == -2 && n.kind != SPF_VAL_GGSW1) {
+            // trivial_lwe / trivial_glwe of a bit at one plaintext bit (crypto/encryption.rs:345-412):
+            // zero mask, body (coefficient 0) = bit << 63
+            uint64_t* v = reinterpret_cast<uint64_t*>(g->h_inputs.data() + n.off);
+            std::memset(v, 0, g->value_bytes(n.kind));
+            const size_t body = n.kind == SPF_VAL_LWE0 ? g->prm.lwe_dimension : k * N;
+            v[body] = (n.param & 1) << 63;
+        }
+    }
+    if (g->inputs_bytes) HIPCHK(c, hipMemcpyAsync(g->d_arena, g->h_inputs.data(), g->inputs_bytes, hipMemcpyHostToDevice, s));
+    bool has_ggsw_const = false;
+    for (const auto& n : g->nodes) has_ggsw_const = has_ggsw_const || (n.op == -2 && n.kind == SPF_VAL_GGSW1);
+    if (has_ggsw_const) { // built (and synchronised) outside any capture
+        spf_status st = ensure_ggsw_constants(c);
+        if (st != SPF_OK) return st;
+    }
+    // Off unless SPF_GRAPH_CAPTURE=1: measured on MI355X / ROCm 7.2 the replay is SLOWER than enqueueing the ~100
+    // launches (32-bit addition 8.00 ms replayed vs 7.67 ms eager; 16 additions 24.8 vs 24.1 ms) — the launches
+    // are already back to back on one stream and hipGraphLaunch adds more than it removes.
+    static const bool capture_on = [] { const char* e = getenv("SPF_GRAPH_CAPTURE"); return e && e[0] == '1'; }();
+    g->runs_since_plan++;
+    if (g->exec && g->exec_epoch != c->buf_epoch) g->drop_exec(); // a scratch buffer moved since the capture
+    if (g->exec) {
+        HIPCHK(c, hipGraphLaunch(g->exec, s));
+        g->n_launches = g->captured_launches;
+    } else {
+        const bool capture = capture_on && !c->timing && g->runs_since_plan >= 2;
+        const uint64_t epoch0 = c->buf_epoch;
+        if (capture) HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        spf_status st = enqueue(g, s);
+        if (capture) {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (st == SPF_OK && e == hipSuccess && graph && epoch0 == c->buf_epoch &&
+                hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                g->exec_epoch = c->buf_epoch;
+                g->captured_launches = g->n_launches;
+            } else {
+                g->exec = nullptr;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            if (st != SPF_OK) return st;
+            if (g->exec) HIPCHK(c, hipGraphLaunch(g->exec, s));
+            else {                       // the capture did not take (a buffer grew, ...): run it plainly this time
+                st = enqueue(g, s);
+                if (st != SPF_OK) return st;
+            }
+        } else if (st != SPF_OK) return st;
     }
     for (const auto& o : g->outputs) {
         const auto& n = g->nodes[o.first];

@@ -69,6 +69,7 @@ struct spf_ctx {
     bool ggsw_const_ready = false;  // reset whenever a key of the circuit bootstrap changes
     int n_cu = 256;                // compute units of the device (picks the blind-rotation shape)
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
+    uint64_t buf_epoch = 0;            // bumped whenever a scratch buffer is reallocated (captured gate graphs hold their addresses)
     const char* last_pbs_kernel = "";  // name of the blind-rotation kernel the last launch used
     hipStream_t copy_stream = nullptr; // device-to-host copies of finished slices, under the next slice's kernel
     std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
@@ -148,6 +149,7 @@ uint32_t ceil_log2(uint32_t v)
 spf_status ensure(spf_ctx* c, DevBuf& b, size_t bytes)
 {
     if (b.cap >= bytes) return SPF_OK;
+    c->buf_epoch++;
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     HIPCHK(c, hipMalloc(&b.p, bytes));

@@ -1,0 +1,173 @@
+"""`mux_circuits::MuxCircuit` on the GPU gate-graph executor (BASELINE configs 3 and 5).
+
+The reference describes integer arithmetic as multiplexer trees over the input bits
+(mux_circuits/src/lib.rs:58-170: `MuxOp::{One, Zero, Mux, Variable(i), Output(i)}` joined by
+`MuxEdgeInfo::{Low, High, Select, Output}` edges) and lowers them into its `FheCircuit` with
+`FheCircuit::insert_mux_circuit` (parasol_runtime/src/fhe_circuit.rs:274-420): every `Mux` becomes an
+`FheOp::CMux` whose selector is the GGSW of an input bit, `One` / `Zero` become trivial GLWEs.  Its
+multiplier blocks are BDD-derived circuits shipped as bincode blobs
+(`mux_circuits::mul::unsigned_multiplier`, mux_circuits/src/mul.rs:62-69: `bincode::deserialize` of
+`data/multiplier-n8-m8`, `-n16-m16`), which this module reads:
+
+    bincode 1.x default options (fixed-width little-endian integers, u64 lengths, u32 enum variant indices)
+    of  struct MuxCircuit { graph: StableGraph<MuxOp, MuxEdgeInfo>, inputs: Vec<NodeIndex> }
+    with petgraph 0.7's serde form of a StableGraph:
+        nodes: Vec<MuxOp>                 (u64 n, then n x { u32 variant [, u32 payload for Variable / Output] })
+        node_holes: Vec<NodeIndex<u32>>   (u64 n, n x u32)
+        edge_property: enum               (u32; 1 = Directed)
+        edges: Vec<Option<(u32 source, u32 target, MuxEdgeInfo)>>   (u64 n, n x { u8 tag [, u32, u32, u32] })
+    inputs: u64 n, n x u32                (node index of Variable(i), in input order)
+
+No FHE happens here: this is graph plumbing over `spf_amd.FheCircuit` (and a plaintext evaluator that the
+tests use to pin the parser against integer multiplication).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+ONE, ZERO, MUX, VARIABLE, OUTPUT = 0, 1, 2, 3, 4      # MuxOp variant indices (declaration order, lib.rs:58-95)
+LOW, HIGH, SELECT, OUT_EDGE = 0, 1, 2, 3              # MuxEdgeInfo variant indices (lib.rs:99-111)
+
+
+class MuxFormatError(ValueError):
+    pass
+
+
+@dataclass
+class MuxCircuit:
+    ops: List[Tuple[int, Optional[int]]]               # (variant, payload) per node
+    low: List[int]                                     # per node: source of its Low / High / Select / Output edge, or -1
+    high: List[int]
+    select: List[int]
+    out_src: List[int]
+    inputs: List[int]                                  # node index of input i
+
+    @property
+    def n_inputs(self) -> int:
+        return len(self.inputs)
+
+    @property
+    def outputs(self) -> List[int]:
+        """node index of Output(i), by i"""
+        outs = sorted((p, i) for i, (v, p) in enumerate(self.ops) if v == OUTPUT)
+        return [i for _, i in outs]
+
+    def metrics(self):
+        """`MuxCircuit::metrics` (lib.rs:199-220)"""
+        return {"mux_gates": sum(v == MUX for v, _ in self.ops), "inputs": sum(v == VARIABLE for v, _ in self.ops),
+                "outputs": sum(v == OUTPUT for v, _ in self.ops)}
+
+    def topological_muxes(self) -> List[int]:
+        """Mux nodes, every one after the Mux nodes its Low / High edges come from (iterative DFS)."""
+        order, state = [], {}
+        for root in self.outputs:
+            stack = [(self.out_src[root], False)]
+            while stack:
+                n, done = stack.pop()
+                if self.ops[n][0] != MUX or state.get(n) == 2:
+                    continue
+                if done:
+                    state[n] = 2
+                    order.append(n)
+                    continue
+                if state.get(n) == 1:
+                    raise MuxFormatError("cycle in the multiplexer graph")
+                state[n] = 1
+                stack.append((n, True))
+                stack.append((self.low[n], False))
+                stack.append((self.high[n], False))
+        return order
+
+    def depth(self) -> int:
+        d = {}
+        for n in self.topological_muxes():
+            d[n] = 1 + max(d.get(self.low[n], 0), d.get(self.high[n], 0))
+        return max((d.get(self.out_src[o], 0) for o in self.outputs), default=0)
+
+
+def parse_mux_circuit(blob: bytes) -> MuxCircuit:
+    off = 0
+
+    def take(fmt, size):
+        nonlocal off
+        if off + size > len(blob):
+            raise MuxFormatError("truncated MuxCircuit")
+        (v,) = struct.unpack_from(fmt, blob, off)
+        off += size
+        return v
+
+    u64, u32, u8 = (lambda: take("<Q", 8)), (lambda: take("<I", 4)), (lambda: take("<B", 1))
+    n = u64()
+    if n > len(blob):
+        raise MuxFormatError("node count exceeds the buffer")
+    ops = []
+    for _ in range(n):
+        v = u32()
+        if v > OUTPUT:
+            raise MuxFormatError(f"unknown MuxOp variant {v}")
+        ops.append((v, u32() if v in (VARIABLE, OUTPUT) else None))
+    holes = [u32() for _ in range(u64())]
+    if holes:
+        raise MuxFormatError("StableGraph with vacant node slots: not produced by the reference's circuits")
+    if u32() != 1:
+        raise MuxFormatError("the graph must be directed")
+    low, high, select, out_src = ([-1] * n for _ in range(4))
+    slot = {LOW: low, HIGH: high, SELECT: select, OUT_EDGE: out_src}
+    for _ in range(u64()):
+        if u8():
+            s, t, kind = u32(), u32(), u32()
+            if s >= n or t >= n or kind not in slot:
+                raise MuxFormatError("edge out of range")
+            if slot[kind][t] != -1:
+                raise MuxFormatError("a node has two edges of the same kind")
+            slot[kind][t] = s
+    inputs = [u32() for _ in range(u64())]
+    for i, node in enumerate(inputs):
+        if node >= n or ops[node] != (VARIABLE, i):
+            raise MuxFormatError("inputs[i] must be the node Variable(i)")
+    for i, (v, _) in enumerate(ops):
+        if v == MUX and (low[i] < 0 or high[i] < 0 or select[i] < 0):
+            raise MuxFormatError("a Mux needs one Low, one High and one Select edge")
+        if v == MUX and ops[select[i]][0] != VARIABLE:
+            raise MuxFormatError("Select lines must come from input variables")
+        if v == OUTPUT and out_src[i] < 0:
+            raise MuxFormatError("an Output needs its edge")
+    return MuxCircuit(ops, low, high, select, out_src, inputs)
+
+
+def evaluate_plain(c: MuxCircuit, bits: Sequence[int]) -> List[int]:
+    """the circuit on plaintext bits (mux = low when select is 0, high when it is 1; lib.rs:71-79)"""
+    if len(bits) != c.n_inputs:
+        raise ValueError("wrong number of input bits")
+    val = {}
+    for i, (v, p) in enumerate(c.ops):
+        if v == ONE:
+            val[i] = 1
+        elif v == ZERO:
+            val[i] = 0
+        elif v == VARIABLE:
+            val[i] = int(bits[p]) & 1
+    for n in c.topological_muxes():
+        val[n] = val[c.high[n]] if val[c.select[n]] else val[c.low[n]]
+    return [val[c.out_src[o]] for o in c.outputs]
+
+
+def insert_mux_circuit(graph, c: MuxCircuit, ggsw_inputs: Sequence[int], add_cmux: Optional[Callable] = None) -> List[int]:
+    """`FheCircuit::insert_mux_circuit(.., MuxMode::Glwe)` (fhe_circuit.rs:274-420) on a `spf_amd.FheCircuit`:
+    `ggsw_inputs[i]` is the graph node holding the GGSW of input bit i; returns the GLWE nodes of the outputs,
+    by output index."""
+    from .graph import FheOp, ValueKind
+    if len(ggsw_inputs) != c.n_inputs:
+        raise ValueError("one GGSW node per circuit input")
+    node = {}
+    for i, (v, p) in enumerate(c.ops):
+        if v == ONE:
+            node[i] = graph.add_trivial(ValueKind.GLWE1, 1)
+        elif v == ZERO:
+            node[i] = graph.add_trivial(ValueKind.GLWE1, 0)
+    for n in c.topological_muxes():
+        sel = ggsw_inputs[c.ops[c.select[n]][1]]
+        node[n] = graph.add_op(FheOp.CMux, [sel, node[c.low[n]], node[c.high[n]]])
+    return [node[c.out_src[o]] for o in c.outputs]

@@ -18,6 +18,10 @@ SMALL_N = 12
 
 @pytest.fixture(scope="module")
 def rig():
+    return _make_rig()
+
+
+def _make_rig():
     ks = keyset(0x5EED0001, SMALL_N)
     P = ks.params
     r = O.Rng(0x6A11)
@@ -227,3 +231,56 @@ def test_graph_ggsw_and_glev_constants(full_rig=None):
     eng.load_scheme_switch_key(ssk)
     assert np.array_equal(eng.l1ggsw_constant(1).view(np.float64),
                           np.asarray(O.circuit_bootstrap(triv[1], ks.bsk_fft, ak, ssk, P)).view(np.float64))
+
+
+def _replay_rounds(eng, P):
+    g = spf_amd.FheCircuit(eng)
+    lwe1 = random_lwe_batch(31, 4, P.N * P.k)
+    a, b = random_glwe(32, 4, P.glwe_len), random_glwe(33, 4, P.glwe_len)
+    li = [g.add_input(ValueKind.LWE1, lwe1[i]) for i in range(4)]
+    ai = [g.add_input(ValueKind.GLWE1, a[i]) for i in range(4)]
+    bi = [g.add_input(ValueKind.GLWE1, b[i]) for i in range(4)]
+    sel = [g.add_op(FheOp.CircuitBootstrap, [g.add_op(FheOp.KeyswitchL1toL0, [x])]) for x in li]
+    m = [g.add_op(FheOp.CMux, [sel[i], ai[i], bi[i]]) for i in range(4)]
+    top = g.add_op(FheOp.CMux, [sel[0], m[1], g.add_op(FheOp.Not, [m[2]])])
+    outs = [g.add_output(x, ValueKind.GLWE1) for x in m + [top]]
+
+    def expected():
+        gg = eng.keyswitch_circuit_bootstrap(lwe1)
+        mm = eng.cmux(gg, a, b)
+        tt = eng.cmux(gg[:1], mm[1:2], eng.glwe_not(mm[2:3]))
+        return list(mm) + [tt[0]]
+
+    for rnd in range(5):
+        if rnd:
+            lwe1[...] = random_lwe_batch(40 + rnd, 4, P.N * P.k)    # same buffers, new contents
+            a[...] = random_glwe(50 + rnd, 4, P.glwe_len)
+        if rnd == 3:
+            eng.circuit_bootstrap(random_lwe_batch(60, 64, P.lwe_n))  # grows the context's scratch: re-capture
+        g.run()
+        for got, exp in zip(outs, expected()):
+            assert np.array_equal(got, exp), rnd
+    g.close()
+
+
+def test_graph_reruns_on_new_inputs(rig):
+    """inputs are read from the callers' buffers at every run: new contents, new (correct) outputs"""
+    ks, eng = rig
+    _replay_rounds(eng, ks.params)
+
+
+def test_replayed_hip_graph_equals_eager_runs():
+    """SPF_GRAPH_CAPTURE=1 (read once per process, hence the child process): spf_graph_run captures the planned
+    launch sequence as a hipGraph on its second run and replays it afterwards; the replay must give the eager
+    results on new inputs, and a context scratch buffer that grows in between must force a re-capture."""
+    import os
+    import subprocess
+    import sys
+    code = ("import tests.test_gpu_graph as t\n"
+            "from tests.util import keyset\n"
+            "ks, eng = t._make_rig()\n"
+            "t._replay_rounds(eng, ks.params)\nprint('replay ok')\n")
+    env = dict(os.environ, SPF_GRAPH_CAPTURE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0 and "replay ok" in r.stdout, r.stderr[-3000:]
