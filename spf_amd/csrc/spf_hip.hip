@@ -243,12 +243,12 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
 #define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
     if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16>), kBlindRotate4Lds);
     else if (variant == 2 && cts == 4 && paired) {
-        static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 2; }();
+        static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 6; }();
         switch (p_opt) {
         case 0: SPF_LAUNCH("blind_rotate2p_kernel<2,16,0>", (blind_rotate2p_kernel<2, 16, 0>), kBlindRotate2pLds); break;
         case 1: SPF_LAUNCH("blind_rotate2p_kernel<2,16,1>", (blind_rotate2p_kernel<2, 16, 1>), kBlindRotate2pLds); break;
-        case 6: SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6>), kBlindRotate2pLds); break;
-        default: SPF_LAUNCH("blind_rotate2p_kernel<2,16,2>", (blind_rotate2p_kernel<2, 16, 2>), kBlindRotate2pLds); break;
+        case 2: SPF_LAUNCH("blind_rotate2p_kernel<2,16,2>", (blind_rotate2p_kernel<2, 16, 2>), kBlindRotate2pLds); break;
+        default: SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6>), kBlindRotate2pLds); break;
         }
     }
     else if (variant == 2 && cts == 4) SPF_LAUNCH("blind_rotate2_kernel<2,16,4>", (blind_rotate2_kernel<2, 16, 4>), blind_rotate2_lds<4>());

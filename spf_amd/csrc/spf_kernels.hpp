@@ -859,7 +859,8 @@ constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlot
 
 // OPT (A/B switches, SPF_P_OPT): bit 0 = exchange 2 of BOTH transforms of a pair in registers
 // (lane_transpose_hi3), bit 1 = of the second transform only (default: balances the LDS store path against
-// the VALU).  Tried on this kernel and rejected (numbers in profiles/r02_experiments_blind_rotate.md): static and
+// the VALU), bit 2 = two key pairs in flight in the MAD instead of three (default; 8 registers, 32 B of scratch
+// less).  Tried on this kernel and rejected (numbers in profiles/r02_experiments_blind_rotate.md): static and
 // alternating s_setprio for the younger SIMD partners, flat-polled and deferred pair rendezvous, and a
 // ping-pong schedule of the two ciphertext groups one slot apart.
 template <int L, int LOGB, int OPT, int W>
