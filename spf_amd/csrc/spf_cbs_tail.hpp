@@ -24,6 +24,20 @@ struct PairCtx {
     int lane, w, me, partner;
 };
 
+// Hand-over between the two waves of a unit: the flat-polled word per wave pair.  Unlike the blind rotation the
+// four units of a workgroup share nothing (no key ring), so pair-local hand-overs let them drift apart and fill
+// each other's waits; a workgroup s_barrier here (compile with -DSPF_TAIL_BARRIER) measured 1.8 % SLOWER on the
+// whole circuit bootstrap (54.4 vs 53.5 ms per 4096) although a polled hand-over costs ≈ 2 000 cycles.
+__device__ __forceinline__ void tail_sync(const PairCtx& c, uint32_t& seq)
+{
+#ifdef SPF_TAIL_BARRIER
+    (void)seq;
+    pair_barrier_w();
+#else
+    pair_barrier(c.flags, c.me, c.partner, seq);
+#endif
+}
+
 // value select on the (wave-uniform) parity: written with scalar selects rather than branches on
 // purpose — branching over struct copies makes hipcc select between *addresses* of register
 // arrays, which pins them in scratch memory.
@@ -37,13 +51,13 @@ __device__ __forceinline__ c64 sel(bool pick_b, c64 a, c64 b)
 __device__ __forceinline__ void pair_forward(const PairCtx& c, uint32_t& seq, c64 (&V)[8], c64 (&X)[8])
 {
     const bool odd = c.w != 0;
-    pair_barrier(c.flags, c.me, c.partner, seq); // partner is done reading my region
+    tail_sync(c, seq); // partner is done reading my region
     fft512_single<+1>(V, c.mine, c.tab, c.lane);
     // radix-2 stage across the two waves: wave 0 finishes bins d < 4 (keeps E[0..3], needs O[0..3]),
     // wave 1 bins d >= 4 (keeps O[4..7], needs E[4..7])
 #pragma unroll
     for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, V[4 + i], V[i]);
-    pair_barrier(c.flags, c.me, c.partner, seq);
+    tail_sync(c, seq);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
@@ -67,18 +81,18 @@ __device__ __forceinline__ void pair_inverse(const PairCtx& c, uint32_t& seq, co
         c64 dd = csub(P[i], P[i + 4]);
         Op[i] = cmul_tw<-1>(dd, c.wc[64 * i]);
     }
-    pair_barrier(c.flags, c.me, c.partner, seq);
+    tail_sync(c, seq);
     // wave 0 keeps E'[0..3] and needs E'[4..7]; wave 1 keeps O'[4..7] and needs O'[0..3]
 #pragma unroll
     for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, Op[i], Ep[i]);
-    pair_barrier(c.flags, c.me, c.partner, seq);
+    tail_sync(c, seq);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
         V[i] = sel(odd, Ep[i], got);
         V[4 + i] = sel(odd, got, Op[i]);
     }
-    pair_barrier(c.flags, c.me, c.partner, seq);
+    tail_sync(c, seq);
     fft512_single<-1>(V, c.mine, c.tab, c.lane);
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) {
@@ -239,11 +253,11 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
         uint64_t st[16];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            pair_barrier(flags, pc.me, pc.partner, seq);
+            tail_sync(pc, seq);
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = p == 0 ? park[e * 64 + lane] : acc_b[e];
-            pair_barrier(flags, pc.me, pc.partner, seq);
+            tail_sync(pc, seq);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 uint32_t cp = ((uint32_t)coef2(e) * kinv) & (2 * kN - 1);

@@ -1429,8 +1429,17 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
     volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes);
-    uint32_t seq = 0;
-    const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
+    [[maybe_unused]] uint32_t seq = 0;
+    [[maybe_unused]] const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
+    // hand-over between the two waves of a gate: every wave of the workgroup runs the same sequence, so a bare
+    // s_barrier does it (0.355 vs 0.366 ms per 4096 gates against r01's flat-polled word per pair; -DSPF_CMUX_POLL)
+    auto cmux_sync = [&]() {
+#ifdef SPF_CMUX_POLL
+        pair_barrier(flags, me, partner, seq);
+#else
+        pair_barrier_w();
+#endif
+    };
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
@@ -1506,7 +1515,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
             int dim = ((int)(wim << (32 - LOGB - sh))) >> (32 - LOGB);
             V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
         }
-        if (m > 0) pair_barrier(flags, me, partner, seq); // partner is done with my last cross data
+        if (m > 0) cmux_sync(); // partner is done with my last cross data
         fft512_single<+1>(V, mine, tab, lane);
         c64 Ei[4], Oi[4];
         if (w == 0) {
@@ -1516,7 +1525,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[i];
         }
-        pair_barrier(flags, me, partner, seq);
+        cmux_sync();
         if (w == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
@@ -1559,7 +1568,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
             c64 dd = csub(prod[q][i], prod[q][i + 4]);
             Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
         }
-        if (q == 0) pair_barrier(flags, me, partner, seq);
+        if (q == 0) cmux_sync();
         if (w == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
@@ -1567,7 +1576,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
         }
-        pair_barrier(flags, me, partner, seq);
+        cmux_sync();
         if (w == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
@@ -1575,7 +1584,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
         }
-        pair_barrier(flags, me, partner, seq);
+        cmux_sync();
         fft512_single<-1>(V, mine, tab, lane);
         double tv[16];
 #pragma unroll
