@@ -300,7 +300,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
 bool ks_mfma_ok(const spf_params& p)
 {
     const uint64_t K = (uint64_t)p.glwe_size * p.polynomial_degree * p.ks_radix_count;
-    return p.ks_radix_log <= 8 && K % 32 == 0 && K * ((uint64_t)1 << (p.ks_radix_log - 1)) * 128 < ((uint64_t)1 << 31);
+    return p.ks_radix_log <= 8 && K % 256 == 0 && K * ((uint64_t)1 << (p.ks_radix_log - 1)) * 128 < ((uint64_t)1 << 31); // K: rounds of 2 x 128 in ks_gemm_kernel
 }
 
 // (re)build the byte-plane image of the keyswitch key; called whenever the key becomes ready

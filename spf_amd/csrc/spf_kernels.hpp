@@ -1941,30 +1941,48 @@ struct KsGemmArgs {
     uint32_t B, n_in, n_out, K;
 };
 
-__global__ __launch_bounds__(256) void ks_gemm_kernel(KsGemmArgs a)
+__global__ __launch_bounds__(256, 2) void ks_gemm_kernel(KsGemmArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const size_t K = a.K;
     const uint32_t m0 = blockIdx.y * KSG_TILE + wm * 64, n0 = blockIdx.x * KSG_TILE + wn * 64;
-    // v_mfma_i32_32x32x32_i8: lane (r, h) supplies 16 consecutive k of A row r and of B column r
-    // for its half h; any k permutation common to both operands leaves the dot products unchanged.
-    const int8_t* pa0 = a.A + (size_t)(m0 + r) * K + 16 * h;
-    const int8_t* pa1 = pa0 + 32 * K;
-    const int8_t* pb0 = a.Bt + (size_t)(n0 + r) * K + 16 * h;
-    const int8_t* pb1 = pb0 + 32 * K;
+    // v_mfma_i32_32x32x32_i8: lane (r, h) supplies 16 k values of A row r and of B column r per instruction; any
+    // assignment of k values to (h, position) that is the same for both operands leaves the dot products
+    // unchanged.  So a lane takes 64 CONTIGUOUS bytes of its row per round of 128 k (k0 + 64 h .. + 64): whole
+    // 128-byte lines per row instead of 32-byte pieces, and the four 16-byte quarters feed four MFMA k-steps.
+    // Rounds are double-buffered in registers: the loads of round i+1 are in flight under the 16 MFMAs of round i.
+    const int8_t* pa = a.A + (size_t)(m0 + r) * K + 64 * h;
+    const int8_t* pb = a.Bt + (size_t)(n0 + r) * K + 64 * h;
+    const size_t row32 = 32 * K;
+    struct Frag { v4i32 a[2][4], b[2][4]; };
+    auto load = [&](Frag& f, size_t k0) {
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f.a[blk][q] = *reinterpret_cast<const v4i32*>(pa + blk * row32 + k0 + 16 * q);
+                f.b[blk][q] = *reinterpret_cast<const v4i32*>(pb + blk * row32 + k0 + 16 * q);
+            }
+    };
     v16i32 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-#pragma unroll 4
-    for (size_t k0 = 0; k0 < K; k0 += 32) {
-        v4i32 a0 = *reinterpret_cast<const v4i32*>(pa0 + k0);
-        v4i32 a1 = *reinterpret_cast<const v4i32*>(pa1 + k0);
-        v4i32 b0 = *reinterpret_cast<const v4i32*>(pb0 + k0);
-        v4i32 b1 = *reinterpret_cast<const v4i32*>(pb1 + k0);
-        acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
+    auto mac = [&](const Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0][q], f.b[0][q], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0][q], f.b[1][q], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1][q], f.b[0][q], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1][q], f.b[1][q], acc11, 0, 0, 0);
+        }
+    };
+    Frag f0, f1;
+    load(f0, 0);
+    for (size_t k0 = 0; k0 < K; k0 += 256) { // K is a multiple of 256 (host check)
+        load(f1, k0 + 128);
+        mac(f0);
+        if (k0 + 256 < K) load(f0, k0 + 256);
+        mac(f1);
     }
     // epilogue: C/D map of the 32x32 forms: row = (reg&3) + 8*(reg>>2) + 4*h, col = r.
     // Column n = 8*word + t: shift plane t into place and add the 8 lanes of a word.
