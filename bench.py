@@ -375,7 +375,7 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
     jobs per GPU (weak scaling), dealt to the ranks by spf_amd.gate_pool, each rank's jobs lowered into ONE gate
     graph on its own GPU; synthetic ciphertexts (timing is value-independent; correctness of the same graph is
     tests/test_gpu_multiply.py).  Reports whole-pool multiplications/s and gates/s."""
-    from spf_amd.gate_pool import lpt_shards, multiply_jobs_as_one_graph
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph, lpt_shards
     from spf_amd.mux_circuits import parse_mux_circuit
     path = os.path.join(ROOT, "tests", "golden", "mux_multiplier_n8_m8.bincode")
     if not os.path.exists(path):
@@ -385,7 +385,7 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
     mine = lpt_shards([circuit.metrics()["mux_gates"]] * n_jobs, world)[rank]
     rng = np.random.default_rng(0x8008 + rank)
     cts = rng.integers(0, 1 << 64, size=(len(mine), 16, P.glwe_words), dtype=np.uint64)
-    g, _ = multiply_jobs_as_one_graph(eng, circuit, cts)
+    g, _ = circuit_jobs_as_one_graph(eng, circuit, cts)
     g.run()                       # plans, allocates, warms up
     if world > 1:
         dist.barrier()
@@ -406,23 +406,41 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
 
 
 def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):
-    """BASELINE config 3: K independent 32-bit additions (the circuit of tests/test_gpu_graph.py:
-    64 x (SampleExtract -> KeyswitchL1toL0 -> CircuitBootstrap) + a ripple-carry chain of 192 CMUX and
-    32 Not per addition) as ONE `FheCircuit` run: one input copy, 68 levels enqueued back to back on
-    one stream, one output copy.  Synthetic keys and inputs (timing is value-independent; correctness
-    of the same graph is tests/test_gpu_graph.py::test_encrypted_add_32_as_one_graph)."""
+    """BASELINE config 3: K independent 32-bit additions through the reference's adder — `mux_circuits::add::
+    ripple_carry_adder(32, 32, false)` (1 679 CMUX in 64 levels: one multiplexer per BDD node of every sum bit,
+    add.rs:13-58 + lib.rs:358-445, rebuilt by spf_amd.mux_circuits) fed like `add_circuit` does (circuits/add.rs:10-32:
+    64 x SampleExtract -> KeyswitchL1toL0 -> CircuitBootstrap) — as ONE `FheCircuit` run: one input copy, all levels
+    enqueued back to back on one stream, one output copy.  `compact` is r01's hand-shared adder (192 CMUX + 32 Not in
+    68 levels), kept for comparison.  Synthetic ciphertexts (timing is value-independent; correctness:
+    tests/test_gpu_graph.py::test_encrypted_add_32_via_mux_circuits_adder / test_encrypted_add_32_as_one_graph)."""
     import spf_amd
     from spf_amd import FheOp, ValueKind
-    if not keys_loaded:
-        for which in (2, 3):
-            ptr, nbytes = eng.key_blob(which)
-            t = torch.as_tensor(DevArray(ptr, nbytes), device=dev)
-            t.copy_((torch.randn(nbytes // 8, generator=gen, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
-            torch.cuda.synchronize()
-            eng.key_blob_commit(which)
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph
+    from spf_amd.mux_circuits import ripple_carry_adder
     rng = np.random.default_rng(0xADD32)
+
+    def timed(g, reps=3):
+        g.run()                       # plans, allocates, warms up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.run()
+        dt = (time.perf_counter() - t0) / reps
+        st = g.stats()
+        g.close()
+        return dt, st
+
+    adder = ripple_carry_adder(32, 32, False)
+    cts = rng.integers(0, 1 << 64, size=(K, 64, P.glwe_words), dtype=np.uint64)
+    g, _ = circuit_jobs_as_one_graph(eng, adder, cts)
+    dt, st = timed(g)
+    gates = adder.metrics()["mux_gates"] + 64
+    out = {"adds_per_graph": K, "circuit": f"mux_circuits ripple_carry_adder(32,32,false): {adder.metrics()['mux_gates']} CMUX, "
+                                             f"depth {adder.depth()}, 64 circuit bootstraps",
+           "ms_per_graph_run": round(dt * 1e3, 3), "adds_per_s": round(K / dt, 2), "gates_per_s": round(K * gates / dt, 1),
+           "nodes": st["nodes"], "levels": st["levels"], "launches": st["launches"],
+           "note": "wall time of spf_graph_run: H2D of 64 GLWE inputs per add, all levels, D2H of 33 GLWE outputs per add"}
+
     g = spf_amd.FheCircuit(eng)
-    outs = []
     for _ in range(K):
         sel = []
         for _ in range(64):
@@ -438,21 +456,13 @@ def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):
             ncarry = g.add_op(FheOp.Not, [carry])
             l1 = [g.add_op(FheOp.CMux, [gb[i], lo, hi]) for lo, hi in
                   [(carry, ncarry), (ncarry, carry), (zero, carry), (carry, one)]]
-            outs.append(g.add_output(g.add_op(FheOp.CMux, [ga[i], l1[0], l1[1]]), ValueKind.GLWE1))
+            g.add_output(g.add_op(FheOp.CMux, [ga[i], l1[0], l1[1]]), ValueKind.GLWE1)
             carry = g.add_op(FheOp.CMux, [ga[i], l1[2], l1[3]])
-        outs.append(g.add_output(carry, ValueKind.GLWE1))
-    g.run()                       # plans, allocates, warms up
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        g.run()
-    dt = (time.perf_counter() - t0) / reps
-    st = g.stats()
-    g.close()
-    return {"adds_per_graph": K, "ms_per_graph_run": round(dt * 1e3, 3), "adds_per_s": round(K / dt, 2),
-            "gates_per_s": round(K * (64 + 192) / dt, 1), "nodes": st["nodes"], "levels": st["levels"],
-            "launches": st["launches"],
-            "note": "wall time of spf_graph_run: H2D of 64 GLWE inputs per add, all levels, D2H of 33 GLWE outputs per add"}
+        g.add_output(carry, ValueKind.GLWE1)
+    dt2, st2 = timed(g)
+    out["compact"] = {"circuit": "192 CMUX + 32 Not, carries shared between sum and carry-out", "ms_per_graph_run": round(dt2 * 1e3, 3),
+                      "levels": st2["levels"], "launches": st2["launches"]}
+    return out
 
 
 if __name__ == "__main__":

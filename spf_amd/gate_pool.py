@@ -63,10 +63,11 @@ def run_sharded(jobs: Sequence, costs: Sequence[float], rank: int, world: int,
     return [merged[i] for i in range(len(jobs))]
 
 
-def multiply_jobs_as_one_graph(engine, circuit, bit_glwes: np.ndarray):
-    """Lower K evaluations of a `MuxCircuit` into ONE gate graph the way `mul_impl` feeds a multiplier block
-    (circuits/mul.rs:104-117 + fhe_circuit.rs:473-494): per input bit an L1 GLWE -> SampleExtract(0) ->
-    KeyswitchL1toL0 -> CircuitBootstrap, the GGSWs select the block's CMUX tree.
+def circuit_jobs_as_one_graph(engine, circuit, bit_glwes: np.ndarray):
+    """Lower K evaluations of a `MuxCircuit` into ONE gate graph the way `add_circuit` / `mul_impl` feed their
+    blocks (`FheCircuit::insert_mux_circuit_and_connect_inputs`, fhe_circuit.rs:473-494; circuits/add.rs:10-32,
+    circuits/mul.rs:104-117): per input bit an L1 GLWE -> SampleExtract(0) -> KeyswitchL1toL0 -> CircuitBootstrap,
+    the GGSWs select the block's CMUX tree.
     bit_glwes: [K, n_inputs, glwe_words] uint64.  Returns (graph, outs) with outs[k][o] the array that
     graph.run() fills with output bit o of evaluation k."""
     from .graph import FheCircuit, FheOp, ValueKind
@@ -85,3 +86,6 @@ def multiply_jobs_as_one_graph(engine, circuit, bit_glwes: np.ndarray):
             sel.append(g.add_op(FheOp.CircuitBootstrap, [x]))
         outs.append([g.add_output(n, ValueKind.GLWE1) for n in insert_mux_circuit(g, circuit, sel)])
     return g, outs
+
+
+multiply_jobs_as_one_graph = circuit_jobs_as_one_graph

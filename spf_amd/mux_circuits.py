@@ -171,3 +171,122 @@ def insert_mux_circuit(graph, c: MuxCircuit, ggsw_inputs: Sequence[int], add_cmu
         sel = ggsw_inputs[c.ops[c.select[n]][1]]
         node[n] = graph.add_op(FheOp.CMux, [sel, node[c.low[n]], node[c.high[n]]])
     return [node[c.out_src[o]] for o in c.outputs]
+
+
+# ---- circuits the reference GENERATES (no blob): reduced ordered BDDs of the outputs, one Mux per BDD node ----------
+#
+# `mux_circuits::add::ripple_carry_adder` (mux_circuits/src/add.rs:13-58) builds the BDD of every sum bit over the
+# variables [carry-in,] a0, b0, a1, b1, ... with a BDD library and converts them with `MuxCircuit::from(&[Bdd])`
+# (lib.rs:358-445): per output, ONE Mux per internal BDD node (select = the node's variable, low / high = its
+# children), terminals = the shared One / Zero, nothing shared between outputs.  A reduced ordered BDD is canonical
+# for a function and a variable order, so any correct ROBDD construction yields the same multiplexer DAG (same gate
+# count, same depth) as the reference's library; the little engine below is that construction.
+
+class _Robdd:
+    """reduced ordered BDDs with a unique table; node ids 0 / 1 are the terminals"""
+
+    def __init__(self, n_vars: int):
+        self.n_vars = n_vars
+        self.nodes = [(n_vars, 0, 0), (n_vars, 1, 1)]
+        self.unique = {}
+        self.memo = {}
+
+    def mk(self, var: int, lo: int, hi: int) -> int:
+        if lo == hi:
+            return lo
+        key = (var, lo, hi)
+        n = self.unique.get(key)
+        if n is None:
+            n = len(self.nodes)
+            self.nodes.append(key)
+            self.unique[key] = n
+        return n
+
+    def var(self, i: int) -> int:
+        return self.mk(i, 0, 1)
+
+    def apply(self, op: str, f: int, g: int) -> int:
+        if f < 2 and g < 2:
+            return {"and": f & g, "or": f | g, "xor": f ^ g}[op]
+        key = (op, f, g) if f <= g else (op, g, f)
+        r = self.memo.get(key)
+        if r is not None:
+            return r
+        vf, vg = self.nodes[f][0], self.nodes[g][0]
+        v = min(vf, vg)
+        f0, f1 = (self.nodes[f][1], self.nodes[f][2]) if vf == v else (f, f)
+        g0, g1 = (self.nodes[g][1], self.nodes[g][2]) if vg == v else (g, g)
+        r = self.mk(v, self.apply(op, f0, g0), self.apply(op, f1, g1))
+        self.memo[key] = r
+        return r
+
+
+def mux_circuit_from_bdds(bdd: _Robdd, roots: Sequence[int]) -> MuxCircuit:
+    """`MuxCircuit::from(&[Bdd])` (lib.rs:358-445)"""
+    ops: List[Tuple[int, Optional[int]]] = []
+    low: List[int] = []
+    high: List[int] = []
+    select_var: List[int] = []
+    out_src: List[int] = []
+
+    def add(op, payload=None):
+        ops.append((op, payload))
+        low.append(-1), high.append(-1), select_var.append(-1), out_src.append(-1)
+        return len(ops) - 1
+
+    terminal = {}
+    for i, root in enumerate(roots):
+        local = {}
+        order, stack, seen = [], [(root, False)], set()
+        while stack:                                         # children before parents
+            n, done = stack.pop()
+            if n < 2 or (n in seen and not done):
+                continue
+            if done:
+                order.append(n)
+                continue
+            seen.add(n)
+            stack.append((n, True))
+            stack.append((bdd.nodes[n][1], False))
+            stack.append((bdd.nodes[n][2], False))
+
+        def node_of(n):
+            if n < 2:
+                if n not in terminal:
+                    terminal[n] = add(ONE if n else ZERO)
+                return terminal[n]
+            return local[n]
+
+        for n in order:
+            v, lo, hi = bdd.nodes[n]
+            m = add(MUX)
+            low[m], high[m], select_var[m] = node_of(lo), node_of(hi), v
+            local[n] = m
+        o = add(OUTPUT, i)
+        out_src[o] = node_of(root)
+    inputs = [add(VARIABLE, v) for v in range(bdd.n_vars)]
+    select = [inputs[v] if v >= 0 else -1 for v in select_var] + [-1] * (len(ops) - len(select_var))
+    return MuxCircuit(ops, low, high, select[:len(ops)], out_src, inputs)
+
+
+def ripple_carry_adder(n: int, m: int, cin: bool) -> MuxCircuit:
+    """`mux_circuits::add::ripple_carry_adder` (add.rs:13-58): an n-bit plus an m-bit integer (plus a carry-in),
+    max(n, m) + 1 output bits (the top one is the carry out).  Inputs: [carry-in,] a0, b0, a1, b1, ... until the
+    shorter operand is exhausted, then the rest of the longer one."""
+    if n <= 0 or m <= 0:
+        raise ValueError("operand widths must be positive")
+    lo_len, hi_len, off = min(n, m), max(n, m), int(bool(cin))
+    bdd = _Robdd(n + m + off)
+    carry = bdd.var(0) if cin else 0
+    sums = []
+    for i in range(lo_len):
+        a, b = bdd.var(off + 2 * i), bdd.var(off + 2 * i + 1)
+        axb = bdd.apply("xor", a, b)
+        sums.append(bdd.apply("xor", carry, axb))
+        carry = bdd.apply("or", bdd.apply("and", axb, carry), bdd.apply("and", a, b))
+    for i in range(hi_len - lo_len):
+        a = bdd.var(2 * lo_len + i + off)
+        sums.append(bdd.apply("xor", carry, a))
+        carry = bdd.apply("and", a, carry)
+    sums.append(carry)
+    return mux_circuit_from_bdds(bdd, sums)

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from spf_amd.gate_pool import lpt_shards, run_sharded
-from spf_amd.mux_circuits import MuxFormatError, evaluate_plain, parse_mux_circuit
+from spf_amd.mux_circuits import MuxFormatError, evaluate_plain, parse_mux_circuit, ripple_carry_adder
 from spf_amd.sharding import gather_shards, shard_range, shard_sizes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mux_multiplier_n8_m8.bincode")
@@ -29,6 +29,24 @@ def test_reference_multiplier_block_parses_and_multiplies():
     for a, b in [(0, 0), (255, 255), (1, 255), (128, 2)] + [tuple(int(v) for v in rng.integers(0, 256, 2)) for _ in range(60)]:
         out = evaluate_plain(c, _bits(a, b))
         assert sum(o << i for i, o in enumerate(out)) == a * b, (a, b)
+
+
+def test_ripple_carry_adder_restated_from_the_reference_adds():
+    """`mux_circuits::add::ripple_carry_adder` (add.rs:13-58) rebuilt from reduced ordered BDDs; the reference's own test
+    (add.rs:66-116: N in {4, 32}, with and without carry-in, 100 random pairs) in plaintext."""
+    rng = np.random.default_rng(3)
+    for N, cin, gates in ((4, False, 41), (4, True, 51), (32, False, 1679), (32, True, 1745)):
+        c = ripple_carry_adder(N, N, cin)
+        assert c.metrics() == {"mux_gates": gates, "inputs": 2 * N + int(cin), "outputs": N + 1}
+        for _ in range(100):
+            a, b, ci = int(rng.integers(0, 1 << N)), int(rng.integers(0, 1 << N)), int(rng.integers(0, 2))
+            bits = ([ci] if cin else []) + [x for i in range(N) for x in ((a >> i) & 1, (b >> i) & 1)]
+            out = evaluate_plain(c, bits)
+            assert sum(o << i for i, o in enumerate(out)) == a + b + (ci if cin else 0)
+    c = ripple_carry_adder(5, 3, False)          # unequal widths: the longer operand's high bits ripple alone
+    for a, b in ((31, 7), (16, 1), (21, 5)):
+        bits = [x for i in range(3) for x in ((a >> i) & 1, (b >> i) & 1)] + [(a >> 3) & 1, (a >> 4) & 1]
+        assert sum(o << i for i, o in enumerate(evaluate_plain(c, bits))) == a + b
 
 
 def test_malformed_blobs_are_rejected():

@@ -284,3 +284,38 @@ def test_replayed_hip_graph_equals_eager_runs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=600)
     assert r.returncode == 0 and "replay ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_encrypted_add_32_via_mux_circuits_adder():
+    """BASELINE config 3 with the reference's OWN adder circuit: `mux_circuits::add::ripple_carry_adder(32, 32, false)`
+    (one multiplexer per BDD node of every sum bit: 1 679 CMUX in 64 levels, rebuilt by spf_amd.mux_circuits) fed the way
+    `add_circuit` feeds it (parasol_runtime/src/circuits/add.rs:10-32: inputs a0, b0, a1, b1, ... each L1 GLWE ->
+    SampleExtract -> KeyswitchL1toL0 -> CircuitBootstrap), one gate graph, DEFAULT_128, decrypt == a + b."""
+    import oracle as O
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph
+    from spf_amd.mux_circuits import ripple_carry_adder
+    from tests.util import keyset, to_engine_params
+    ks = keyset(0x5EED0001, 637)
+    P = ks.params
+    r = O.Rng(0xADD33)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(O.gen_auto_key_fft(r, ks.glwe_sk, P))
+    eng.load_scheme_switch_key(O.gen_ssk_fft(r, ks.glwe_sk, P))
+    adder = ripple_carry_adder(32, 32, False)
+    assert adder.metrics() == {"mux_gates": 1679, "inputs": 64, "outputs": 33} and adder.depth() == 64
+    a, b = 0xFFFF0F37, 0x9E3779B9
+    cts = []
+    for i in range(32):
+        for bit in ((a >> i) & 1, (b >> i) & 1):
+            m = np.zeros(P.N, dtype=np.uint64)
+            m[0] = O.encode(bit, 1)
+            cts.append(O.encrypt_glwe(r, ks.glwe_sk, m, P.N, P.k, P.glwe_std))
+    g, outs = circuit_jobs_as_one_graph(eng, adder, np.stack(cts)[None])
+    g.run()
+    got = 0
+    for i, o in enumerate(outs[0]):
+        got |= O.decode(int(O.decrypt_glwe_raw(o, ks.glwe_sk, P.N, P.k)[0]), 1) << i
+    g.close()
+    assert got == a + b
