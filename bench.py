@@ -222,9 +222,10 @@ def main() -> int:
         step()
         torch.cuda.synchronize()
 
-    mul8 = None
+    mul8 = mul32 = None
     if extras:
         mul8 = _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch)
+        mul32 = _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch)
         step()
         torch.cuda.synchronize()
 
@@ -363,6 +364,8 @@ def main() -> int:
             line["add32"] = add32
         if mul8:
             line["mul8_gate_pool"] = mul8
+        if mul32:
+            line["mul32_gate_pool"] = mul32
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -403,6 +406,52 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
             "multiplications_per_s": round(n_jobs / dt, 2), "gates_per_s": round(gates / dt, 1),
             "levels": st["levels"], "launches_per_rank": st["launches"],
             "block": "mux_circuits unsigned_multiplier(8,8): 3228 CMUX, depth 126, 16 circuit bootstraps"}
+
+
+def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=1):
+    """BASELINE config 5: 32 x 32-bit encrypted multiplications via mux_circuits, one gate pool job = one
+    multiplication built exactly as `append_uint_multiply` does (parasol_runtime/src/circuits/mul.rs:75-200): 64 input
+    conversions, four `unsigned_multiplier(16, 16)` blocks (the reference's blob), 128 conversions of the partial
+    products, `gradeschool_reduce(32, 32)`: ~127 k CMUX + 192 circuit bootstraps, 620+ levels.  `per_gpu` jobs per GPU
+    (weak scaling), dealt by spf_amd.gate_pool, each rank's jobs in one graph on its GPU.  Synthetic ciphertexts;
+    correctness of the same graph: tests/test_gpu_multiply.py::test_config5_encrypted_multiply_32x32."""
+    from spf_amd import FheCircuit, ValueKind
+    from spf_amd.gate_pool import lpt_shards
+    from spf_amd.mux_circuits import GraphBuilder, append_uint_multiply, parse_mux_circuit
+    path = os.path.join(ROOT, "tests", "golden", "mux_multiplier_n16_m16.bincode")
+    if not os.path.exists(path):
+        return None
+    blk16 = parse_mux_circuit(open(path, "rb").read())
+    n_jobs = per_gpu * world
+    mine = lpt_shards([1.0] * n_jobs, world)[rank]
+    rng = np.random.default_rng(0x3232 + rank)
+    t_build = time.perf_counter()
+    g = FheCircuit(eng)
+    builder = GraphBuilder(g)
+    for _ in mine:
+        sel = [builder.to_ggsw(g.add_input(ValueKind.GLWE1, rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64)))
+               for _ in range(64)]
+        for n in append_uint_multiply(builder, sel[:32], sel[32:], lambda a, b: {(16, 16): blk16}[(a, b)]):
+            g.add_output(n, ValueKind.GLWE1)
+    t_build = time.perf_counter() - t_build
+    g.run()                       # plans, allocates (4 GB of GLWE per job), warms up
+    if world > 1:
+        dist.barrier()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.run()
+    dt = (time.perf_counter() - t0) / reps
+    st = g.stats()
+    g.close()
+    if world > 1:
+        dt = max_over_ranks(dt, dist, device=dev)
+    cmux = 4 * blk16.metrics()["mux_gates"] + 9104
+    return {"multiplications": n_jobs, "per_gpu": per_gpu, "ms_per_pool_run": round(dt * 1e3, 3),
+            "multiplications_per_s": round(n_jobs / dt, 2), "gates_per_s": round(n_jobs * (cmux + 192) / dt, 1),
+            "cmux_per_multiplication": cmux, "circuit_bootstraps_per_multiplication": 192,
+            "nodes": st["nodes"], "levels": st["levels"], "launches_per_rank": st["launches"],
+            "graph_build_s": round(t_build, 2)}
 
 
 def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):

@@ -290,3 +290,170 @@ def ripple_carry_adder(n: int, m: int, cin: bool) -> MuxCircuit:
         carry = bdd.apply("and", a, carry)
     sums.append(carry)
     return mux_circuit_from_bdds(bdd, sums)
+
+
+def common_subexpression_elimination(c: MuxCircuit) -> MuxCircuit:
+    """`MuxCircuit::optimize` (lib.rs:274-279 -> opt.rs:328-415): multiplexers with the same select, low and high
+    operands are one multiplexer; applied in topological order so that merged children merge their parents."""
+    canon = {}
+    for i, (v, _) in enumerate(c.ops):
+        if v != MUX:
+            canon[i] = i
+    seen = {}
+    for n in c.topological_muxes():
+        key = (c.select[n], canon[c.low[n]], canon[c.high[n]])
+        canon[n] = seen.setdefault(key, n)
+    keep = [i for i, (v, _) in enumerate(c.ops) if v != MUX or canon[i] == i]
+    new_index = {old: k for k, old in enumerate(keep)}
+    remap = lambda x: -1 if x < 0 else new_index[canon[x]]
+    return MuxCircuit([c.ops[i] for i in keep], [remap(c.low[i]) for i in keep], [remap(c.high[i]) for i in keep],
+                      [remap(c.select[i]) for i in keep], [remap(c.out_src[i]) for i in keep], [new_index[i] for i in c.inputs])
+
+
+CIRCUIT_CUTOFF = 16     # mul.rs:243
+
+
+def partition_integer(n: int) -> Tuple[int, int]:
+    """mul.rs:245-260: (low, high) word lengths; no split up to the cutoff"""
+    return (n, 0) if n <= CIRCUIT_CUTOFF else ((n + 1) // 2, n // 2)
+
+
+def encode_gradeschool_reduction(n: int, m: int, lo_lo, lo_hi, hi_lo, hi_hi) -> list:
+    """mul.rs:262-388: the order in which the bits of the four partial products a_lo*b_lo, a_lo*b_hi, a_hi*b_lo,
+    a_hi*b_hi enter the reduction circuit (by the column they are added in)."""
+    a_lo, a_hi = partition_integer(n)
+    b_lo, b_hi = partition_integer(m)
+    assert len(lo_lo) == a_lo + b_lo and len(lo_hi) == a_lo + b_hi and len(hi_lo) == a_hi + b_lo and len(hi_hi) == a_hi + b_hi
+    assert a_lo >= b_lo and a_hi <= a_lo and b_hi <= b_lo
+    out, o = [], {"ll": 0, "hl": 0, "lh": 0, "hh": 0}
+    src = {"ll": lo_lo, "hl": hi_lo, "lh": lo_hi, "hh": hi_hi}
+    for run, names in ((b_lo, ("ll",)), (a_lo - b_lo, ("ll", "lh")), (b_lo, ("ll", "hl", "lh")), (b_hi, ("hl", "lh", "hh")),
+                       (a_hi - b_hi, ("hl", "hh")), (b_hi, ("hh",))):
+        for i in range(run):
+            for k in names:
+                out.append(src[k][o[k] + i])
+        for k in names:
+            o[k] += run
+    return out
+
+
+def gradeschool_reduce(n: int, m: int) -> MuxCircuit:
+    """`gradeschool_reduce_impl` (mul.rs:390-590): the 4-operand shifted addition of the partial products as BDDs over
+    the encoded bit order, one multiplexer per BDD node, then `optimize`.  (The reference ships only the 64 x 64
+    instance as a blob and generates the others like this at run time.)"""
+    assert n >= m
+    a_lo, a_hi = partition_integer(n)
+    b_lo, b_hi = partition_integer(m)
+    bdd = _Robdd(2 * (n + m))
+    V = [bdd.var(i) for i in range(2 * (n + m))]
+    xor, land, lor = (lambda f, g: bdd.apply("xor", f, g)), (lambda f, g: bdd.apply("and", f, g)), (lambda f, g: bdd.apply("or", f, g))
+    neg = lambda f: bdd.apply("xor", f, 1)
+
+    def exactly(bits, k):                      # n_bits_are_true (mul.rs:213-240)
+        import itertools
+        res = 0
+        for chosen in itertools.combinations(range(len(bits)), k):
+            clause = 1
+            for i, x in enumerate(bits):
+                clause = land(clause, x if i in chosen else neg(x))
+            res = lor(res, clause)
+        return res
+
+    result = [0] * (n + m)
+    c0 = c1 = c2 = 0
+    for i in range(n + m):                     # section 1 as the reference writes it: every output starts as input i
+        result[i] = V[i]
+    i_off, o_off = b_lo, b_lo
+    for i in range(a_lo - b_lo):               # section 2: two operands + one carry
+        a, b = V[i_off + 2 * i], V[i_off + 2 * i + 1]
+        ops = [a, b, c0]
+        result[o_off + i] = xor(xor(a, b), c0)
+        c0 = lor(exactly(ops, 2), exactly(ops, 3))
+    i_off += 2 * (a_lo - b_lo)
+    o_off += a_lo - b_lo
+    for i in range(b_lo + b_hi):               # sections 3, 4: three operands + two carries
+        a, b, c = V[i_off + 3 * i], V[i_off + 3 * i + 1], V[i_off + 3 * i + 2]
+        result[o_off + i] = xor(xor(xor(xor(a, b), c), c0), c1)
+        ops = [a, b, c, c0, c1]
+        two, three, four, five = (exactly(ops, k) for k in (2, 3, 4, 5))
+        c0 = lor(two, three)
+        c1 = c2
+        c2 = lor(four, five)
+    i_off += 3 * (b_lo + b_hi)
+    o_off += b_lo + b_hi
+    for i in range(a_hi - b_hi):               # section 5: two operands + two carries
+        a, b = V[i_off + 2 * i], V[i_off + 2 * i + 1]
+        ops = [a, b, c0, c1]
+        two, three, four = (exactly(ops, k) for k in (2, 3, 4))
+        result[o_off + i] = xor(xor(xor(a, b), c0), c1)
+        c0 = lor(two, three)
+        c1 = c2
+        c2 = four
+    i_off += 2 * (a_hi - b_hi)
+    o_off += a_hi - b_hi
+    for i in range(b_hi):                      # section 6: carries ripple into a_hi * b_hi
+        a = V[i_off + i]
+        if i < 2:
+            result[o_off + i] = xor(xor(a, c0), c1)
+            ops = [a, c0, c1]
+            c0 = lor(exactly(ops, 2), exactly(ops, 3))
+            if i == 0:
+                c1 = c2
+        else:
+            result[o_off + i] = xor(a, c0)
+            c0 = land(a, c0)
+    return common_subexpression_elimination(mux_circuit_from_bdds(bdd, result))
+
+
+class PlainBuilder:
+    """plaintext stand-in for the gate graph (tests): nodes are bits"""
+
+    def insert(self, circuit: MuxCircuit, inputs):
+        return evaluate_plain(circuit, inputs)
+
+    def to_ggsw(self, bit):
+        return bit
+
+
+class GraphBuilder:
+    """the same interface over `spf_amd.FheCircuit`: `insert` = insert_mux_circuit (MuxMode::Glwe), `to_ggsw` =
+    insert_ciphertext_conversion(L1Glwe -> L1Ggsw) = SampleExtract(0), KeyswitchL1toL0, CircuitBootstrap
+    (fhe_circuit.rs:563-622)"""
+
+    def __init__(self, graph):
+        self.graph = graph
+
+    def insert(self, circuit: MuxCircuit, ggsw_nodes):
+        return insert_mux_circuit(self.graph, circuit, ggsw_nodes)
+
+    def to_ggsw(self, glwe_node):
+        from .graph import FheOp
+        x = self.graph.add_op(FheOp.SampleExtract, [glwe_node], 0)
+        x = self.graph.add_op(FheOp.KeyswitchL1toL0, [x])
+        return self.graph.add_op(FheOp.CircuitBootstrap, [x])
+
+
+def append_uint_multiply(builder, a: Sequence, b: Sequence, blocks: Callable[[int, int], MuxCircuit]) -> list:
+    """`mul_impl` (parasol_runtime/src/circuits/mul.rs:90-200): recursive gradeschool multiplication of two unsigned
+    integers given as GGSW bit nodes (LSB first); returns the len(a) + len(b) product bits as GLWE nodes.
+    `blocks(n, m)` supplies `unsigned_multiplier(n, m)` (the reference loads 8 x 8, 16 x 16 from blobs)."""
+    if len(a) < len(b):
+        a, b = b, a
+    a_lo_len, a_hi_len = partition_integer(len(a))
+    b_lo_len, b_hi_len = partition_integer(len(b))
+    a_lo, a_hi, b_lo, b_hi = a[:a_lo_len], a[a_lo_len:], b[:b_lo_len], b[b_lo_len:]
+    if a_hi_len == 0 and b_hi_len == 0:
+        return builder.insert(blocks(len(a), len(b)), list(a) + list(b))
+    if b_hi_len == 0:
+        ll = append_uint_multiply(builder, a_lo, b_lo, blocks)
+        hl = append_uint_multiply(builder, a_hi, b_lo, blocks)
+        adder = ripple_carry_adder(b_lo_len, a_hi_len + b_lo_len, False)
+        lo, hi = ll[:a_lo_len], ll[a_lo_len:]
+        ins = [x for pair in zip(hi, hl[:a_lo_len]) for x in pair] + list(hl[a_lo_len:])
+        return lo + builder.insert(adder, [builder.to_ggsw(x) for x in ins])
+    ll = append_uint_multiply(builder, a_lo, b_lo, blocks)
+    lh = append_uint_multiply(builder, a_lo, b_hi, blocks)
+    hl = append_uint_multiply(builder, a_hi, b_lo, blocks)
+    hh = append_uint_multiply(builder, a_hi, b_hi, blocks)
+    bits = encode_gradeschool_reduction(len(a), len(b), ll, lh, hl, hh)
+    return builder.insert(gradeschool_reduce(len(a), len(b)), [builder.to_ggsw(x) for x in bits])

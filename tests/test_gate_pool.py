@@ -123,3 +123,20 @@ def test_gate_pool_and_config4_sharding_over_gloo_ranks(world):
     assert all(r[1] for r in gather) and sorted(r[2] for r in gather) == sorted(shard_sizes(65536, world))
     if world == 8:
         assert all(r[2] == 8192 for r in gather)              # 65 536 bootstraps = 8 192 per GPU
+
+
+def test_config5_multiplier_32x32_the_reference_way_in_plaintext():
+    """`mul_impl` (parasol_runtime/src/circuits/mul.rs:90-200) for 32 x 32 bits: four `unsigned_multiplier(16, 16)`
+    blocks (the reference's blob, a data fixture here), `encode_gradeschool_reduction` and `gradeschool_reduce(32, 32)`
+    (rebuilt from BDDs + common-subexpression elimination, mul.rs:390-590), all evaluated on plaintext bits."""
+    from spf_amd.mux_circuits import PlainBuilder, append_uint_multiply, gradeschool_reduce
+    blk16 = parse_mux_circuit(open(GOLDEN.replace("n8_m8", "n16_m16"), "rb").read())
+    assert blk16.metrics() == {"mux_gates": 29500, "inputs": 32, "outputs": 32} and blk16.depth() == 510
+    red = gradeschool_reduce(32, 32)
+    assert red.metrics()["inputs"] == 128 and red.metrics()["outputs"] == 64
+    rng = np.random.default_rng(5)
+    for a, b in [(0xFFFFFFFF, 0xFFFFFFFF), (0, 12345), (0x80000000, 2)] + \
+            [tuple(int(v) for v in rng.integers(0, 1 << 32, 2)) for _ in range(3)]:
+        out = append_uint_multiply(PlainBuilder(), [(a >> i) & 1 for i in range(32)], [(b >> i) & 1 for i in range(32)],
+                                   lambda n, m: {(16, 16): blk16}[(n, m)])
+        assert sum(o << i for i, o in enumerate(out)) == a * b, (hex(a), hex(b))
