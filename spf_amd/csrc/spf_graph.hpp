@@ -148,6 +148,52 @@ inline spf_status plan(spf_graph* g)
             n.level = lv + 1;
             max_level = std::max(max_level, n.level);
         }
+    // A circuit bootstrap launch costs as much as ~150 CMUX levels whatever its width (up to one ciphertext per CU),
+    // and conversions in the middle of a circuit become ready one by one (the 128 partial-product bits of a 32 x 32
+    // multiplication at 32 different depths): batch them.  Within the slack that does not lengthen the graph
+    // (latest level = min over consumers of their latest level - 1), bootstraps are moved to common levels —
+    // repeatedly take the bootstrap that must run soonest and run every bootstrap that is ready by then with it —
+    // and the SampleExtract / KeyswitchL1toL0 nodes feeding them follow.  (Nodes are in topological order: operands
+    // precede their users.)
+    {
+        const size_t nn = g->nodes.size();
+        std::vector<uint32_t> alap(nn, max_level);
+        for (size_t id = nn; id-- > 0;) {
+            const auto& n = g->nodes[id];
+            if (n.op < 0) continue;
+            for (uint32_t i = 0; i < n.n_in; i++)
+                if (g->nodes[n.in[i]].op >= 0) alap[n.in[i]] = std::min(alap[n.in[i]], alap[id] - 1);
+        }
+        std::vector<uint32_t> cbs;
+        for (uint32_t id = 0; id < nn; id++)
+            if (g->nodes[id].op == SPF_OP_CIRCUIT_BOOTSTRAP) cbs.push_back(id);
+        std::sort(cbs.begin(), cbs.end(), [&](uint32_t a, uint32_t b) { return alap[a] != alap[b] ? alap[a] < alap[b] : a < b; });
+        std::vector<uint32_t> fixed(nn, 0);
+        std::vector<bool> done(nn, false);
+        for (uint32_t lead : cbs) {
+            if (done[lead]) continue;
+            const uint32_t t = alap[lead];
+            for (uint32_t id : cbs)
+                if (!done[id] && g->nodes[id].level <= t) { done[id] = true; fixed[id] = t; }
+        }
+        // forward again with the chosen bootstrap levels as lower bounds (t <= latest level: depth unchanged)
+        for (size_t id = 0; id < nn; id++) {
+            auto& n = g->nodes[id];
+            if (n.op < 0) continue;
+            uint32_t lv = 0;
+            for (uint32_t i = 0; i < n.n_in; i++) lv = std::max(lv, g->nodes[n.in[i]].level);
+            n.level = std::max(lv + 1, fixed[id]);
+        }
+        // pull the conversion chain's head (SampleExtract -> KeyswitchL1toL0) up against its bootstrap
+        std::vector<uint32_t> min_user(nn, 0xffffffffu);
+        for (size_t id = nn; id-- > 0;) {
+            auto& n = g->nodes[id];
+            if (n.op < 0) continue;
+            if ((n.op == SPF_OP_KEYSWITCH_L1_TO_L0 || n.op == SPF_OP_SAMPLE_EXTRACT) && min_user[id] != 0xffffffffu)
+                n.level = std::max(n.level, min_user[id] - 1);
+            for (uint32_t i = 0; i < n.n_in; i++) min_user[n.in[i]] = std::min(min_user[n.in[i]], n.level);
+        }
+    }
     g->n_levels = max_level;
     // one group per (level, kind, parameter), members in node order
     std::map<std::tuple<uint32_t, int32_t, uint64_t>, size_t> index;
