@@ -408,7 +408,7 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
             "block": "mux_circuits unsigned_multiplier(8,8): 3228 CMUX, depth 126, 16 circuit bootstraps"}
 
 
-def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=1):
+def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=4):
     """BASELINE config 5: 32 x 32-bit encrypted multiplications via mux_circuits, one gate pool job = one
     multiplication built exactly as `append_uint_multiply` does (parasol_runtime/src/circuits/mul.rs:75-200): 64 input
     conversions, four `unsigned_multiplier(16, 16)` blocks (the reference's blob), 128 conversions of the partial
