@@ -61,8 +61,8 @@ def main():
             lines.append(f"| {os.path.basename(d)} | `{k[:60]}` | {c} | {len(v)} | {sum(v)/len(v):.6g} |")
     # derived figures per kernel
     lines += ["", "## Derived (per dispatch)", "",
-              "| kernel | ms | VALU busy | LDS array busy | wave-cycles waiting (waitcnt/barrier) | issue-stalled | HBM bytes (FETCHx2 + WRITE) |",
-              "|---|---|---|---|---|---|---|"]
+              "| kernel | ms | VALU busy | MFMA busy | LDS array busy | wave-cycles waiting (waitcnt/barrier) | issue-stalled | HBM bytes (FETCHx2 + WRITE) |",
+              "|---|---|---|---|---|---|---|---|"]
     derived = {}
     for k, c in allacc.items():
         ms = kernel_ms.get(k)
@@ -77,6 +77,8 @@ def main():
         if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
             d["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
             d["issue_stall_frac"] = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            d["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cyc   # cycles the matrix pipes are occupied
         if "FETCH_SIZE" in c:
             d["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c.get("WRITE_SIZE", 0) * 1024
         for n in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
@@ -85,7 +87,7 @@ def main():
                 d[n] = c[n]
         derived[k] = d
         f = lambda x: "—" if x is None else f"{x:.3f}"
-        lines.append(f"| `{k[:60]}` | {ms:.4f} | {f(d.get('valu_busy_frac'))} | {f(d.get('lds_busy_frac'))} | "
+        lines.append(f"| `{k[:60]}` | {ms:.4f} | {f(d.get('valu_busy_frac'))} | {f(d.get('mfma_busy_frac'))} | {f(d.get('lds_busy_frac'))} | "
                      f"{f(d.get('wait_frac'))} | {f(d.get('issue_stall_frac'))} | "
                      f"{d['hbm_bytes_per_launch']:.4g}" + (" |" if 'hbm_bytes_per_launch' in d else "— |"))
     os.makedirs("profiles", exist_ok=True)
