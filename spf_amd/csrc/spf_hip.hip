@@ -354,7 +354,11 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
         g.A = (const int8_t*)c->ks_dig.p; g.Bt = c->d_ksk_planes; g.rowsum = (const int*)c->ks_rowsum.p;
         g.in = d_in; g.out = d_out; g.B = a.B; g.n_in = a.n_in; g.n_out = a.n_out; g.K = (uint32_t)K;
         dim3 grid((unsigned)(c->ks_npad / KSG_TILE), (unsigned)(mpad / KSG_TILE));
-        hipLaunchKernelGGL(ks_gemm_kernel, grid, dim3(256), 0, s, g);
+        // SPF_KS_GEMM=direct: operands straight from L2 into registers (r01 form, 64-byte pieces); default: tiles
+        // staged through LDS by LDS-DMA
+        static const bool direct = [] { const char* e = getenv("SPF_KS_GEMM"); return e && e[0] == 'd'; }();
+        if (direct) hipLaunchKernelGGL(ks_gemm_kernel, grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(ks_gemm_lds_kernel, grid, dim3(256), kKsLdsBytes, s, g);
     } else {
         dim3 grid((a.n_out + 1 + 255) / 256, (unsigned)((B + KS_CT - 1) / KS_CT)), block(256);
         hipLaunchKernelGGL(keyswitch_kernel, grid, block, 0, s, a);
@@ -461,6 +465,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           kKsLdsBytes));
 #define SPF_P_ATTR(O) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, O>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
     SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(6);

@@ -1941,6 +1941,36 @@ struct KsGemmArgs {
     uint32_t B, n_in, n_out, K;
 };
 
+// epilogue shared by the two GEMM kernels
+__device__ __forceinline__ void ks_gemm_epilogue(const KsGemmArgs& a, const v16i32& acc00, const v16i32& acc01, const v16i32& acc10,
+                                                 const v16i32& acc11, uint32_t m0, uint32_t n0, int r, int h)
+{
+    // epilogue: C/D map of the 32x32 forms: row = (reg&3) + 8*(reg>>2) + 4*h, col = r.
+    // Column n = 8*word + t: shift plane t into place and add the 8 lanes of a word.
+    const uint32_t w = a.n_out + 1;
+    const int t = r & 7;
+    auto finish = [&](const v16i32& acc, uint32_t mbase, uint32_t nbase) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const uint32_t row = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const long long s = (long long)acc[reg] + 128ll * (long long)a.rowsum[row];
+            unsigned long long v = (unsigned long long)s << (8 * t);
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            const uint32_t word = (nbase + r) >> 3;
+            if (t == 0 && row < a.B && word < w) {
+                const uint64_t body = (word == a.n_out) ? a.in[(size_t)row * (a.n_in + 1) + a.n_in] : 0;
+                a.out[(size_t)row * w + word] = body - v;
+            }
+        }
+    };
+    finish(acc00, m0, n0);
+    finish(acc01, m0, n0 + 32);
+    finish(acc10, m0 + 32, n0);
+    finish(acc11, m0 + 32, n0 + 32);
+}
+
 __global__ __launch_bounds__(256, 2) void ks_gemm_kernel(KsGemmArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1984,30 +2014,81 @@ __global__ __launch_bounds__(256, 2) void ks_gemm_kernel(KsGemmArgs a)
         if (k0 + 256 < K) load(f0, k0 + 256);
         mac(f1);
     }
-    // epilogue: C/D map of the 32x32 forms: row = (reg&3) + 8*(reg>>2) + 4*h, col = r.
-    // Column n = 8*word + t: shift plane t into place and add the 8 lanes of a word.
-    const uint32_t w = a.n_out + 1;
-    const int t = r & 7;
-    auto finish = [&](const v16i32& acc, uint32_t mbase, uint32_t nbase) {
+    ks_gemm_epilogue(a, acc00, acc01, acc10, acc11, m0, n0, r, h);
+}
+
+// ks_gemm_lds_kernel: the same block-GEMM with the operand tiles staged through LDS.  A workgroup (4 waves, 128 x 128
+// tile, 64 x 64 per wave) brings each 128-row x 128-byte slab of A and of Bt into LDS ONCE per round (LDS-DMA, 1 KiB
+// per wave-instruction, double-buffered: the slabs of round i+1 land under the 16 MFMAs per wave of round i) instead
+// of every wave fetching its own rows from L2: half the vector-memory traffic, which is what bounds the direct form
+// (64 B/clk/CU against 128 B/clk needed at full MFMA rate).  Image: 16-byte slot of (row, chunk) =
+// 8 row + (chunk ^ ((row >> 1) & 7)) — the DMA writes slots linearly and chooses WHICH chunk each lane fetches, the
+// reads of a 16-lane ds_read_b128 group (16 rows, one chunk) hit 16 distinct slots mod 16: conflict-free.
+// Two workgroups per CU (64 KiB of LDS each).
+constexpr int kKsLdsBytes = 2 * 2 * KSG_TILE * 128;
+
+__global__ __launch_bounds__(256, 2) void ks_gemm_lds_kernel(KsGemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const size_t K = a.K;
+    const uint32_t tm0 = blockIdx.y * KSG_TILE, tn0 = blockIdx.x * KSG_TILE;
+    // DMA duty of this wave: rows [32 wave, +32) of the A slab and of the B slab, 8 rows per piece
+    uint32_t voffA[4], voffB[4];
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const uint32_t row = mbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const long long s = (long long)acc[reg] + 128ll * (long long)a.rowsum[row];
-            unsigned long long v = (unsigned long long)s << (8 * t);
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            const uint32_t word = (nbase + r) >> 3;
-            if (t == 0 && row < a.B && word < w) {
-                const uint64_t body = (word == a.n_out) ? a.in[(size_t)row * (a.n_in + 1) + a.n_in] : 0;
-                a.out[(size_t)row * w + word] = body - v;
-            }
-        }
+    for (int j = 0; j < 4; j++) {
+        const uint32_t row = 32 * wave + 8 * j + (lane >> 3);
+        const uint32_t chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voffA[j] = (uint32_t)((size_t)row * K + 16 * chunk);
+        voffB[j] = voffA[j];
+    }
+    const char* gA = reinterpret_cast<const char*>(a.A) + (size_t)tm0 * K;
+    const char* gB = reinterpret_cast<const char*>(a.Bt) + (size_t)tn0 * K;
+    const uint32_t lds0 = lds_address(smem);
+    auto dma_round = [&](size_t k0, int stage) {
+        const uint32_t base = lds0 + stage * (2 * KSG_TILE * 128) + (32 * wave) * 128;
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds_dma_piece(gA + k0, voffA[j], base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds_dma_piece(gB + k0, voffB[j], base + KSG_TILE * 128 + j * 1024);
     };
-    finish(acc00, m0, n0);
-    finish(acc01, m0, n0 + 32);
-    finish(acc10, m0 + 32, n0);
-    finish(acc11, m0 + 32, n0 + 32);
+    // fragment addresses: row of block blk = 64 wm + 32 blk + r (A) / 64 wn + 32 blk + r (B); chunk of step q = 2 q + h
+    uint32_t rdA[2], rdB[2], swA[2], swB[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const uint32_t ra = 64 * wm + 32 * blk + r, rb = 64 * wn + 32 * blk + r;
+        rdA[blk] = ra * 128; swA[blk] = (ra >> 1) & 7;
+        rdB[blk] = KSG_TILE * 128 + rb * 128; swB[blk] = (rb >> 1) & 7;
+    }
+    v16i32 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    dma_round(0, 0);
+    const size_t rounds = K / 128;
+    for (size_t rd = 0; rd < rounds; rd++) {
+        const int stage = (int)(rd & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my pieces of this round have landed
+        __builtin_amdgcn_s_barrier();                     // ... everyone's; and everyone is done reading the other stage
+        if (rd + 1 < rounds) dma_round((rd + 1) * 128, stage ^ 1);
+        const char* st = smem + stage * (2 * KSG_TILE * 128);
+        v4i32 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                fa[blk][q] = *reinterpret_cast<const v4i32*>(st + rdA[blk] + 16 * ((2 * q + h) ^ swA[blk]));
+                fb[blk][q] = *reinterpret_cast<const v4i32*>(st + rdB[blk] + 16 * ((2 * q + h) ^ swB[blk]));
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0][q], fb[0][q], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0][q], fb[1][q], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[1][q], fb[0][q], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[1][q], fb[1][q], acc11, 0, 0, 0);
+        }
+    }
+    const uint32_t m0 = tm0 + wm * 64, n0 = tn0 + wn * 64;
+    ks_gemm_epilogue(a, acc00, acc01, acc10, acc11, m0, n0, r, h);
 }
 
 // sample_extract (ops/ciphertext/glwe_ciphertext_ops.rs:31-76), k = 1, batched
