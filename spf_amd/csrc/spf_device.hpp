@@ -18,6 +18,18 @@ struct c64 {
     double re, im;
 };
 
+// Pointers fetched from a table in memory (per-gate operand tables) are generic to the compiler: it emits
+// flat_load, which counts on lgkmcnt as well as vmcnt, so every LDS wait in the transforms also waits for the
+// key rows in flight.  These views pin the address space to global (global_load/global_store: vmcnt only).
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef const f64x2_t __attribute__((address_space(1)))* gc64_ptr;
+typedef const uint64_t __attribute__((address_space(1)))* gu64_cptr;
+typedef uint64_t __attribute__((address_space(1)))* gu64_ptr;
+__device__ __forceinline__ gc64_ptr global_view(const c64* p) { return (gc64_ptr)(uintptr_t)p; }
+__device__ __forceinline__ gu64_cptr global_view(const uint64_t* p) { return (gu64_cptr)(uintptr_t)p; }
+__device__ __forceinline__ gu64_ptr global_view(uint64_t* p) { return (gu64_ptr)(uintptr_t)p; }
+__device__ __forceinline__ c64 gload(gc64_ptr p) { f64x2_t v = *p; return {v.x, v.y}; }
+
 __device__ __forceinline__ c64 cadd(c64 a, c64 b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ c64 csub(c64 a, c64 b) { return {a.re - b.re, a.im - b.im}; }
 

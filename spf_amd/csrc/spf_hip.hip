@@ -479,8 +479,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2w_lds<1>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kCmuxLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 4>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, cmux_lds_bytes(4)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, cmux_lds_bytes(2)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux4_kernel<4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kCmux4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),
@@ -769,8 +771,14 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
     if (quad_mode == 2 || (quad_mode == 1 && a.B <= (uint32_t)c->n_cu)) {
         hipLaunchKernelGGL((cmux4_kernel<4, 4>), dim3(a.B), dim3(256), kCmux4Lds, s, a);
     } else {
-        dim3 grid((unsigned)((a.B + kWavesPerBlock - 1) / kWavesPerBlock)), block(512);
-        hipLaunchKernelGGL((cmux_kernel<4, 4>), grid, block, kCmuxLds, s, a);
+        // two gates per workgroup, two workgroups per CU: the same eight waves as one workgroup of four gates, but
+        // the two halves drift apart, so one half's selector requests fly while the other computes, and a barrier
+        // ties four waves instead of eight (0.329 -> 0.316 ms per 4096 gates; SPF_CMUX_GATES=4 for the old shape)
+        static const int gates = [] { const char* e = getenv("SPF_CMUX_GATES"); return e ? atoi(e) : 2; }();
+        if (gates == 2)
+            hipLaunchKernelGGL((cmux_kernel<4, 4, 2>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
+        else
+            hipLaunchKernelGGL((cmux_kernel<4, 4, 4>), dim3((a.B + 3) / 4), dim3(512), cmux_lds_bytes(4), s, a);
     }
 }
 

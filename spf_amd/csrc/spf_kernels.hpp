@@ -1412,10 +1412,10 @@ struct CmuxArgs {
     // {ggsw, d0 (null = zero ciphertext), d1, out} from ptrs[4u .. 4u+3] instead of the arrays above.
     const void* const* ptrs;
 };
-constexpr int kCmuxLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
+constexpr int cmux_lds_bytes(int gates) { return kTableBytes + gates * kWaveBufBytes + 64; }
 
-template <int L, int LOGB>
-__global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
+template <int L, int LOGB, int G>
+__global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
 {
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes);
+    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + G * kWaveBufBytes);
     [[maybe_unused]] uint32_t seq = 0;
     [[maybe_unused]] const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
     // hand-over between the two waves of a gate: every wave of the workgroup runs the same sequence, so a bare
@@ -1443,10 +1443,10 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
+        for (int i = tid; i < kTableEntries; i += 128 * G) dst[i] = src[i];
         if (tid < 8) flags[tid] = 0;
     }
-    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + cslot;
+    const uint32_t ct_raw = blockIdx.x * G + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
     const c64* ggsw;
@@ -1466,6 +1466,8 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
         d1 = a.d1 + (size_t)ct * 2 * kN;
         out_ct = a.out + (size_t)ct * 2 * kN;
     }
+    const gu64_cptr gd0 = global_view(d0), gd1 = global_view(d1);
+    const gu64_ptr gout = global_view(out_ct);
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
     uint32_t dig[2][16];
@@ -1474,7 +1476,8 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int c = p * kN + coef2(e);
-            uint64_t diff = d1[c] - (d0_zero ? 0 : d0[c]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+            const uint64_t x1 = gd1[c], x0 = gd0[c]; // d0 aliases d1 when it is the zero ciphertext: no branch around the load
+            uint64_t diff = x1 - (d0_zero ? 0 : x0); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
             constexpr int shift = 64 - L * LOGB;
             uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
             uint32_t packed = 0;
@@ -1497,15 +1500,27 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
 #pragma unroll
         for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
 
+    // this wave's bins of key row (p, L-1-j), both output polynomials (2 x 8 KiB per wave), are requested one
+    // round ahead: k0 of round m+1 right after round m's first MAD has consumed k0, k1 after the second, so a
+    // wave keeps 8-16 KiB of selector in flight through the whole transform instead of waiting on each row
+    const gc64_ptr gkey = global_view(ggsw) + 256 * w + lane;
+    auto key_row = [&](int m) -> gc64_ptr {
+        const int p = m / L, j = m - p * L;
+        return gkey + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf;
+    };
+    c64 k0[8], k1[8];
+    {
+        const gc64_ptr row = key_row(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) k0[r] = gload(row + 64 * (r & 3) + 512 * (r >> 2));
+#pragma unroll
+        for (int r = 0; r < 8; r++) k1[r] = gload(row + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+    }
 #pragma unroll 1
     for (int m = 0; m < 2 * L; m++) {
         const int p = m / L, j = m - p * L, sh = j * LOGB;
-        // this wave's bins of key row (p, L-1-j): issue the loads for output polynomial 0 now,
-        // they land while the transform runs
-        const c64* row = ggsw + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf + 256 * w + lane;
-        c64 k0[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) k0[r] = row[64 * (r & 3) + 512 * (r >> 2)];
+        // the last round re-requests its own row (an L2 hit) rather than branching around the loads
+        const gc64_ptr next = key_row(m + 1 < 2 * L ? m + 1 : m);
         c64 V[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) {
@@ -1547,9 +1562,8 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
             prod[0][r].re = __builtin_fma(-k0[r].im, X[r].im, re);
             prod[0][r].im = __builtin_fma(k0[r].im, X[r].re, im);
         }
-        c64 k1[8]; // the SIMD partner wave covers this round trip
 #pragma unroll
-        for (int r = 0; r < 8; r++) k1[r] = row[kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+        for (int r = 0; r < 8; r++) k0[r] = gload(next + 64 * (r & 3) + 512 * (r >> 2));
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             double re = __builtin_fma(k1[r].re, X[r].re, prod[1][r].re);
@@ -1557,11 +1571,20 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
             prod[1][r].re = __builtin_fma(-k1[r].im, X[r].im, re);
             prod[1][r].im = __builtin_fma(k1[r].im, X[r].re, im);
         }
+#pragma unroll
+        for (int r = 0; r < 8; r++) k1[r] = gload(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
     }
 
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         c64 Ep[4], Op[4], V[8];
+        // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180): d_0 is re-read rather than held across the
+        // transforms, all sixteen words requested here so they land under the inverse transform
+        const gu64_ptr out = gout + q * kN;
+        const gu64_cptr base = gd0 + q * kN;
+        uint64_t d0w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) d0w[e] = base[coef2(e)];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Ep[i] = cadd(prod[q][i], prod[q][i + 4]);
@@ -1597,20 +1620,16 @@ __global__ __launch_bounds__(512, 2) void cmux_kernel(CmuxArgs a)
         double mn = __builtin_fabs(tv[0]);
 #pragma unroll
         for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-        // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180); d_0 is re-read rather than held
-        // in registers across the transforms
-        uint64_t* out = out_ct + q * kN;
-        const uint64_t* base = d0 + q * kN;
         if (__all(mn >= 4503599627370496.0)) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = (d0_zero ? 0 : base[coef2(e)]) + f64_bigint_to_torus(tv[e]);
+                uint64_t v = (d0_zero ? 0 : d0w[e]) + f64_bigint_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint64_t v = (d0_zero ? 0 : base[coef2(e)]) + f64_round_to_torus(tv[e]);
+                uint64_t v = (d0_zero ? 0 : d0w[e]) + f64_round_to_torus(tv[e]);
                 if (owns_output) out[coef2(e)] = v;
             }
         }
@@ -1670,11 +1689,16 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
         out_ct = a.out + (size_t)ct * 2 * kN;
     }
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+    // operand pointers may come from the per-gate table: pin them to global memory so that the loads count on
+    // vmcnt only and stay in flight across the LDS waits and barriers of the transforms (see global_view)
+    const gc64_ptr gkey = global_view(ggsw) + 256 * w + lane;
+    const gu64_cptr gd0 = global_view(d0) + h * kN, gd1 = global_view(d1) + h * kN;
+    const gu64_ptr gout = global_view(out_ct) + h * kN;
     // selector row (p, level L-1-j), output polynomial h, this wave's bins
     auto load_row = [&](c64 (&k)[8], int p, int j) {
-        const c64* row = ggsw + (size_t)((p * L + (L - 1 - j)) * 2 + h) * kHalf + 256 * w + lane;
+        const gc64_ptr row = gkey + (size_t)((p * L + (L - 1 - j)) * 2 + h) * kHalf;
 #pragma unroll
-        for (int r = 0; r < 8; r++) k[r] = row[64 * (r & 3) + 512 * (r >> 2)];
+        for (int r = 0; r < 8; r++) k[r] = gload(row + 64 * (r & 3) + 512 * (r >> 2));
     };
     c64 key0[L][8], key1[L][8];
 #pragma unroll
@@ -1683,9 +1707,11 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
     uint32_t dig[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const int c = h * kN + coef2(e);
-        // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168), then the gadget digits
-        dig[e] = gadget_digits_packed<L, LOGB>(d1[c] - (d0_zero ? 0 : d0[c]));
+        const int c = coef2(e);
+        // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168), then the gadget digits; d0 aliases d1 when it
+        // is the zero ciphertext, so the load needs no branch
+        const uint64_t x1 = gd1[c], x0 = gd0[c];
+        dig[e] = gadget_digits_packed<L, LOGB>(x1 - (d0_zero ? 0 : x0));
     }
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
@@ -1793,14 +1819,15 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
         }
         wg_barrier(); // cross reads retired before the image is overwritten
     }
+    // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180): d_0 re-read under the inverse transform
+    uint64_t d0w[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) d0w[e] = gd0[coef2(e)];
     fft512_single<-1, 7>(V, mine, tab, lane);
-    // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180)
     uint64_t t[16];
     untwist_to_torus(V, twist, t);
-    uint64_t* out = out_ct + h * kN;
-    const uint64_t* base = d0 + h * kN;
 #pragma unroll
-    for (int e = 0; e < 16; e++) out[coef2(e)] = (d0_zero ? 0 : base[coef2(e)]) + t[e];
+    for (int e = 0; e < 16; e++) gout[coef2(e)] = (d0_zero ? 0 : d0w[e]) + t[e];
 }
 
 // ------------------------------------------------------------------------------------------
