@@ -333,6 +333,72 @@ __device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8])
     }
 }
 
+// fft512_pair, software-pipelined for a wave that has its SIMD to itself (the latency kernels): there
+// nothing else covers an LDS round trip, and the lockstep form above costs exactly twice one transform
+// (measured 5 774 vs 2 707 cycles).  A wave's DS instructions execute in issue order, so a read issued
+// behind the writes of the same image needs no drain: every exchange of one transform is issued and then
+// left in flight under a radix-8 pass of the other.  Same butterflies on the same values: same words.
+template <int DIR>
+__device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], char* bufE, char* bufO,
+                                                      const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
+    c64 tw1[7], tw2[7];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) tw1[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
+#pragma unroll
+    for (int c = 1; c < 8; c++) tw2[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
+    // E pass 1 -> exchange-1 image
+    radix8<DIR>(E);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) E[k1] = cmul_tw<DIR>(E[k1], tw1[k1 - 1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = E[k1];
+    compiler_fence();
+    // O pass 1, E's exchange-1 reads in flight under it
+#pragma unroll
+    for (int a = 0; a < 8; a++) E[a] = *reinterpret_cast<const c64*>(bufE + 1024 * a + rd);
+    compiler_fence();
+    radix8<DIR>(O);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) O[k1] = cmul_tw<DIR>(O[k1], tw1[k1 - 1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = O[k1];
+    compiler_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) O[a] = *reinterpret_cast<const c64*>(bufO + 1024 * a + rd);
+    compiler_fence();
+    // E pass 2 (O's reads in flight) -> exchange-2 image
+    radix8<DIR>(E);
+#pragma unroll
+    for (int c = 1; c < 8; c++) E[c] = cmul_tw<DIR>(E[c], tw2[c - 1]);
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
+    compiler_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
+    compiler_fence();
+    // O pass 2 (E's reads in flight)
+    radix8<DIR>(O);
+#pragma unroll
+    for (int c = 1; c < 8; c++) O[c] = cmul_tw<DIR>(O[c], tw2[c - 1]);
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
+    compiler_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
+    compiler_fence();
+    // pass 3
+    radix8<DIR>(E);
+    radix8<DIR>(O);
+    compiler_fence(); // the tile's next writer stays behind these reads
+}
+
 // fft512_pair with ONE 8 KiB exchange image for both transforms — the form that fits two waves per
 // SIMD (blind_rotate2p_kernel: 256 registers, 8 KiB of LDS per wave).  A wave's DS instructions execute
 // in issue order, so the two transforms can take turns on the same image as long as the program
@@ -482,6 +548,16 @@ __device__ __forceinline__ uint64_t f64_bigint_to_torus_bits(double v, uint32_t&
 }
 
 // untwist_to_torus with the integer conversion on the fast path
+__device__ __forceinline__ void torus_bits16(const double (&tv)[16], uint64_t (&t)[16])
+{
+    uint32_t sh_or = 0, qmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < 16; e++) t[e] = f64_bigint_to_torus_bits(tv[e], sh_or, qmin);
+    if (!__all(sh_or < 64u && qmin != 0u)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) t[e] = f64_round_to_torus(tv[e]);
+    }
+}
 __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64* twist_lds, uint64_t (&t)[16])
 {
     double tv[16];
@@ -492,13 +568,20 @@ __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c
         tv[n1] = u.re;
         tv[8 + n1] = u.im;
     }
-    uint32_t sh_or = 0, qmin = 0xFFFFFFFFu;
+    torus_bits16(tv, t);
+}
+// the same with the twist factors held in registers (the latency kernels)
+__device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64 (&twist)[8], uint64_t (&t)[16])
+{
+    double tv[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) t[e] = f64_bigint_to_torus_bits(tv[e], sh_or, qmin);
-    if (!__all(sh_or < 64u && qmin != 0u)) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) t[e] = f64_round_to_torus(tv[e]);
+    for (int n1 = 0; n1 < 8; n1++) {
+        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        c64 u = cmul_nf_conj(xs, twist[n1]);
+        tv[n1] = u.re;
+        tv[8 + n1] = u.im;
     }
+    torus_bits16(tv, t);
 }
 
 // ---- pieces shared by the latency-shape kernels (blind_rotate2w / blind_rotate4 / cmux4) ----------

@@ -230,8 +230,9 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     }
 #ifdef SPF_STAMPS
     static uint64_t* d_stamps = nullptr;
-    const size_t n_stamp = (size_t)grid.x * 8 * 16;
-    if (cts == 4) {
+    const size_t stamp_waves = quad ? 4 : 8;
+    const size_t n_stamp = (size_t)grid.x * stamp_waves * 16;
+    if (cts == 4 || quad) {
         if (d_stamps) (void)hipFree(d_stamps);
         HIPCHK(c, hipMalloc(&d_stamps, n_stamp * 8));
         HIPCHK(c, hipMemsetAsync(d_stamps, 0, n_stamp * 8, s));
@@ -270,13 +271,16 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         static const char* names[12] = {"stage+rendezvous", "gather+decomp+twist", "rendezvous(gathered)", "fwd transform pair",
             "cross write+key barrier", "cross read+combine", "MAD x2", "ring barrier", "inverse cross exchange",
             "inv transform pair", "untwist+convert+acc", "step head"};
+        static const char* names4[12] = {"key issue+stage+barrier1", "gather+decomp+twist", "barrier2", "fwd transform pair",
+            "cross write+barrier3", "cross read+combine", "barrier4+swap write+barrier5", "sibling read+MAD", "barriers6-8+inverse cross",
+            "inv transform", "untwist+convert+acc", "-"};
         double total = 0;
         std::vector<double> med(12), med_old(12), med_young(12);
         for (int i = 0; i < 12; i++) {
             std::vector<uint64_t> v, vo, vy;
-            for (size_t wv = 0; wv < (size_t)grid.x * 8; wv++) {
+            for (size_t wv = 0; wv < (size_t)grid.x * stamp_waves; wv++) {
                 v.push_back(h[wv * 16 + i]);
-                ((wv & 7) < 4 ? vo : vy).push_back(h[wv * 16 + i]);
+                ((wv % stamp_waves) < stamp_waves / 2 ? vo : vy).push_back(h[wv * 16 + i]);
             }
             std::sort(v.begin(), v.end());
             std::sort(vo.begin(), vo.end());
@@ -286,9 +290,9 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
             med_young[i] = (double)vy[vy.size() / 2] / a.n;
             total += med[i];
         }
-        fprintf(stderr, "[stamps] per CMUX step, median over %zu waves (cycles, share | waves 0-3 | waves 4-7)\n", (size_t)grid.x * 8);
+        fprintf(stderr, "[stamps] per CMUX step, median over %zu waves (cycles, share | waves 0-3 | waves 4-7)\n", (size_t)grid.x * stamp_waves);
         for (int i = 0; i < 12; i++)
-            fprintf(stderr, "[stamps] %-26s %8.0f %5.1f%% | %8.0f | %8.0f\n", names[i], med[i], 100.0 * med[i] / total, med_old[i], med_young[i]);
+            fprintf(stderr, "[stamps] %-30s %8.0f %5.1f%% | %8.0f | %8.0f\n", (quad ? names4 : names)[i], med[i], 100.0 * med[i] / total, med_old[i], med_young[i]);
         fprintf(stderr, "[stamps] %-26s %8.0f\n", "total", total);
     }
 #endif

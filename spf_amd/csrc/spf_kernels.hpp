@@ -16,6 +16,7 @@
 //   entities/polynomial.rs:171-236 monomial rotation, :257-274 fft
 //   entities/polynomial_fft.rs:82-99 ifft, math/simd/scalar.rs:12-35,75-119
 #pragma once
+#include <type_traits>
 #include "spf_device.hpp"
 
 namespace spf {
@@ -1183,16 +1184,17 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
 // (eight per step); keys go straight from L2 into registers as in blind_rotate2w_kernel.
 constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192;
 
-template <int L, int LOGB>
-__global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a)
+template <int L, int LOGB, int W>
+__device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, char* smem)
 {
     static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & 1, h = wv >> 1;
+    constexpr int w = W; // sample parity: compile-time (one copy of the body per parity), so that which half of a
+                         // cross exchange a wave keeps is static instead of ~160 v_cndmask per step
+    const int h = wv >> 1;
     // region of wave (w, h): two 8 KiB images
     auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 16384; };
     char* mine = region(w, h);
@@ -1232,41 +1234,62 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 #pragma unroll
     for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
 
+#ifdef SPF_STAMPS
+    uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP4(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP4(i) do { } while (0)
+#endif
+    // this wave's bins of OUTPUT polynomial h in all four key rows of a step (levels consumed in reverse):
+    // [row polynomial p][digit j][r].  32 KiB per wave and step, 128 KiB per CU: about 4 500 cycles of the CU's
+    // L2 path (~30 B/clk), and a wave that asks for all of it in one place spends 2 000-3 000 cycles waiting to
+    // issue.  So the rows of step s+1 are requested in eight pieces of four loads, spread from behind the MADs
+    // of step s (which free the registers) to the transform of step s+1.
+    c64 key[2][2][8];
+    const c64* key_base = a.bsk + h * kHalf + 256 * w + lane;
+    const c64* key_next = key_base; // rows of the step whose pieces are being requested
+    auto request_keys = [&](auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        constexpr int p = piece >> 2, j = (piece >> 1) & 1, r0 = 4 * (piece & 1);
+        const c64* row = key_next + (size_t)(p * L + (L - 1 - j)) * (2 * kHalf);
+#pragma unroll
+        for (int r = r0; r < r0 + 4; r++) key[p][j][r] = row[64 * (r & 3) + 512 * (r >> 2)];
+    };
+#define SPF_KEY_PIECE(i) request_keys(std::integral_constant<int, i>{})
+    SPF_KEY_PIECE(0); SPF_KEY_PIECE(1); SPF_KEY_PIECE(2); SPF_KEY_PIECE(3); SPF_KEY_PIECE(4);
     uint64_t a_next = lwe[0];
     for (uint32_t step = 0; step < a.n; step++) {
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
+        SPF_KEY_PIECE(5);
 
-        // this wave's bins of OUTPUT polynomial h in all four key rows (levels consumed in reverse):
-        // [row polynomial p][digit j][r]
-        c64 key[2][2][8];
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const c64* row = a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf) + h * kHalf + 256 * w + lane;
-#pragma unroll
-                for (int r = 0; r < 8; r++) key[p][j][r] = row[64 * (r & 3) + 512 * (r >> 2)];
-            }
 
         // ---- rotate, subtract, decompose polynomial h
         uint64_t* stage = reinterpret_cast<uint64_t*>(mine);
 #pragma unroll
         for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
         wg_barrier(); // 1: both parities of both polynomials staged
+        STAMP4(0);
+        SPF_KEY_PIECE(6);
         uint32_t dig[16];
         {
+            // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024 for
+            // e >= 8): region (parity) and the low address bits do not depend on e
+            const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
+            const char* src = region((int)(t0 & 1), h);
             uint64_t gin[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint32_t srcc = ((uint32_t)coef2(e) + 2 * kN - at) & (kN - 1);
-                gin[e] = reinterpret_cast<const uint64_t*>(region((int)(srcc & 1), h))[srcc >> 1];
+                const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
+                gin[e] = *reinterpret_cast<const uint64_t*>(src + ((t << 2) & 0x1FF8u));
             }
             compiler_fence();
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
-                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - gin[e] : gin[e];
+                const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
+                const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
+                const uint64_t rot = (gin[e] ^ sgn) - sgn;
                 dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[e]);
             }
         }
@@ -1275,8 +1298,12 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
+        SPF_KEY_PIECE(7);
+        STAMP4(1);
         wg_barrier(); // 2: everyone is done gathering; the images are free
-        fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
+        STAMP4(2);
+        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane);
+        STAMP4(3);
         // radix-2 stage across the parities, both digits in one exchange
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -1285,6 +1312,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
                 reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? VV[j][4 + i].re : VV[j][i].re,
                                                                          w == 0 ? VV[j][4 + i].im : VV[j][i].im};
         wg_barrier(); // 3
+        STAMP4(4);
         {
             c64 xin[2][4];
 #pragma unroll
@@ -1308,6 +1336,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
                 for (int r = 0; r < 8; r++) VV[j][r] = X[r];
             }
         }
+        STAMP4(5);
         wg_barrier(); // 4: cross reads retired; the regions can carry the transforms
 
         // ---- multiply-accumulate.  prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q, in this
@@ -1318,30 +1347,38 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 #pragma unroll
             for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(j * 8 + r) * 64 + lane] = VV[j][r];
         wg_barrier(); // 5: every wave's two transforms are in its region
-        c64 SX[2][8]; // the sibling's transforms: polynomial 1 - h, same parity
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) SX[j][r] = reinterpret_cast<const c64*>(sibling)[(j * 8 + r) * 64 + lane];
-        compiler_fence();
+        STAMP4(6);
         c64 V[8]; // prod[h]
 #pragma unroll
         for (int r = 0; r < 8; r++) V[r] = {0.0, 0.0};
 #pragma unroll
-        for (int p = 0; p < 2; p++)
+        for (int p = 0; p < 2; p++) {
+            // row polynomial p: this wave's own transforms when p == h, the sibling's otherwise — both read back
+            // from LDS (16 more ds_read_b128 instead of 128 v_cndmask per step)
+            const c64* sx = reinterpret_cast<const c64*>(region(w, p)) + lane;
+            c64 X[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) X[j][r] = sx[(j * 8 + r) * 64];
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const c64 k = key[p][j][r];
-                    // row polynomial p: my own transform when p == h, the sibling's otherwise
-                    const c64 x = {p == h ? VV[j][r].re : SX[j][r].re, p == h ? VV[j][r].im : SX[j][r].im};
+                    const c64 x = X[j][r];
                     double re = __builtin_fma(k.re, x.re, V[r].re);
                     double im = __builtin_fma(k.re, x.im, V[r].im);
                     V[r].re = __builtin_fma(-k.im, x.im, re);
                     V[r].im = __builtin_fma(k.im, x.re, im);
                 }
+        }
+        // the last step re-requests its own rows
+        key_next = key_base + (size_t)(step + 1 < a.n ? step + 1 : step) * (2 * L) * (2 * kHalf);
+        SPF_KEY_PIECE(0);
+        STAMP4(7);
         wg_barrier(); // 6: sibling reads retired; regions free again
+        SPF_KEY_PIECE(1);
 
         // ---- polynomial h back to the torus
         {
@@ -1355,6 +1392,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
             for (int i = 0; i < 4; i++)
                 reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
             wg_barrier(); // 7
+            SPF_KEY_PIECE(2);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
@@ -1363,16 +1401,29 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
             }
             wg_barrier(); // 8: cross reads retired before the images are overwritten
         }
+        STAMP4(8);
+        SPF_KEY_PIECE(3);
         fft512_single<-1, 7>(V, mine, tab, lane);
+        STAMP4(9);
+        SPF_KEY_PIECE(4);
         {
             uint64_t t[16];
-            untwist_to_torus(V, twist, t);
+            untwist_to_torus_bits(V, twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] += t[e];
         }
+        STAMP4(10);
         // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
     }
 
+#ifdef SPF_STAMPS
+    if (a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + i] = st_acc[i];
+    }
+#endif
+#undef STAMP4
+#undef SPF_KEY_PIECE
     uint64_t* out = a.out + (size_t)ct * a.out_stride;
     if (!a.sample_extract) {
 #pragma unroll
@@ -1388,6 +1439,15 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
             }
         }
     }
+}
+
+// one copy of the body per sample parity (see blind_rotate2p_kernel)
+template <int L, int LOGB>
+__global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate4_body<L, LOGB, 1>(a, smem);
+    else blind_rotate4_body<L, LOGB, 0>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
