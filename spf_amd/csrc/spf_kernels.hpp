@@ -1710,16 +1710,16 @@ __global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
 // forward transforms.  Same operations in the same order on every value as cmux_kernel: same words.
 constexpr int kCmux4Lds = kTableBytes + 4 * 4 * 8192;
 
-template <int L, int LOGB>
-__global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
+template <int L, int LOGB, int W>
+__device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
 {
     static_assert(L == 4 && L * LOGB <= 32, "four digits, processed as two pairs");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & 1, h = wv >> 1;
+    constexpr int w = W; // sample parity: one copy of the body per parity (see blind_rotate4_kernel)
+    const int h = wv >> 1;
     // region of wave (w, h): 32 KiB = two exchange images while transforming, then its four transforms
     auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 32768; };
     char* mine = region(w, h);
@@ -1794,7 +1794,7 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) X[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
         if (jj) wg_barrier(); // partner is done with my last cross data
-        fft512_pair<+1>(X[jj], X[jj + 1], mine, mineB, tab, lane);
+        fft512_pair_pipelined<+1>(X[jj], X[jj + 1], mine, mineB, tab, lane);
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -1885,9 +1885,17 @@ __global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
     for (int e = 0; e < 16; e++) d0w[e] = gd0[coef2(e)];
     fft512_single<-1, 7>(V, mine, tab, lane);
     uint64_t t[16];
-    untwist_to_torus(V, twist, t);
+    untwist_to_torus_bits(V, twist, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) gout[coef2(e)] = (d0_zero ? 0 : d0w[e]) + t[e];
+}
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(256, 1) void cmux4_kernel(CmuxArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cmux4_body<L, LOGB, 1>(a, smem);
+    else cmux4_body<L, LOGB, 0>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
