@@ -1175,14 +1175,16 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
 // counts.  Wave (w, h): sample parity w (as in the two-wave kernels) and polynomial h.  The two
 // polynomials of a CMUX step are independent until the multiply-accumulate, so the pair h = 0 and
 // the pair h = 1 each rotate, decompose and transform ONE polynomial (both digits together,
-// `fft512_pair`) at the same time, and each transforms ONE output polynomial back.  The accumulation
+// `fft512_pair_pipelined`) at the same time, and each transforms ONE output polynomial back.  The accumulation
 //   prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q          (in this order, each term 4 FMAs)
 // stays the sequential chain the reference's `glwe_ggsw_mad` defines: the two pairs swap their
 // transforms through LDS and wave (w, h) then runs the whole chain of OUTPUT polynomial q = h (its
 // own transforms for the rows of polynomial h, the sibling's for the others).  Same operations in
 // the same order on every value: same words.  All hand-overs are s_barrier among the four waves
-// (eight per step); keys go straight from L2 into registers as in blind_rotate2w_kernel.
-constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192;
+// (four per step: staged, cross data out, spectra out, inverse cross data out — each LDS region has one
+// use per step, so nothing waits for "reads retired"); keys go straight from L2 into registers, requested
+// a step ahead.  The whole 160 KiB of LDS: twiddles, 4 x 2 exchange images, 4 staging / spectra regions.
+constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192 + 4 * 16384; // exchange images + staging / spectra regions
 
 template <int L, int LOGB, int W>
 __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, char* smem)
@@ -1200,7 +1202,10 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
     char* mine = region(w, h);
     char* mineB = mine + 8192;
     char* partner = region(w ^ 1, h); // same polynomial, other parity
-    char* sibling = region(w, h ^ 1); // same parity, other polynomial
+    // second region of wave (w, h), 16 KiB: its staged accumulator (rotation source) at the top of a step, its two
+    // transforms for the MADs later.  Having it apart from the exchange images is what lets a step do with four
+    // barriers instead of eight: no image is reused while someone may still read it.
+    auto spectra = [&](int ww, int hh) -> char* { return smem + kTableBytes + 4 * 16384 + (hh * 2 + ww) * 16384; };
     auto wg_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // not __syncthreads(): keep the key loads in flight
         __builtin_amdgcn_s_barrier();
@@ -1266,7 +1271,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
 
 
         // ---- rotate, subtract, decompose polynomial h
-        uint64_t* stage = reinterpret_cast<uint64_t*>(mine);
+        uint64_t* stage = reinterpret_cast<uint64_t*>(spectra(w, h));
 #pragma unroll
         for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
         wg_barrier(); // 1: both parities of both polynomials staged
@@ -1277,7 +1282,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024 for
             // e >= 8): region (parity) and the low address bits do not depend on e
             const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
-            const char* src = region((int)(t0 & 1), h);
+            const char* src = spectra((int)(t0 & 1), h);
             uint64_t gin[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -1300,9 +1305,8 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
         SPF_KEY_PIECE(7);
         STAMP4(1);
-        wg_barrier(); // 2: everyone is done gathering; the images are free
         STAMP4(2);
-        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane);
+        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane); // exchange 2 in registers (XP): 4.03 -> 3.98 ms, not worth a third form
         STAMP4(3);
         // radix-2 stage across the parities, both digits in one exchange
 #pragma unroll
@@ -1337,7 +1341,6 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             }
         }
         STAMP4(5);
-        wg_barrier(); // 4: cross reads retired; the regions can carry the transforms
 
         // ---- multiply-accumulate.  prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q, in this
         // order (glwe_ggsw_mad): the two pairs swap their transforms through LDS, then wave (w, h)
@@ -1345,8 +1348,8 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(j * 8 + r) * 64 + lane] = VV[j][r];
-        wg_barrier(); // 5: every wave's two transforms are in its region
+            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(spectra(w, h))[(j * 8 + r) * 64 + lane] = VV[j][r];
+        wg_barrier(); // 5: every wave's two transforms are in its region (the gathers from it ended before barrier 3)
         STAMP4(6);
         c64 V[8]; // prod[h]
 #pragma unroll
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         for (int p = 0; p < 2; p++) {
             // row polynomial p: this wave's own transforms when p == h, the sibling's otherwise — both read back
             // from LDS (16 more ds_read_b128 instead of 128 v_cndmask per step)
-            const c64* sx = reinterpret_cast<const c64*>(region(w, p)) + lane;
+            const c64* sx = reinterpret_cast<const c64*>(spectra(w, p)) + lane;
             c64 X[2][8];
 #pragma unroll
             for (int j = 0; j < 2; j++)
@@ -1377,7 +1380,6 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         key_next = key_base + (size_t)(step + 1 < a.n ? step + 1 : step) * (2 * L) * (2 * kHalf);
         SPF_KEY_PIECE(0);
         STAMP4(7);
-        wg_barrier(); // 6: sibling reads retired; regions free again
         SPF_KEY_PIECE(1);
 
         // ---- polynomial h back to the torus
@@ -1399,11 +1401,10 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                 V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
                 V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
             }
-            wg_barrier(); // 8: cross reads retired before the images are overwritten
         }
         STAMP4(8);
         SPF_KEY_PIECE(3);
-        fft512_single<-1, 7>(V, mine, tab, lane);
+        fft512_single<-1, 7>(V, mineB, tab, lane); // image B: the partner may still be reading the cross data in A
         STAMP4(9);
         SPF_KEY_PIECE(4);
         {
