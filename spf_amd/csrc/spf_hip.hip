@@ -773,6 +773,36 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 {
     static const int quad_mode = [] { const char* e = getenv("SPF_CMUX4"); return e ? e[0] - '0' : 1; }();
     if (quad_mode == 2 || (quad_mode == 1 && a.B <= (uint32_t)c->n_cu)) {
+#ifdef SPF_STAMPS
+        // diagnostic build: per-phase cycles of the first few cmux4 launches (median over waves)
+        static int reported = 0;
+        static uint64_t* d_st = nullptr;
+        if (reported < 6 && a.B <= 256) {
+            if (!d_st) (void)hipMalloc(&d_st, 256 * 4 * 16 * 8);
+            (void)hipMemsetAsync(d_st, 0, 256 * 4 * 16 * 8, s);
+            CmuxArgs b = a;
+            b.stamps = d_st;
+            hipLaunchKernelGGL((cmux4_kernel<4, 4>), dim3(a.B), dim3(256), kCmux4Lds, s, b);
+            (void)hipStreamSynchronize(s);
+            std::vector<uint64_t> h((size_t)a.B * 4 * 16);
+            (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+            static const char* nm[9] = {"entry: pointers, loads issued, table copy", "barrier (table in place)", "twist tables to registers",
+                "decompose + 2 x (transform pair, cross)", "key1 issue + spectra out + 2 barriers", "8-row accumulation chain",
+                "inverse cross (3 barriers)", "inverse transform + untwist + store issue", "store drain"};
+            fprintf(stderr, "[cmux4 stamps] B=%u\n", a.B);
+            double tot = 0;
+            for (int i = 0; i < 9; i++) {
+                std::vector<uint64_t> v;
+                for (size_t wv = 0; wv < (size_t)a.B * 4; wv++) v.push_back(h[wv * 16 + i]);
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "[cmux4 stamps] %-44s %8llu\n", nm[i], (unsigned long long)v[v.size() / 2]);
+                tot += (double)v[v.size() / 2];
+            }
+            fprintf(stderr, "[cmux4 stamps] total %.0f cycles\n", tot);
+            reported++;
+            return;
+        }
+#endif
         hipLaunchKernelGGL((cmux4_kernel<4, 4>), dim3(a.B), dim3(256), kCmux4Lds, s, a);
     } else {
         // two gates per workgroup, two workgroups per CU: the same eight waves as one workgroup of four gates, but

@@ -1472,6 +1472,7 @@ struct CmuxArgs {
     // Scattered operands (the graph executor, spf_graph.hpp): when non-null, unit u takes
     // {ggsw, d0 (null = zero ciphertext), d1, out} from ptrs[4u .. 4u+3] instead of the arrays above.
     const void* const* ptrs;
+    uint64_t* stamps;     // diagnostic builds (-DSPF_STAMPS): per-phase cycle counts of cmux4_kernel, else null
 };
 constexpr int cmux_lds_bytes(int gates) { return kTableBytes + gates * kWaveBufBytes + 64; }
 
@@ -1721,6 +1722,13 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int w = W; // sample parity: one copy of the body per parity (see blind_rotate4_kernel)
     const int h = wv >> 1;
+#ifdef SPF_STAMPS
+    uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMPC(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMPC(i) do { } while (0)
+#endif
     // region of wave (w, h): 32 KiB = two exchange images while transforming, then its four transforms
     auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 32768; };
     char* mine = region(w, h);
@@ -1732,6 +1740,19 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
         asm volatile("" ::: "memory");
     };
     const uint32_t ct = blockIdx.x; // grid = units
+    // Load order = need order, because vmcnt retires in issue order: the twiddle image first (it does not depend on
+    // the operand table), then d1 / d0 (the decomposition waits for them), the selector rows last (the accumulation
+    // chain is far away) — requested the other way round the decomposition waited for 32 KiB of selector per wave.
+    constexpr int kTabPerThread = (kTableEntries + 255) / 256;
+    f64x2_t tab_img[kTabPerThread];
+    {
+        const f64x2_t* src = reinterpret_cast<const f64x2_t*>(a.tables);
+#pragma unroll
+        for (int i = 0; i < kTabPerThread; i++) {
+            const int idx = tid + 256 * i;
+            tab_img[i] = src[idx < kTableEntries ? idx : kTableEntries - 1];
+        }
+    }
     const c64* ggsw;
     const uint64_t *d0, *d1;
     uint64_t* out_ct;
@@ -1761,31 +1782,39 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
 #pragma unroll
         for (int r = 0; r < 8; r++) k[r] = gload(row + 64 * (r & 3) + 512 * (r >> 2));
     };
+    // d0 aliases d1 when it is the zero ciphertext, so its loads need no branch
+    uint64_t x1[16], x0[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) x1[e] = gd1[coef2(e)];
+#pragma unroll
+    for (int e = 0; e < 16; e++) x0[e] = gd0[coef2(e)];
+    compiler_fence();
+    {
+        f64x2_t* dst = reinterpret_cast<f64x2_t*>(smem);
+#pragma unroll
+        for (int i = 0; i < kTabPerThread; i++) {
+            const int idx = tid + 256 * i;
+            if (idx < kTableEntries) dst[idx] = tab_img[i];
+        }
+    }
+    compiler_fence();
     c64 key0[L][8], key1[L][8];
 #pragma unroll
     for (int j = 0; j < L; j++) load_row(key0[j], 0, j);
-
-    uint32_t dig[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int c = coef2(e);
-        // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168), then the gadget digits; d0 aliases d1 when it
-        // is the zero ciphertext, so the load needs no branch
-        const uint64_t x1 = gd1[c], x0 = gd0[c];
-        dig[e] = gadget_digits_packed<L, LOGB>(x1 - (d0_zero ? 0 : x0));
-    }
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
-    }
+    STAMPC(0);
     wg_barrier(); // twiddle image in place
+    STAMPC(1);
     c64 twist[8], wc[4];
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
 #pragma unroll
     for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
 
+    STAMPC(2);
+    uint32_t dig[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168), then the gadget digits
+        dig[e] = gadget_digits_packed<L, LOGB>(x1[e] - (d0_zero ? 0 : x0[e]));
     // ---- the four digit transforms of polynomial h, two at a time
     c64 X[L][8];
 #pragma unroll
@@ -1825,14 +1854,18 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
             for (int r = 0; r < 8; r++) X[jj + j][r] = Y[r];
         }
     }
-#pragma unroll
-    for (int j = 0; j < L; j++) load_row(key1[j], 1, j); // the last four rows, behind the transforms
+    STAMPC(3);
     wg_barrier(); // cross reads retired: the regions can carry the transforms
+    // spectra out, and behind each one — into the registers it frees — the matching one of the last four selector
+    // rows: the 32 requests trickle into the vector-memory queue between the LDS stores instead of stalling in a block
 #pragma unroll
-    for (int j = 0; j < L; j++)
+    for (int j = 0; j < L; j++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(mine)[(j * 8 + r) * 64 + lane] = X[j][r];
+        load_row(key1[j], 1, j);
+    }
     wg_barrier(); // every wave's four transforms are in its region
+    STAMPC(4);
 
     // ---- accumulation chain of output polynomial h: rows (0, j = 0..3) then (1, j = 0..3)
     c64 V[8];
@@ -1858,6 +1891,7 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
                 V[r].im = __builtin_fma(k.im, x.re, im);
             }
         }
+    STAMPC(5);
     wg_barrier(); // sibling reads retired; regions free again
 
     // ---- polynomial h back to the torus, plus d0
@@ -1884,11 +1918,23 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
     uint64_t d0w[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) d0w[e] = gd0[coef2(e)];
+    STAMPC(6);
     fft512_single<-1, 7>(V, mine, tab, lane);
     uint64_t t[16];
     untwist_to_torus_bits(V, twist, t);
 #pragma unroll
     for (int e = 0; e < 16; e++) gout[coef2(e)] = (d0_zero ? 0 : d0w[e]) + t[e];
+    STAMPC(7);
+#ifdef SPF_STAMPS
+    if (a.stamps && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // count the stores' drain
+        const uint64_t t_end = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + i] = st_acc[i];
+        a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + 8] = t_end - st_prev;
+    }
+#endif
+#undef STAMPC
 }
 
 template <int L, int LOGB>
