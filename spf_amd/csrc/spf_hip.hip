@@ -219,7 +219,9 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     const int cts = cts_override ? cts_override : (B <= 2 * n_cu ? (wide ? 1 : (B <= n_cu ? 1 : 2)) : 4);
     // at most one ciphertext per CU: four waves per ciphertext (blind_rotate4_kernel); SPF_QUAD=0 disables
     static const bool quad_on = [] { const char* e = getenv("SPF_QUAD"); return !(e && e[0] == '0'); }();
-    const bool quad = variant == 2 && wide && quad_on && !cts_override && B <= n_cu;
+    // ... and again from 1.2 to 2 ciphertexts per CU, as two rounds of workgroups (2 x 4.0 ms against 8.5 ms of the
+    // two-wave latency schedule; below 1.2 the second round would be mostly empty and blind_rotate2w_kernel wins)
+    const bool quad = variant == 2 && wide && quad_on && !cts_override && (B <= n_cu || (10 * B > 12 * n_cu && B <= 2 * n_cu));
     const size_t per_wg = variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock;
     dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? (quad ? 256 : 128 * cts) : 256);
     TimedLaunch tl{};
