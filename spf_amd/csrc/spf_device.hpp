@@ -157,8 +157,7 @@ __device__ __forceinline__ void sched_fence()
 // being issued one or two at a time right where they are needed (what the compiler does by itself to
 // save registers: about five exposed LDS round trips per pass).  Costs 4 PRE live VGPRs across the
 // radix-8; the kernels pick what their register budget allows.
-__device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8]); // below
-template <int DIR, int PRE = 0, bool XP = false> // XP: exchange 2 in registers instead of through the image
+template <int DIR, int PRE = 0>
 __device__ __forceinline__ void fft512_single(c64 (&V)[8], char* buf, const c64* tab, int lane)
 {
     const int hi3 = lane >> 3, lo3 = lane & 7;
@@ -190,16 +189,12 @@ __device__ __forceinline__ void fft512_single(c64 (&V)[8], char* buf, const c64*
             V[c] = cmul_tw<DIR>(V[c], (c - 1 < PRE) ? tw[c - 1 < PRE ? c - 1 : 0] : tab[kT2Off + (c - 1) * 8 + hi3]);
     }
     compiler_fence();
-    if constexpr (XP) {
-        lane_transpose_hi3(V); // exchange 2 in registers
-    } else {
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = V[c];
-        wave_lds_fence();
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = V[c];
+    wave_lds_fence();
 #pragma unroll
-        for (int b = 0; b < 8; b++) V[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
-    }
+    for (int b = 0; b < 8; b++) V[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
     radix8<DIR>(V);
     compiler_fence();
 }
@@ -343,13 +338,12 @@ __device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8])
 // (measured 5 774 vs 2 707 cycles).  A wave's DS instructions execute in issue order, so a read issued
 // behind the writes of the same image needs no drain: every exchange of one transform is issued and then
 // left in flight under a radix-8 pass of the other.  Same butterflies on the same values: same words.
-// XP: exchange 2 in registers (`lane_transpose_hi3`) for 0 none / 1 both / 2 only O — trades the LDS store path,
-// which the four waves of a CU share (13 cycles per ds_write_b128), against 80 32-bit VALU instructions.
-template <int DIR, int XP = 0>
+// (Exchange 2 in registers, `lane_transpose_hi3` as in fft512_pair1, trades the LDS store path the four waves of a CU
+// share against 80 32-bit VALU instructions per transform: 4.03 -> 3.98 ms on blind_rotate4_kernel, not kept.)
+template <int DIR>
 __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], char* bufE, char* bufO,
                                                       const c64* tab, int lane)
 {
-    constexpr bool XE = XP == 1, XO = XP == 1 || XP == 2;
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
     c64 tw1[7], tw2[7];
@@ -383,37 +377,27 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     radix8<DIR>(E);
 #pragma unroll
     for (int c = 1; c < 8; c++) E[c] = cmul_tw<DIR>(E[c], tw2[c - 1]);
-    if constexpr (XE) {
-        lane_transpose_hi3(E);
-    } else {
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
-        compiler_fence();
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
+    compiler_fence();
 #pragma unroll
-        for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
-        compiler_fence();
-    }
+    for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
+    compiler_fence();
     // O pass 2 (E's reads in flight)
     radix8<DIR>(O);
 #pragma unroll
     for (int c = 1; c < 8; c++) O[c] = cmul_tw<DIR>(O[c], tw2[c - 1]);
-    if constexpr (XO) {
-        radix8<DIR>(E); // pass 3 of E
-        lane_transpose_hi3(O);
-        radix8<DIR>(O);
-    } else {
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
-        compiler_fence();
+    for (int c = 0; c < 8; c++)
+        *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
+    compiler_fence();
 #pragma unroll
-        for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
-        compiler_fence();
-        // pass 3
-        radix8<DIR>(E);
-        radix8<DIR>(O);
-    }
+    for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
+    compiler_fence();
+    // pass 3
+    radix8<DIR>(E);
+    radix8<DIR>(O);
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 

@@ -1306,7 +1306,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         SPF_KEY_PIECE(7);
         STAMP4(1);
         STAMP4(2);
-        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane); // exchange 2 in registers (XP): 4.03 -> 3.98 ms, not worth a third form
+        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane);
         STAMP4(3);
         // radix-2 stage across the parities, both digits in one exchange
 #pragma unroll
