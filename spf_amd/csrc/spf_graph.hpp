@@ -240,20 +240,32 @@ inline spf_status plan(spf_graph* g)
             const size_t per = gr.op == SPF_OP_GLEV_CMUX ? g->prm.cbs_radix_count : 1;
             const size_t gw = g->value_bytes(SPF_VAL_GLWE1);
             gr.ptr_index[0] = table.size();
+            struct Unit { void* p[4]; };
+            std::vector<Unit> units;
+            units.reserve(B * per);
             for (size_t i = 0; i < B; i++) {
                 const auto& n = g->nodes[gr.members[i]];
                 for (size_t j = 0; j < per; j++) {
-                    table.push_back(g->d_arena + g->nodes[n.in[0]].off);
+                    Unit u;
+                    u.p[0] = g->d_arena + g->nodes[n.in[0]].off;
                     if (gr.op == SPF_OP_MULTIPLY_GGSW_GLWE) {
-                        table.push_back(nullptr); // zero ciphertext
-                        table.push_back(g->d_arena + g->nodes[n.in[1]].off);
+                        u.p[1] = nullptr; // zero ciphertext
+                        u.p[2] = g->d_arena + g->nodes[n.in[1]].off;
                     } else {
-                        table.push_back(g->d_arena + g->nodes[n.in[1]].off + j * gw);
-                        table.push_back(g->d_arena + g->nodes[n.in[2]].off + j * gw);
+                        u.p[1] = g->d_arena + g->nodes[n.in[1]].off + j * gw;
+                        u.p[2] = g->d_arena + g->nodes[n.in[2]].off + j * gw;
                     }
-                    table.push_back(g->d_arena + n.off + j * gw);
+                    u.p[3] = g->d_arena + n.off + j * gw;
+                    units.push_back(u);
                 }
             }
+            // Units that select on the same GGSW go next to each other: a level of a mux_circuits block tests ONE
+            // variable (MuxCircuit::from(&[Bdd]), lib.rs:358-445), so a wide level is a handful of selectors with
+            // dozens of gates each, and neighbouring workgroups then hit the same 256 KiB in L2 (the streaming kernel
+            // does 17.3 M gates/s on four units per selector against 12.9 M/s on distinct ones).  Order inside a
+            // level is free: every unit carries its own output pointer.
+            std::stable_sort(units.begin(), units.end(), [](const Unit& x, const Unit& y) { return x.p[0] < y.p[0]; });
+            for (const Unit& u : units) for (void* q : u.p) table.push_back(q);
             continue;
         }
         for (int s = 0; s < info.arity; s++) {
