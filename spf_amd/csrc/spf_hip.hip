@@ -219,11 +219,16 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     const int cts = cts_override ? cts_override : (B <= 2 * n_cu ? (wide ? 1 : (B <= n_cu ? 1 : 2)) : 4);
     // at most one ciphertext per CU: four waves per ciphertext (blind_rotate4_kernel); SPF_QUAD=0 disables
     static const bool quad_on = [] { const char* e = getenv("SPF_QUAD"); return !(e && e[0] == '0'); }();
-    // ... and again from 1.2 to 2 ciphertexts per CU, as two rounds of workgroups (2 x 4.0 ms against 8.5 ms of the
-    // two-wave latency schedule; below 1.2 the second round would be mostly empty and blind_rotate2w_kernel wins)
-    const bool quad = variant == 2 && wide && quad_on && !cts_override && (B <= n_cu || (10 * B > 12 * n_cu && B <= 2 * n_cu));
-    const size_t per_wg = variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock;
-    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? (quad ? 256 : 128 * cts) : 256);
+    // SPF_MID picks the shape between one and two ciphertexts per CU: "pair" (default) = the paired throughput
+    // schedule with two ciphertexts per workgroup, "quad" = two rounds of the four-wave kernel (from 1.2 per CU),
+    // "wide" = blind_rotate2w_kernel
+    static const int mid = [] { const char* e = getenv("SPF_MID"); return !e ? 2 : (e[0] == 'q' ? 1 : (e[0] == 'w' ? 0 : 2)); }();
+    const bool between = B > n_cu && B <= 2 * n_cu && variant == 2 && wide && !cts_override;
+    const bool pair2 = between && mid == 2;
+    const bool quad = variant == 2 && wide && quad_on && !cts_override &&
+                      (B <= n_cu || (mid == 1 && 10 * B > 12 * n_cu && B <= 2 * n_cu));
+    const size_t per_wg = pair2 ? 2 : (variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock);
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? ((quad || pair2) ? 256 : 128 * cts) : 256);
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
@@ -245,6 +250,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     static const bool paired = [] { const char* e = getenv("SPF_PAIRED"); return !(e && e[0] == '0'); }();
 #define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
     if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16>), kBlindRotate4Lds);
+    else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,6>", (blind_rotate2p2_kernel<2, 16, 6>), kBlindRotate2p2Lds);
     else if (variant == 2 && cts == 4 && paired) {
         static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 6; }();
         switch (p_opt) {
@@ -477,6 +483,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
     SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(6);
 #undef SPF_P_ATTR
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 6>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),

@@ -864,7 +864,7 @@ constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlot
 // less).  Tried on this kernel and rejected (numbers in profiles/r02_experiments_blind_rotate.md): static and
 // alternating s_setprio for the younger SIMD partners, flat-polled and deferred pair rendezvous, and a
 // ping-pong schedule of the two ciphertext groups one slot apart.
-template <int L, int LOGB, int OPT, int W>
+template <int L, int LOGB, int OPT, int W, int CTS = 4>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
     constexpr int XP = (OPT & 1) ? 1 : ((OPT & 2) ? 2 : 0);
@@ -877,7 +877,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #define STAMP(i) do { } while (0)
 #endif
     static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
-    constexpr int NT = 512;
+    constexpr int NT = 128 * CTS; // CTS ciphertexts per workgroup, two waves each
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -887,7 +887,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
-    char* bskring = smem + kTableBytes + 4 * kWaveBufBytes;
+    char* bskring = smem + kTableBytes + CTS * kWaveBufBytes;
 
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
@@ -895,7 +895,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
         for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
     }
 
-    const uint32_t ct_raw = blockIdx.x * 4 + cslot;
+    const uint32_t ct_raw = blockIdx.x * CTS + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
     const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 8 + wv) * 16 + i] = st_acc[i];
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * (2 * CTS) + wv) * 16 + i] = st_acc[i];
     }
 #endif
 #undef STAMP
@@ -1167,6 +1167,18 @@ __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1>(a, smem);
     else blind_rotate2p_body<L, LOGB, OPT, 0>(a, smem);
+}
+
+// The same schedule with TWO ciphertexts per workgroup (four waves, one per SIMD, one workgroup per CU): for batches
+// between one and two ciphertexts per CU, where the four-ciphertext shape would leave CUs idle and the four-wave
+// latency kernel needs two rounds.  The pair shares each key chunk through the ring; same words.
+constexpr int kBlindRotate2p2Lds = kTableBytes + 2 * kWaveBufBytes + 2 * kBskSlotBytes;
+template <int L, int LOGB, int OPT>
+__global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 2>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0, 2>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
