@@ -29,8 +29,9 @@ def test_bench_line_has_the_contract_fields():
         assert key in roof, key
     # "fp64": the f64 work runs on the VALU, whose peak equals the MFMA-f64 peak (VERDICT r1 asked for the relabel)
     assert roof["bound"] in ("hbm", "mfma", "fp64") and 0.0 < roof["frac"] < 1.0
-    # the kernel named is the one that ran: 512 ciphertexts take the paired latency shape, not the throughput kernel
-    assert roof["kernel"].startswith("blind_rotate2w_kernel"), roof["kernel"]
+    # the kernel named is the one that ran: 512 ciphertexts (two per CU) take the two-ciphertext paired shape, not the
+    # four-ciphertext throughput kernel
+    assert roof["kernel"].startswith("blind_rotate2p2_kernel"), roof["kernel"]
     for leg in ("gate", "cmux", "circuit_bootstrap", "add32", "pcie_inclusive"):
         assert isinstance(d.get(leg), dict), leg
     assert d["pcie_inclusive"]["same_words_as_device_path"] is True
