@@ -1488,17 +1488,16 @@ struct CmuxArgs {
 };
 constexpr int cmux_lds_bytes(int gates) { return kTableBytes + gates * kWaveBufBytes + 64; }
 
-template <int L, int LOGB, int G>
-__global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
+template <int L, int LOGB, int G, int W>
+__device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 {
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cslot = wv >> 1;
-    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    constexpr int w = W; // sample parity: one copy of the body per parity (no branches that merge register arrays)
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
@@ -1649,65 +1648,73 @@ __global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
         for (int r = 0; r < 8; r++) k1[r] = gload(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
     }
 
+    // ---- both output polynomials back to the torus as ONE transform pair (`fft512_pair1`: each exchange of one
+    // transform travels under a butterfly pass of the other; one cross exchange, three hand-overs instead of five)
+    // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180): d_0 is re-read rather than held across the transforms,
+    // all words requested here so they land under the inverse transforms.  The lane index goes through an opaque
+    // move first: otherwise the 32 output / d_0 addresses are computed in the prologue and parked in scratch, and a
+    // kernel of thousands of short workgroups pays for every byte of scratch it declares (0.32 -> 0.40 ms per 4096).
+    int lane_late = lane;
+    asm volatile("" : "+v"(lane_late));
+    auto coef2_late = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane_late + w; };
+    uint64_t d0w[2][16];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        c64 Ep[4], Op[4], V[8];
-        // add_glwe_ciphertexts(c, prod, d_0) (fft_ops.rs:180): d_0 is re-read rather than held across the
-        // transforms, all sixteen words requested here so they land under the inverse transform
-        const gu64_ptr out = gout + q * kN;
-        const gu64_cptr base = gd0 + q * kN;
-        uint64_t d0w[16];
+    for (int q = 0; q < 2; q++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) d0w[e] = base[coef2(e)];
+        for (int e = 0; e < 16; e++) d0w[q][e] = gd0[q * kN + coef2_late(e)];
+    c64 WW[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            Ep[i] = cadd(prod[q][i], prod[q][i + 4]);
-            c64 dd = csub(prod[q][i], prod[q][i + 4]);
-            Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
+            WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                             // Ep: kept by wave 0
+            WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wc[64 * i]); // Op: kept by wave 1
         }
-        if (q == 0) cmux_sync();
-        if (w == 0) {
+    cmux_sync(); // partner is done with my last cross data
+    if constexpr (w == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
-        } else {
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
-        }
-        cmux_sync();
-        if (w == 0) {
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+    } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
-        } else {
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
-        }
-        cmux_sync();
-        fft512_single<-1>(V, mine, tab, lane);
-        double tv[16];
+            for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
+    }
+    cmux_sync();
+    if constexpr (w == 0) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; n1++) {
-            c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-            c64 t = cmul_nf_conj(xs, twist[64 * n1]);
-            tv[n1] = t.re;
-            tv[8 + n1] = t.im;
-        }
-        double mn = __builtin_fabs(tv[0]);
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-        for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-        if (__all(mn >= 4503599627370496.0)) {
+            for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+    } else {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint64_t v = (d0_zero ? 0 : d0w[e]) + f64_bigint_to_torus(tv[e]);
-                if (owns_output) out[coef2(e)] = v;
-            }
-        } else {
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint64_t v = (d0_zero ? 0 : d0w[e]) + f64_round_to_torus(tv[e]);
-                if (owns_output) out[coef2(e)] = v;
-            }
+            for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+    }
+    cmux_sync(); // both cross reads retired before either image is overwritten
+    fft512_pair1<-1, 2>(WW[0], WW[1], mine, tab, lane);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint64_t t[16];
+        untwist_to_torus_bits(WW[q], twist, t);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint64_t v = (d0_zero ? 0 : d0w[q][e]) + t[e];
+            if (owns_output) gout[q * kN + coef2_late(e)] = v;
         }
     }
+}
+
+template <int L, int LOGB, int G>
+__global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cmux_body<L, LOGB, G, 1>(a, smem);
+    else cmux_body<L, LOGB, G, 0>(a, smem);
+
 }
 
 // ------------------------------------------------------------------------------------------
