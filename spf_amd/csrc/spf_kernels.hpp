@@ -1659,9 +1659,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     auto coef2_late = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane_late + w; };
     uint64_t d0w[2][16];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) d0w[q][e] = gd0[q * kN + coef2_late(e)];
+    for (int e = 0; e < 16; e++) d0w[0][e] = gd0[coef2_late(e)];
     c64 WW[2][8];
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -1696,6 +1694,10 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     }
     cmux_sync(); // both cross reads retired before either image is overwritten
     fft512_pair1<-1, 2>(WW[0], WW[1], mine, tab, lane);
+    // (the second polynomial's words only now: all 32 across the transform pair do not fit the registers, and a
+    // spilled load waits for everything in flight; they land under the first polynomial's conversion)
+#pragma unroll
+    for (int e = 0; e < 16; e++) d0w[1][e] = gd0[kN + coef2_late(e)];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         uint64_t t[16];
