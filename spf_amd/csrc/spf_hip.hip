@@ -778,7 +778,7 @@ spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_
 }
 
 // At most one gate per CU: the four-waves-per-gate latency shape (a level of a gate graph); beyond
-// that four gates per workgroup, the streaming shape.  SPF_CMUX4=0 keeps the streaming shape.
+// that two (or four) gates per workgroup, the streaming shape.  SPF_CMUX4=0 keeps the streaming shape.
 static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 {
     static const int quad_mode = [] { const char* e = getenv("SPF_CMUX4"); return e ? e[0] - '0' : 1; }();

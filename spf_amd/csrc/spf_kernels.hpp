@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
 // the levels of a gate graph that hold at most one gate per CU (a ripple-carry chain is 1-4 gates per
 // level, and its depth, not its width, is what a run waits for).  Same split as blind_rotate4_kernel:
 // wave (w, h) = sample parity w x polynomial h.  Each pair of waves decomposes ONE polynomial of
-// d1 - d0 and pushes its four digits through two `fft512_pair`s; the pairs then publish their four
+// d1 - d0 and pushes its four digits through two `fft512_pair_pipelined`s; the pairs then publish their four
 // transforms in LDS and wave (w, h) runs the whole accumulation chain of OUTPUT polynomial h over the
 // eight rows in the reference's order (row polynomial 0 levels 3..0, then polynomial 1: fft_ops.rs:67-98
 // reversed GLEV rows) — its own transforms for the rows of polynomial h, the sibling's for the others —

@@ -266,7 +266,7 @@ def test_cmux_random_words_parity(small):
 @pytest.mark.parametrize("B", [255, 258, 301])
 def test_cmux_both_shapes_are_bit_equal(small, B):
     """At most one gate per CU runs cmux4_kernel (four waves per gate), larger batches the streaming
-    cmux_kernel (four gates per workgroup, ragged tail included).  Same words from both, and from the
+    cmux_kernel (two gates per workgroup, ragged tail included).  Same words from both, and from the
     oracle on a sample."""
     ks, eng = small
     P = ks.params
