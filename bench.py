@@ -29,14 +29,28 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PBS = 263.5e6          # 637 x 413 696 f64 flop
 FP64_PEAK_TFLOPS = 78.6         # MI355X dense FP64 (vector == matrix): 256 CU x 128 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
+INT8_MFMA_PEAK_TOPS = 5000.0    # dense int8 MFMA = 2 x the bf16 rate (MI355X_MICROARCH.md, Matrix cores)
+# cbs_trace_kernel, per circuit bootstrap: 4 gadget levels x 11 automorphism rounds x
+# (6 forward + 2 inverse FFT-1024 at 5*1024*10 flop, 12 pointwise MAD rows at 8*1024, 6 twists at 6*1024, 2 untwists at 8*1024)
+TRACE_FLOP_PER_CT = 4 * 11 * (8 * 51200 + 12 * 8192 + 6 * 6144 + 2 * 8192)
+# scheme_switch_kernel, per circuit bootstrap: 4 levels x (17 forward + 2 inverse FFT-1024, 30 MAD rows, 17 twists, 2 untwists)
+SCHEME_SWITCH_FLOP_PER_CT = 4 * (19 * 51200 + 30 * 8192 + 17 * 6144 + 2 * 8192)
 
 
-class _DevArray:
-    """zero-copy torch view of a raw device pointer (CUDA array interface)."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
-                                         "version": 3, "strides": None}
+def _self_launch(gpus: int) -> int:
+    """`python3 bench.py --gpus N` from a bare shell (no launcher, WORLD_SIZE unset): start the N ranks as CHILD
+    processes through torch.distributed.run and relay their output.  Nothing in this process has touched the GPU
+    (no torch import yet), and nothing is exec'ed: the children are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main() -> int:
@@ -62,18 +76,21 @@ def main() -> int:
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return _self_launch(args.gpus)
+
     import torch
     import torch.distributed as dist
 
     import spf_amd
-    from spf_amd.sharding import broadcast_keys, max_over_ranks
+    from spf_amd.sharding import _DevArray, key_blob_tensors, max_over_ranks, replicate_keys
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run "
-              f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: launch with torch.distributed.run "
+              f"--nproc-per-node {args.gpus}, or run `python3 bench.py --gpus {args.gpus}` by itself", file=sys.stderr)
         return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
@@ -107,10 +124,7 @@ def main() -> int:
     # ---- synthetic evaluation keys: generated on rank 0, RCCL-broadcast into every rank's HBM blob.
     # All four ComputeKey fields (bootstrap, keyswitch, automorphism, scheme switch: crypto/keys.rs:306-318).
     t_keys0 = time.time()
-    blobs = []
-    for which in (0, 1, 2, 3):
-        ptr, nbytes = eng.key_blob(which)
-        blobs.append(torch.as_tensor(_DevArray(ptr, nbytes), device=dev))
+    blobs = key_blob_tensors(eng, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0001)
     if rank == 0:
@@ -125,13 +139,14 @@ def main() -> int:
             blobs[which].copy_((torch.randn(n64, generator=g, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
     torch.cuda.synchronize()
     t_bcast0 = time.time()
+    # RCCL over xGMI, once: 83.5 MB + 62.7 MB + 2.2 MB + 0.5 MB; then every rank commits its replica
+    t_bcast, key_bytes = replicate_keys(eng, blobs, dist if world > 1 else None, src=0)
+    rccl = None
     if world > 1:
-        broadcast_keys(blobs, dist, src=0)   # RCCL over xGMI, once: 146 MB + 63 MB + 2.2 MB + 0.5 MB
-        torch.cuda.synchronize()
-    t_bcast = time.time() - t_bcast0
-    key_bytes = sum(int(b.numel()) for b in blobs)
-    for which in (0, 1, 2, 3):
-        eng.key_blob_commit(which)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "broadcast_s": round(t_bcast, 4), "broadcast_bytes": key_bytes,
+                "broadcast_GBs": round(key_bytes / max(t_bcast, 1e-9) / 1e9, 2),
+                "note": "first collective of the process group: includes communicator set-up"}
 
     # ---- synthetic ciphertext batch (uniform torus words; throughput is value-independent)
     B = args.batch
@@ -169,8 +184,26 @@ def main() -> int:
         dt = max_over_ranks(dt, dist, device=dev)
         kernel_ms_minmax = [-max_over_ranks(-kernel_ms, dist, device=dev), max_over_ranks(kernel_ms, dist, device=dev)]
 
-    gate = None
-    if args.with_keyswitch:
+    # ---- the other legs of the line.  Each is timed on its own rank between two LOCAL synchronisations (the ranks are
+    # independent: weak scaling, no data-path collective) and the MAX over ranks is taken once at the end, so that a
+    # leg that fails on one rank is reported in the line instead of leaving the others in a barrier.
+    leg_errors = {}
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 - reported in the line, never fatal for the headline
+            leg_errors[name] = f"{type(e).__name__}: {e}"[:300]
+            return None
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def restore_headline_output():
+        step()   # leave glwe_out holding the plain-PBS result for the parity sample below
+        sync()
+
+    def _gate():
         lwe1 = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.lwe1_words), generator=g, device=dev, dtype=torch.int64)
         mid = torch.empty((B, P.lwe0_words), device=dev, dtype=torch.int64)
 
@@ -179,77 +212,115 @@ def main() -> int:
             eng.circuit_bootstrap_pbs_dev(stream, B, mid.data_ptr(), glwe_out.data_ptr())
 
         gate_step()
-        barrier()
+        sync()
         eng.set_timing(True)
         tg = time.perf_counter()
         for _ in range(args.steps):
             gate_step()
-        barrier()
+        sync()
         tg = time.perf_counter() - tg
-        if world > 1:
-            tg = max_over_ranks(tg, dist, device=dev)
         ks_ms, _ = eng.last_kernel_ms("keyswitch")
         eng.last_kernel_ms("pbs")
         eng.set_timing(False)
         ks_ops = 2.0 * B * (P.glwe_size * P.polynomial_degree * P.ks_radix_count) * P.lwe0_words * 8   # int8 MACs x 2 over the 8 byte planes
-        gate = {"gates_per_s": round(world * B * args.steps / tg, 1), "keyswitch_kernel_ms": round(ks_ms, 4),
-                "keyswitch_int8_mfma_frac": round(ks_ops / (ks_ms * 1e-3) / 5.0e15, 4) if ks_ms else None}
-        # leave glwe_out holding the plain-PBS result for the parity sample below
-        step()
-        torch.cuda.synchronize()
+        ks_tops = ks_ops / (ks_ms * 1e-3) / 1e12 if ks_ms else None
+        return {"_seconds": tg, "_units": B * args.steps, "_rate_key": "gates_per_s",
+                "keyswitch_kernel_ms": round(ks_ms, 4),
+                "keyswitch_int8_mfma_frac": round(ks_tops / INT8_MFMA_PEAK_TOPS, 4) if ks_tops else None,
+                "keyswitch_roofline": {"bound": "mfma", "kernel": "ks_digits_kernel + ks_gemm_lds_kernel", "achieved": round(ks_tops, 1) if ks_tops else None,
+                                       "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8)",
+                                       "frac": round(ks_tops / INT8_MFMA_PEAK_TOPS, 4) if ks_tops else None,
+                                       "ops_per_launch": ks_ops, "units_per_launch": B}}
 
-    cbs = None
-    if args.with_cbs:
+    def _cbs():
         # Evaluation::circuit_bootstrap end to end: PBS -> trace (4 x 11 GLWE keyswitches) -> scheme switch
         ggsw = torch.empty((B, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
         eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
-        barrier()
+        sync()
+        eng.set_timing(True)
         tc = time.perf_counter()
         for _ in range(args.steps):
             eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
-        barrier()
+        sync()
         tc = time.perf_counter() - tc
-        if world > 1:
-            tc = max_over_ranks(tc, dist, device=dev)
-        cbs = {"circuit_bootstraps_per_s": round(world * B * args.steps / tc, 1), "ms_per_batch": round(tc / args.steps * 1e3, 3)}
-        del ggsw
-        step()   # restore the plain-PBS output for the parity sample
-        torch.cuda.synchronize()
+        tr_ms, _ = eng.last_kernel_ms("trace")
+        ss_ms, _ = eng.last_kernel_ms("scheme_switch")
+        eng.last_kernel_ms("pbs")
+        eng.set_timing(False)
+        out = {"_seconds": tc, "_units": B * args.steps, "_rate_key": "circuit_bootstraps_per_s",
+               "ms_per_batch": round(tc / args.steps * 1e3, 3)}
+        if tr_ms:
+            tf = TRACE_FLOP_PER_CT * B / (tr_ms * 1e-3) / 1e12
+            out["trace_roofline"] = {"bound": "fp64", "kernel": "cbs_trace_kernel", "kernel_ms": round(tr_ms, 4),
+                                     "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(tf / FP64_PEAK_TFLOPS, 4), "flop_per_unit": TRACE_FLOP_PER_CT,
+                                     "units_per_launch": B}
+        if ss_ms:
+            tf = SCHEME_SWITCH_FLOP_PER_CT * B / (ss_ms * 1e-3) / 1e12
+            out["scheme_switch_roofline"] = {"bound": "fp64", "kernel": "scheme_switch_kernel", "kernel_ms": round(ss_ms, 4),
+                                             "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                                             "flop_per_unit": SCHEME_SWITCH_FLOP_PER_CT, "units_per_launch": B}
+        return out
 
-    add32 = None
-    if args.with_add32 > 0 and rank == 0:
-        add32 = _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, True)
-        step()
-        torch.cuda.synchronize()
-
-    mul8 = mul32 = None
-    if extras:
-        mul8 = _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch)
-        mul32 = _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch)
-        step()
-        torch.cuda.synchronize()
-
-    cmux = None
-    if args.with_cmux:
+    def _cmux():
         # KeylessEvaluation::cmux over a batch: every ciphertext brings its own 256 KiB GGSW
         gg = torch.randn((B, P.cbs_ggsw_complex * 2), generator=g, device=dev, dtype=torch.float64) * (2.0 ** 60)
         da = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
         db = torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
         dc = torch.empty_like(da)
         eng.cmux_dev(stream, B, gg.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr())
-        barrier()
+        sync()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
         e0.record()
         for _ in range(reps):
             eng.cmux_dev(stream, B, gg.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr())
         e1.record()
-        barrier()
+        sync()
         ms = e0.elapsed_time(e1) / reps
         cm_bytes = B * (P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8)
-        cmux = {"cmux_per_s": round(B / ms * 1e3, 1), "kernel_ms": round(ms, 4),
-                "algorithmic_GBs": round(cm_bytes / ms / 1e6, 1), "hbm_frac": round(cm_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
-        del gg, da, db, dc
+        gbs = cm_bytes / ms / 1e6
+        return {"cmux_per_s": round(B / ms * 1e3, 1), "kernel_ms": round(ms, 4),
+                "algorithmic_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                "roofline": {"bound": "hbm", "kernel": "cmux_kernel<4,4,2>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B}}
+
+    gate = leg("gate", _gate) if args.with_keyswitch else None
+    cbs = leg("circuit_bootstrap", _cbs) if args.with_cbs else None
+    add32 = None
+    if args.with_add32 > 0 and rank == 0:
+        add32 = leg("add32", lambda: _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, True))
+    mul8 = mul32 = None
+    if extras:
+        mul8 = leg("mul8_gate_pool", lambda: _bench_mul8_pool(eng, P, rank, world))
+        mul32 = leg("mul32_gate_pool", lambda: _bench_mul32_pool(eng, P, rank, world))
+    cmux = leg("cmux", _cmux) if args.with_cmux else None
+    leg("restore", restore_headline_output)
+
+    # one collective for all legs: MAX of the per-rank seconds (inf where a rank failed)
+    timed_legs = [("gate", gate), ("circuit_bootstrap", cbs), ("mul8_gate_pool", mul8), ("mul32_gate_pool", mul32)]
+    secs = [(d["_seconds"] if d else float("inf")) for _, d in timed_legs]
+    if world > 1:
+        t = torch.tensor(secs, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = [float(x) for x in t.tolist()]
+    for (name, d), sec in zip(timed_legs, secs):
+        if d is None:
+            continue
+        if sec == float("inf"):
+            leg_errors.setdefault(name, "failed on another rank")
+            d.clear()
+            continue
+        d.pop("_seconds")
+        units = d.pop("_units") * world
+        d[d.pop("_rate_key")] = round(units / sec, 2)
+        if "_gates" in d:
+            d["gates_per_s"] = round(d.pop("_gates") * world / sec, 1)
+        if name.endswith("_pool"):
+            d["ms_per_pool_run"] = round(sec * 1e3, 3)
+    gate, cbs, mul8, mul32 = [(d or None) for _, d in timed_legs]
 
     total_units = world * B * args.steps
     value = total_units / dt
@@ -351,6 +422,7 @@ def main() -> int:
             "cpu_baseline": cpu,
             "key_broadcast_s": round(t_bcast, 4) if world > 1 else None,
             "key_broadcast_bytes": key_bytes,
+            "rccl": rccl,
             "pcie_inclusive": pcie,
             "setup_s": round(t_bcast0 - t_keys0, 2),
         }
@@ -366,32 +438,32 @@ def main() -> int:
             line["mul8_gate_pool"] = mul8
         if mul32:
             line["mul32_gate_pool"] = mul32
+        if leg_errors:
+            line["leg_errors"] = leg_errors
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
     return 0
 
 
-def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=8):
+DATA_DIR = os.path.join(ROOT, "spf_amd", "data")
+
+
+def _bench_mul8_pool(eng, P, rank, world, per_gpu=8):
     """BASELINE config 5's shape: a pool of independent multiplications through the reference's 8 x 8 multiplier
     block (mux_circuits `unsigned_multiplier(8, 8)`: 3 228 CMUX in 126 levels + 16 bit conversions each), `per_gpu`
     jobs per GPU (weak scaling), dealt to the ranks by spf_amd.gate_pool, each rank's jobs lowered into ONE gate
     graph on its own GPU; synthetic ciphertexts (timing is value-independent; correctness of the same graph is
-    tests/test_gpu_multiply.py).  Reports whole-pool multiplications/s and gates/s."""
+    tests/test_gpu_multiply.py).  Returns this rank's seconds per pool run; main() takes the MAX over ranks."""
     from spf_amd.gate_pool import circuit_jobs_as_one_graph, lpt_shards
     from spf_amd.mux_circuits import parse_mux_circuit
-    path = os.path.join(ROOT, "tests", "golden", "mux_multiplier_n8_m8.bincode")
-    if not os.path.exists(path):
-        return None
-    circuit = parse_mux_circuit(open(path, "rb").read())
+    circuit = parse_mux_circuit(open(os.path.join(DATA_DIR, "mux_multiplier_n8_m8.bincode"), "rb").read())
     n_jobs = per_gpu * world
     mine = lpt_shards([circuit.metrics()["mux_gates"]] * n_jobs, world)[rank]
     rng = np.random.default_rng(0x8008 + rank)
     cts = rng.integers(0, 1 << 64, size=(len(mine), 16, P.glwe_words), dtype=np.uint64)
     g, _ = circuit_jobs_as_one_graph(eng, circuit, cts)
     g.run()                       # plans, allocates, warms up
-    if world > 1:
-        dist.barrier()
     reps = 2
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -399,16 +471,14 @@ def _bench_mul8_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_
     dt = (time.perf_counter() - t0) / reps
     st = g.stats()
     g.close()
-    if world > 1:
-        dt = max_over_ranks(dt, dist, device=dev)
-    gates = n_jobs * (circuit.metrics()["mux_gates"] + 16)
-    return {"multiplications": n_jobs, "per_gpu": per_gpu, "ms_per_pool_run": round(dt * 1e3, 3),
-            "multiplications_per_s": round(n_jobs / dt, 2), "gates_per_s": round(gates / dt, 1),
+    return {"_seconds": dt, "_units": per_gpu, "_rate_key": "multiplications_per_s",
+            "_gates": per_gpu * (circuit.metrics()["mux_gates"] + 16),
+            "multiplications": n_jobs, "per_gpu": per_gpu,
             "levels": st["levels"], "launches_per_rank": st["launches"],
             "block": "mux_circuits unsigned_multiplier(8,8): 3228 CMUX, depth 126, 16 circuit bootstraps"}
 
 
-def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per_gpu=4):
+def _bench_mul32_pool(eng, P, rank, world, per_gpu=4):
     """BASELINE config 5: 32 x 32-bit encrypted multiplications via mux_circuits, one gate pool job = one
     multiplication built exactly as `append_uint_multiply` does (parasol_runtime/src/circuits/mul.rs:75-200): 64 input
     conversions, four `unsigned_multiplier(16, 16)` blocks (the reference's blob), 128 conversions of the partial
@@ -418,10 +488,7 @@ def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per
     from spf_amd import FheCircuit, ValueKind
     from spf_amd.gate_pool import lpt_shards
     from spf_amd.mux_circuits import GraphBuilder, append_uint_multiply, parse_mux_circuit
-    path = os.path.join(ROOT, "tests", "golden", "mux_multiplier_n16_m16.bincode")
-    if not os.path.exists(path):
-        return None
-    blk16 = parse_mux_circuit(open(path, "rb").read())
+    blk16 = parse_mux_circuit(open(os.path.join(DATA_DIR, "mux_multiplier_n16_m16.bincode"), "rb").read())
     n_jobs = per_gpu * world
     mine = lpt_shards([1.0] * n_jobs, world)[rank]
     rng = np.random.default_rng(0x3232 + rank)
@@ -435,8 +502,6 @@ def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per
             g.add_output(n, ValueKind.GLWE1)
     t_build = time.perf_counter() - t_build
     g.run()                       # plans, allocates (4 GB of GLWE per job), warms up
-    if world > 1:
-        dist.barrier()
     reps = 2
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -444,11 +509,9 @@ def _bench_mul32_pool(eng, P, dev, rank, world, dist, max_over_ranks, torch, per
     dt = (time.perf_counter() - t0) / reps
     st = g.stats()
     g.close()
-    if world > 1:
-        dt = max_over_ranks(dt, dist, device=dev)
     cmux = 4 * blk16.metrics()["mux_gates"] + 9104
-    return {"multiplications": n_jobs, "per_gpu": per_gpu, "ms_per_pool_run": round(dt * 1e3, 3),
-            "multiplications_per_s": round(n_jobs / dt, 2), "gates_per_s": round(n_jobs * (cmux + 192) / dt, 1),
+    return {"_seconds": dt, "_units": per_gpu, "_rate_key": "multiplications_per_s", "_gates": per_gpu * (cmux + 192),
+            "multiplications": n_jobs, "per_gpu": per_gpu,
             "cmux_per_multiplication": cmux, "circuit_bootstraps_per_multiplication": 192,
             "nodes": st["nodes"], "levels": st["levels"], "launches_per_rank": st["launches"],
             "graph_build_s": round(t_build, 2)}

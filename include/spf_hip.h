@@ -323,15 +323,15 @@ spf_status spf_gather_rows_dev(spf_ctx *ctx, void *stream, size_t rows, size_t w
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------- */
 
-/* Average device time in milliseconds of the `reps` most recent blind-rotation launches made
- * through this context, measured with hipEvents recorded on the launch stream around each
- * kernel.  Enable with spf_set_timing(ctx, 1) before launching. */
+/* Average device time in milliseconds of the launches of one kernel family made through this
+ * context since timing was enabled (or since the last query, which clears the record), measured
+ * with hipEvents recorded on the launch stream around each launch: "pbs" (blind rotation),
+ * "keyswitch" (digits + GEMM), "trace" (cbs_trace_kernel), "scheme_switch", "cmux" (contiguous
+ * batched CMUX family).  A host-pointer bootstrap of more than one chip round is launched in slices
+ * of 1024 ciphertexts: it records one "pbs" entry per slice.  Enable with spf_set_timing(ctx, 1). */
 spf_status spf_set_timing(spf_ctx *ctx, int enabled);
-spf_status spf_last_kernel_ms(spf_ctx *ctx, const char *kernel /* "pbs" | "keyswitch" */,
+spf_status spf_last_kernel_ms(spf_ctx *ctx, const char *kernel /* "pbs" | "keyswitch" | "trace" | "scheme_switch" | "cmux" */,
                               double *avg_ms, int *launches);
-/* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
- * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
- * shape).  For measurement records; never NULL. */
 /* `generate_lut` (sunscreen_tfhe ops/bootstrapping/programmable_bootstrapping.rs:129-185) for
  * `programmable_bootstrap_univariate`: map_tables[f * 2^bits + x] = f(x) for n_maps functions over a
  * plaintext space of 2^bits values (the reference takes closures; a table is their C form).  Writes the trivial
@@ -348,6 +348,9 @@ spf_status spf_load_compute_key_bincode(spf_ctx *ctx, const uint8_t *bytes, size
  * (k+1)*l_cbs*(k+1)*N/2 complex) that `Evaluation::new` obtains by circuit-bootstrapping the trivial L0 LWE of
  * the bit (:161-197).  Computed on first use after the keys were (re)loaded, cached in HBM. */
 spf_status spf_l1ggsw_constant(spf_ctx *ctx, int bit, double *ggsw_fft_out);
+/* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
+ * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
+ * shape).  For measurement records; never NULL. */
 const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
 
 /* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */

@@ -38,6 +38,10 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+// kernels whose launches spf_set_timing brackets with hipEvents on the launch stream (spf_last_kernel_ms)
+enum TimedKernel { T_PBS = 0, T_KS, T_TRACE, T_SS, T_CMUX, T_COUNT };
+const char* const kTimedNames[T_COUNT] = {"pbs", "keyswitch", "trace", "scheme_switch", "cmux"};
+
 } // namespace
 
 struct spf_ctx {
@@ -74,7 +78,7 @@ struct spf_ctx {
     hipStream_t copy_stream = nullptr; // device-to-host copies of finished slices, under the next slice's kernel
     std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
     bool timing = false;
-    std::vector<TimedLaunch> t_pbs, t_ks;
+    std::vector<TimedLaunch> timed[T_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
 
@@ -183,6 +187,28 @@ spf_status get_events(spf_ctx* c, hipEvent_t* a, hipEvent_t* b)
     return SPF_OK;
 }
 
+// hipEvent bracket around the launches of one entry point, when timing is on
+struct TimedScope {
+    spf_ctx* c; hipStream_t s; int which; TimedLaunch tl{}; bool on = false;
+    TimedScope(spf_ctx* c_, hipStream_t s_, int which_) : c(c_), s(s_), which(which_) {}
+    spf_status begin()
+    {
+        if (!c->timing) return SPF_OK;
+        spf_status st = get_events(c, &tl.start, &tl.stop);
+        if (st != SPF_OK) return st;
+        HIPCHK(c, hipEventRecord(tl.start, s));
+        on = true;
+        return SPF_OK;
+    }
+    spf_status end()
+    {
+        if (!on) return SPF_OK;
+        HIPCHK(c, hipEventRecord(tl.stop, s));
+        c->timed[which].push_back(tl);
+        return SPF_OK;
+    }
+};
+
 spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe,
                                const uint64_t* d_lut, size_t lut_stride, uint32_t log_chi,
                                uint32_t log_v, uint64_t body_rotate, uint64_t* d_out,
@@ -269,7 +295,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
-        c->t_pbs.push_back(tl);
+        c->timed[T_PBS].push_back(tl);
     }
 #ifdef SPF_STAMPS
     if (a.stamps) { // diagnostic build: median over waves of the per-phase cycle sums, per CMUX step
@@ -378,7 +404,7 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
         HIPCHK(c, hipEventRecord(tl.stop, s));
-        c->t_ks.push_back(tl);
+        c->timed[T_KS].push_back(tl);
     }
     return SPF_OK;
 }
@@ -513,8 +539,8 @@ void spf_destroy(spf_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto& t : c->t_pbs) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    for (auto& t : c->t_ks) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto& v : c->timed)
+        for (auto& t : v) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_ksk, (void*)c->d_cbs_lut,
                     c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->ks_dig.p,
                     c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
@@ -659,9 +685,12 @@ static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
     a.cbs_radix_log = c->prm.cbs_radix_log;
     dim3 grid((a.units + kWavesPerBlock - 1) / kWavesPerBlock), block(512);
+    TimedScope ts(c, s, T_TRACE);
+    spf_status st = ts.begin();
+    if (st != SPF_OK) return st;
     hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTraceLds, s, a);
     HIPCHK(c, hipGetLastError());
-    return SPF_OK;
+    return ts.end();
 }
 
 static spf_status launch_scheme_switch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_glev, double* d_ggsw)
@@ -671,9 +700,12 @@ static spf_status launch_scheme_switch(spf_ctx* c, hipStream_t s, size_t B, cons
     a.glev = d_glev; a.ggsw_out = reinterpret_cast<c64*>(d_ggsw); a.ssk = c->d_ssk; a.tables = c->d_tables;
     a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
     dim3 grid((a.units + kWavesPerBlock - 1) / kWavesPerBlock), block(512);
+    TimedScope ts(c, s, T_SS);
+    spf_status st = ts.begin();
+    if (st != SPF_OK) return st;
     hipLaunchKernelGGL((scheme_switch_kernel<15, 3>), grid, block, kTailLds, s, a);
     HIPCHK(c, hipGetLastError());
-    return SPF_OK;
+    return ts.end();
 }
 
 spf_status spf_mod_switch_trace_and_rotate_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, uint64_t* d_glev)
@@ -838,9 +870,12 @@ static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t 
     // zero ciphertext (multiply_glwe_ggsw)
     a.ggsw = reinterpret_cast<const c64*>(d_sel); a.d0 = d_a ? d_a : d_b; a.d1 = d_b; a.out = d_out;
     a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = per_ggsw; a.d0_zero = d_a ? 0u : 1u;
+    TimedScope ts(c, s, T_CMUX);
+    spf_status st = ts.begin();
+    if (st != SPF_OK) return st;
     launch_cmux_args(c, s, a);
     HIPCHK(c, hipGetLastError());
-    return SPF_OK;
+    return ts.end();
 }
 
 spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel, const uint64_t* d_a, const uint64_t* d_b,
@@ -957,20 +992,28 @@ static spf_status bootstrap_sliced_to_host(spf_ctx* c, size_t B, const uint64_t*
         c->slice_ev.push_back(e);
     }
     uint64_t* d_out = (uint64_t*)c->out.p;
-    for (size_t k = 0; k < n_slices; k++) {
-        const size_t off = k * slice, n = std::min(slice, B - off);
-        spf_status s = launch_blind_rotate(c, c->stream, n, d_lwe + off * lw, d_lut + off * lut_stride, lut_stride, log_chi,
-                                           log_v, rot, d_out + off * ow, ow, extract);
-        if (s != SPF_OK) return s;
-        HIPCHK(c, hipEventRecord(c->slice_ev[k], c->stream));
-    }
-    for (size_t k = 0; k < n_slices; k++) {
-        const size_t off = k * slice, n = std::min(slice, B - off);
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->slice_ev[k], 0));
-        HIPCHK(c, hipMemcpyAsync(host_out + off * ow, d_out + off * ow, n * ow * 8, hipMemcpyDeviceToHost, c->copy_stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // Once something is enqueued, no return before both streams are idle: kernels may still be writing c->out and
+    // copies may still be landing in the caller's buffer, which the caller is free to release after an error.
+    auto enqueue = [&]() -> spf_status {
+        for (size_t k = 0; k < n_slices; k++) {
+            const size_t off = k * slice, n = std::min(slice, B - off);
+            spf_status s = launch_blind_rotate(c, c->stream, n, d_lwe + off * lw, d_lut + off * lut_stride, lut_stride, log_chi,
+                                               log_v, rot, d_out + off * ow, ow, extract);
+            if (s != SPF_OK) return s;
+            HIPCHK(c, hipEventRecord(c->slice_ev[k], c->stream));
+        }
+        for (size_t k = 0; k < n_slices; k++) {
+            const size_t off = k * slice, n = std::min(slice, B - off);
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->slice_ev[k], 0));
+            HIPCHK(c, hipMemcpyAsync(host_out + off * ow, d_out + off * ow, n * ow * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        return SPF_OK;
+    };
+    const spf_status st = enqueue();
+    const hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
+    if (st != SPF_OK) return st; // the message of the first failure stays in place
+    HIPCHK(c, e1);
+    HIPCHK(c, e2);
     return SPF_OK;
 }
 
@@ -1286,9 +1329,9 @@ spf_status spf_last_kernel_ms(spf_ctx* c, const char* kernel, double* avg_ms, in
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<TimedLaunch>* v = nullptr;
-    if (!strcmp(kernel, "pbs")) v = &c->t_pbs;
-    else if (!strcmp(kernel, "keyswitch")) v = &c->t_ks;
-    else return fail(c, SPF_ERR_INVALID_ARGUMENT, "kernel must be \"pbs\" or \"keyswitch\"");
+    for (int k = 0; k < T_COUNT; k++)
+        if (!strcmp(kernel, kTimedNames[k])) v = &c->timed[k];
+    if (!v) return fail(c, SPF_ERR_INVALID_ARGUMENT, "kernel must be \"pbs\", \"keyswitch\", \"trace\", \"scheme_switch\" or \"cmux\"");
     double total = 0.0;
     int n = 0;
     for (auto& t : *v) {
@@ -1443,8 +1486,18 @@ void spf_pool_destroy(spf_pool* p)
         std::lock_guard<std::mutex> lk(p->mu);
         p->stop = true;
     }
+    // wake everything that can be parked on this pool: the worker, producers blocked on back-pressure (they
+    // return an error), and waiters (the worker drains the queues before it exits, so their tickets complete)
     p->cv_work.notify_all();
+    p->cv_space.notify_all();
+    p->cv_done.notify_all();
     if (p->worker.joinable()) p->worker.join();
+    {
+        // nobody may still be inside submit() / spf_pool_wait() on the mutex and condition variables freed below
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.notify_all();
+        p->cv_idle.wait(lk, [&] { return p->blocked == 0; });
+    }
     delete p;
 }
 
@@ -1471,13 +1524,18 @@ spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)
 {
     if (!p) return SPF_ERR_INVALID_ARGUMENT;
     std::unique_lock<std::mutex> lk(p->mu);
-    // a ticket can be waited for exactly once: unknown, or already collected, is an error (not a hang)
-    if (p->open.count(ticket) == 0) return SPF_ERR_INVALID_ARGUMENT;
+    // a ticket can be waited for exactly once: unknown, already collected, or already being waited for by
+    // another thread is an error (not a hang) — the claim is taken under the same lock as the check
+    if (p->open.count(ticket) == 0 || !p->claimed.insert(ticket).second) return SPF_ERR_INVALID_ARGUMENT;
+    p->blocked++;
     p->cv_done.wait(lk, [&] { return p->done.count(ticket) != 0; });
+    p->blocked--;
     spf_status st = p->done[ticket];
     p->done.erase(ticket);
     p->open.erase(ticket);
+    p->claimed.erase(ticket);
     p->cv_space.notify_all();
+    if (p->stop) p->cv_idle.notify_all();
     return st;
 }
 

@@ -88,13 +88,14 @@ __device__ __forceinline__ void bsk_slot_dma(const c64* src, char* slot, int tid
 // One LDS-DMA piece in the scalar-base form: 64 lanes x 16 bytes from `sbase + voff` (sbase wave-uniform
 // in an SGPR pair, voff this lane's 32-bit byte offset) to LDS bytes [lds, lds + 1024) (lds wave-uniform,
 // lane l lands at lds + 16 l).  Written out because the builtin, given `base + k * stride + lane offset`,
-// keeps one 64-bit per-lane address per piece live (16 VGPRs for an 8-piece refill).  M0 is written
-// here and not declared (hipcc rejects it as a clobber): a kernel that uses this must not use the
-// LDS-DMA builtin or any other M0 consumer (s_movrel, sendmsg, GDS) beside it.
+// keeps one 64-bit per-lane address per piece live (16 VGPRs for an 8-piece refill).  hipcc does not accept
+// M0 as a clobber, so the asm saves M0 in an SGPR and puts it back behind the load (the instruction reads M0
+// when it issues): whatever the compiler may keep in M0 around this point survives.
 __device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t voff, uint32_t lds)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(sbase), "s"(lds) : "memory");
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_address(const void* p)
 {

@@ -48,6 +48,9 @@ struct spf_pool {
     std::deque<spf_pool_impl::Request> q[spf_pool_impl::N_OPS];
     std::unordered_map<uint64_t, spf_status> done;
     std::unordered_set<uint64_t> open;  // submitted and not yet collected by spf_pool_wait
+    std::unordered_set<uint64_t> claimed; // tickets some thread is already waiting for (a ticket has ONE waiter)
+    size_t blocked = 0;                 // callers inside submit() / spf_pool_wait(): destroy waits until they have left
+    std::condition_variable cv_idle;
     size_t max_inflight = 16384;        // submit blocks while this many tickets are open (back-pressure)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
@@ -161,8 +164,13 @@ struct spf_pool {
         if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
         std::unique_lock<std::mutex> lk(mu);
         // back-pressure: a producer that runs ahead of its own waits blocks here instead of growing the queues
+        blocked++;
         cv_space.wait(lk, [&] { return stop || open.size() < max_inflight; });
-        if (stop) return SPF_ERR_INVALID_ARGUMENT;
+        blocked--;
+        if (stop) {
+            cv_idle.notify_all(); // spf_pool_destroy waits for blocked callers to leave before it frees the pool
+            return SPF_ERR_INVALID_ARGUMENT;
+        }
         try {
             spf_pool_impl::Request r{a, b, c, out, next_ticket, std::chrono::steady_clock::now()};
             q[op].push_back(r);

@@ -23,6 +23,7 @@ tests use to pin the parser against integer multiplication).
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -85,6 +86,19 @@ class MuxCircuit:
         for n in self.topological_muxes():
             d[n] = 1 + max(d.get(self.low[n], 0), d.get(self.high[n], 0))
         return max((d.get(self.out_src[o], 0) for o in self.outputs), default=0)
+
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def unsigned_multiplier(n: int, m: int) -> "MuxCircuit":
+    """`mux_circuits::mul::unsigned_multiplier(n, m)` (mux_circuits/src/mul.rs:62-69): the reference ships these
+    blocks as precomputed bincode blobs and `include_bytes!`es them; spf_amd/data/ holds the same files (README there)."""
+    path = os.path.join(DATA_DIR, f"mux_multiplier_n{n}_m{m}.bincode")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"no precomputed multiplier block for {n} x {m} bits ({path})")
+    with open(path, "rb") as f:
+        return parse_mux_circuit(f.read())
 
 
 def parse_mux_circuit(blob: bytes) -> MuxCircuit:

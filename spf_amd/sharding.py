@@ -31,6 +31,45 @@ def broadcast_keys(blobs: Sequence, dist, src: int = 0) -> None:
         dist.broadcast(b, src=src)
 
 
+class _DevArray:
+    """zero-copy view of a raw device pointer (CUDA array interface), for torch.as_tensor"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+def key_blob_tensors(engine, device) -> List:
+    """The four ComputeKey fields of `engine` (bootstrap, keyswitch, automorphism, scheme switch:
+    parasol_runtime/src/crypto/keys.rs:306-318) as uint8 torch tensors that ALIAS the engine's own HBM
+    (spf_key_blob): what the RCCL broadcast writes into.  Call `replicate_keys` (or spf_key_blob_commit per
+    blob) after filling them."""
+    import torch
+    out = []
+    for which in (0, 1, 2, 3):
+        ptr, nbytes = engine.key_blob(which)
+        out.append(torch.as_tensor(_DevArray(ptr, nbytes), device=device))
+    return out
+
+
+def replicate_keys(engine, blobs: Sequence, dist=None, src: int = 0) -> Tuple[float, int]:
+    """One-time key replication: broadcast the four blobs from rank `src` (RCCL over xGMI when the process
+    group's backend is nccl; skipped without a process group), then commit them on this rank's GPU (derives the
+    keyswitch byte planes, drops cached constants).  Returns (seconds spent in the broadcast, bytes per rank)."""
+    import time
+
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if dist is not None and dist.is_initialized():
+        broadcast_keys(blobs, dist, src=src)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for which in range(len(blobs)):
+        engine.key_blob_commit(which)
+    return dt, sum(int(b.numel()) for b in blobs)
+
+
 def max_over_ranks(value: float, dist, device=None) -> float:
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)

@@ -1,5 +1,5 @@
 """BASELINE config 5's shape on CPU: the reference's own 8x8 multiplier block (mux_circuits' bincode blob, kept as a
-data fixture: tests/golden/mux_multiplier_n8_m8.bincode = mux_circuits/src/data/multiplier-n8-m8, loaded by
+data fixture: spf_amd/data/mux_multiplier_n8_m8.bincode = mux_circuits/src/data/multiplier-n8-m8, loaded by
 `unsigned_multiplier`, mux_circuits/src/mul.rs:62-69) parsed and evaluated, and a pool of such evaluations sharded
 over 2 and 8 gloo ranks with the plaintext evaluator standing in for the GPU (the product has no CPU path)."""
 import os
@@ -14,7 +14,7 @@ from spf_amd.gate_pool import lpt_shards, run_sharded
 from spf_amd.mux_circuits import MuxFormatError, evaluate_plain, parse_mux_circuit, ripple_carry_adder
 from spf_amd.sharding import gather_shards, shard_range, shard_sizes
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mux_multiplier_n8_m8.bincode")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spf_amd", "data", "mux_multiplier_n8_m8.bincode")
 
 
 def _bits(a, b):

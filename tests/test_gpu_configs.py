@@ -133,3 +133,22 @@ def test_golden_default128_fixture(golden_dir):
     eng.load_bootstrap_key(ks.bsk_fft)
     assert np.array_equal(eng.circuit_bootstrap_pbs(z["lwe"]), z["cbs_out"])
     assert int(ks.bsk_fft.view(np.uint64).sum(dtype=np.uint64)) == int(z["bsk_checksum"]), "key recipe drifted"
+
+
+def test_config4_shard_8192_default128(full):
+    """BASELINE configs[3] ("65536 PBS sharded across 8xMI355X"): the per-GPU shard, B = 8192 at n = 637, through
+    spf_circuit_bootstrap_pbs_batch.  Sampled ciphertexts (first / last of a host slice of 1024, of a workgroup
+    of four, of a chip round, the tail) against the oracle, and the whole batch against the same inputs sent
+    1024 at a time (other slice / workgroup boundaries; generalized_programmable_bootstrap has no cross-
+    ciphertext state, programmable_bootstrapping.rs:342-410)."""
+    ks, eng = full
+    B = 8192
+    lwe = random_lwe_batch(0xC0F8, B, 637)
+    got = eng.circuit_bootstrap_pbs(lwe)
+    sample = (0, 1, 3, 4, 1023, 1024, 1027, 2047, 2048, 4095, 4096, 4099, 6143, 7168, 8188, 8189, 8190, 8191)
+    _, exp = O.bench_cbs_pbs(lwe[list(sample)], ks.bsk_fft, ks.params, HOST_THREADS, native=False)
+    for k, i in enumerate(sample):
+        assert np.array_equal(got[i], exp[k]), i
+    ref = np.concatenate([eng.circuit_bootstrap_pbs(lwe[i:i + 1024]) for i in range(0, B, 1024)])
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} ciphertexts differ between one 8192-launch and eight 1024-launches, first {bad[:8]}"

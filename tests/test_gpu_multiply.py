@@ -17,7 +17,7 @@ from tests.util import keyset, to_engine_params
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mux_multiplier_n8_m8.bincode")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spf_amd", "data", "mux_multiplier_n8_m8.bincode")
 
 
 def test_encrypted_multiply_8x8_through_the_reference_block():

@@ -85,3 +85,38 @@ def test_two_rank_gloo_shard_broadcast_gather():
     assert any(r[0] is True for r in res)            # rank 0: gathered == unsharded run
     assert all(abs(r[1] - 2.0) < 1e-12 for r in res)  # MAX over ranks of (1, 2)
     assert res[0][2] == res[1][2] != 0               # both ranks hold the same key bytes
+
+
+def _bare_env():
+    return {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+
+
+def test_bench_rejects_a_launcher_mismatch():
+    """--gpus that disagrees with the launcher's WORLD_SIZE is an error (rc 2), before any GPU work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _bare_env()
+    env.update({"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_starts_its_ranks_as_children():
+    """`python3 bench.py --gpus 2` with no launcher spawns torch.distributed.run with two ranks and returns their
+    status.  Without a GPU (this test runs on CPU) each rank must stop with "no GPU visible" — there is no CPU path —
+    and the parent must report the failure instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher plumbing; the GPU form is tests/test_gpu_rccl.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1"],
+                       capture_output=True, text=True, timeout=280, cwd=root, env=_bare_env())
+    assert r.returncode != 0
+    assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]       # both child ranks got as far as the GPU check
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

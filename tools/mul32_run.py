@@ -37,7 +37,7 @@ def main():
             t.copy_((torch.randn(nbytes // 8, generator=g0, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
         torch.cuda.synchronize()
         eng.key_blob_commit(which)
-    blk16 = parse_mux_circuit(open(os.path.join(ROOT, "tests", "golden", "mux_multiplier_n16_m16.bincode"), "rb").read())
+    blk16 = parse_mux_circuit(open(os.path.join(ROOT, "spf_amd", "data", "mux_multiplier_n16_m16.bincode"), "rb").read())
     rng = np.random.default_rng(2)
     g = FheCircuit(eng)
     b = GraphBuilder(g)
