@@ -344,6 +344,24 @@ spf_status spf_generate_lut(const spf_params *params, const uint64_t *map_tables
  * with_fixint_encoding — four sequences (u64 LE count, elements) in the order bs_key, ks_key, ss_key, auto_key.
  * Every count is checked against the context's parameters before anything is loaded; trailing bytes are allowed. */
 spf_status spf_load_compute_key_bincode(spf_ctx *ctx, const uint8_t *bytes, size_t len);
+/* Ciphertext wire format (parasol_runtime/src/crypto/encryption.rs:23-110: L0LweCiphertext, L1LweCiphertext,
+ * L1GlweCiphertext, L1GlevCiphertext are serde newtypes over entities with one field `data: AVec<Torus<u64>>`,
+ * sunscreen_tfhe/src/dst.rs:25-41) as `safe_bincode::deserialize` reads it (safe_bincode.rs:16-28): bincode
+ * DefaultOptions + fixint encoding = a u64 little-endian element count, then the words little-endian; the read
+ * is bounded by GetSize = (count + 1) * 8 bytes (encryption.rs:454-519), `check_is_valid` then demands exactly
+ * the length the parameters give, trailing bytes are allowed.  L1GgswCiphertext is not Serialize in the
+ * reference (encryption.rs:93-97): SPF_VAL_GGSW1 is SPF_ERR_UNSUPPORTED.  Host only, no GPU, ctx-free.
+ *   spf_ciphertext_words:        number of u64 words of a ciphertext of `kind` (0 for an unknown kind)
+ *   spf_ciphertext_from_bincode: bytes -> words_out (caller-allocated, spf_ciphertext_words(kind) words).  A count
+ *                                that differs from the parameters' (the reference's malformed-length vector
+ *                                safe_bincode.rs:58-66 included) or a truncated body is SPF_ERR_INVALID_ARGUMENT and
+ *                                leaves words_out untouched.
+ *   spf_ciphertext_to_bincode:   words -> out (capacity `cap` bytes); *written = 8 + 8 * words. */
+size_t spf_ciphertext_words(const spf_params *params, spf_value_kind kind);
+spf_status spf_ciphertext_from_bincode(const spf_params *params, spf_value_kind kind, const uint8_t *bytes, size_t len,
+                                       uint64_t *words_out);
+spf_status spf_ciphertext_to_bincode(const spf_params *params, spf_value_kind kind, const uint64_t *words, uint8_t *out,
+                                     size_t cap, size_t *written);
 /* `Evaluation::l1ggsw_zero()` / `l1ggsw_one()` (crypto/evaluation.rs:254-262): the GGSW (cbs radix, FFT domain,
  * (k+1)*l_cbs*(k+1)*N/2 complex) that `Evaluation::new` obtains by circuit-bootstrapping the trivial L0 LWE of
  * the bit (:161-197).  Computed on first use after the keys were (re)loaded, cached in HBM. */

@@ -104,6 +104,9 @@ SYMBOLS = [
     ("spf_l1ggsw_constant", _I, [_P, _I, _P]),
     ("spf_generate_lut", _I, [C.POINTER(_CParams), _P, _SZ, _U32, _P]),
     ("spf_load_compute_key_bincode", _I, [_P, _P, _SZ]),
+    ("spf_ciphertext_words", _SZ, [C.POINTER(_CParams), _I]),
+    ("spf_ciphertext_from_bincode", _I, [C.POINTER(_CParams), _I, _P, _SZ, _P]),
+    ("spf_ciphertext_to_bincode", _I, [C.POINTER(_CParams), _I, _P, _P, _SZ, C.POINTER(_SZ)]),
     ("spf_version", C.c_char_p, []),
 ]
 
@@ -175,6 +178,40 @@ def generate_lut(maps, plaintext_bits: int, params: Params = DEFAULT_128) -> np.
     if st != 0:
         raise SpfError(st, (lib.spf_last_error(None) or b"").decode())
     return out
+
+
+def _cparams(params: Params) -> _CParams:
+    return _CParams(*[getattr(params, n) for n, _ in _CParams._fields_])
+
+
+def ciphertext_words(kind: int, params: Params = DEFAULT_128) -> int:
+    return int(load_library().spf_ciphertext_words(C.byref(_cparams(params)), int(kind)))
+
+
+def ciphertext_from_bincode(kind: int, blob: bytes, params: Params = DEFAULT_128) -> np.ndarray:
+    """`safe_bincode::deserialize::<L0Lwe | L1Lwe | L1Glwe | L1Glev Ciphertext>` (safe_bincode.rs:16-28,
+    encryption.rs:23-110): bytes -> u64 words.  Host only.  Malformed input raises SpfError."""
+    lib = load_library()
+    n = ciphertext_words(kind, params)
+    out = np.empty(max(n, 1), dtype=np.uint64)
+    buf = np.frombuffer(bytes(blob) if len(blob) else b"\0", dtype=np.uint8)
+    st = lib.spf_ciphertext_from_bincode(C.byref(_cparams(params)), int(kind), _ptr(buf), len(blob), _ptr(out))
+    if st != 0:
+        raise SpfError(st, (lib.spf_last_error(None) or b"").decode())
+    return out[:n]
+
+
+def ciphertext_to_bincode(kind: int, words, params: Params = DEFAULT_128) -> bytes:
+    """`bincode::serialize` of one of the serializable ciphertext newtypes (fixint): u64 count + words, little-endian."""
+    lib = load_library()
+    n = ciphertext_words(kind, params)
+    w = _in("ciphertext", words, np.uint64, max(n, 1)) if n else np.zeros(1, dtype=np.uint64)
+    out = np.empty(8 + 8 * n, dtype=np.uint8)
+    written = _SZ(0)
+    st = lib.spf_ciphertext_to_bincode(C.byref(_cparams(params)), int(kind), _ptr(w), _ptr(out), out.size, C.byref(written))
+    if st != 0:
+        raise SpfError(st, (lib.spf_last_error(None) or b"").decode())
+    return out[:written.value].tobytes()
 
 
 class Engine:

@@ -1411,6 +1411,67 @@ spf_status spf_load_compute_key_bincode(spf_ctx* c, const uint8_t* bytes, size_t
     return st;
 }
 
+// Ciphertext wire format: see include/spf_hip.h.  (encryption.rs:23-110, 454-519; safe_bincode.rs:16-28.)
+size_t spf_ciphertext_words(const spf_params* p, spf_value_kind kind)
+{
+    if (!p) return 0;
+    switch (kind) {
+    case SPF_VAL_LWE0: return lwe0_words(*p);
+    case SPF_VAL_LWE1: return lwe1_words(*p);
+    case SPF_VAL_GLWE1: return glwe_words(*p);
+    case SPF_VAL_GLEV1: return (size_t)p->cbs_radix_count * glwe_words(*p);
+    default: return 0;
+    }
+}
+
+static const char* wire_kind_name(spf_value_kind k)
+{
+    static const char* n[5] = {"L0LweCiphertext", "L1LweCiphertext", "L1GlweCiphertext", "L1GgswCiphertext", "L1GlevCiphertext"};
+    return ((unsigned)k < 5) ? n[k] : "ciphertext";
+}
+
+spf_status spf_ciphertext_from_bincode(const spf_params* p, spf_value_kind kind, const uint8_t* bytes, size_t len,
+                                       uint64_t* words_out)
+{
+    if (!p || !bytes || !words_out) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_ciphertext_from_bincode: null argument");
+    if (kind == SPF_VAL_GGSW1)
+        return fail(nullptr, SPF_ERR_UNSUPPORTED, "L1GgswCiphertext has no wire format in the reference (not Serialize)");
+    const size_t want = spf_ciphertext_words(p, kind);
+    if (want == 0) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_ciphertext_from_bincode: unknown ciphertext kind");
+    const std::string what = wire_kind_name(kind);
+    if (len < 8) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, what + ": truncated before the element count");
+    uint64_t n = 0;
+    for (int b = 7; b >= 0; b--) n = (n << 8) | bytes[b]; // little-endian, any alignment
+    // the reference bounds the read at (want + 1) * 8 bytes (bincode's SizeLimit error for anything longer) and
+    // check_is_valid rejects anything shorter: only the exact count passes
+    if (n != want)
+        return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, what + ": " + std::to_string(n) + " elements, the parameters need " + std::to_string(want));
+    if ((len - 8) / 8 < want) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, what + ": truncated inside the data");
+    for (size_t i = 0; i < want; i++) {
+        uint64_t w = 0;
+        for (int b = 7; b >= 0; b--) w = (w << 8) | bytes[8 + 8 * i + b];
+        words_out[i] = w;
+    }
+    return SPF_OK;
+}
+
+spf_status spf_ciphertext_to_bincode(const spf_params* p, spf_value_kind kind, const uint64_t* words, uint8_t* out, size_t cap,
+                                     size_t* written)
+{
+    if (!p || !words || !out || !written) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_ciphertext_to_bincode: null argument");
+    if (kind == SPF_VAL_GGSW1)
+        return fail(nullptr, SPF_ERR_UNSUPPORTED, "L1GgswCiphertext has no wire format in the reference (not Serialize)");
+    const size_t n = spf_ciphertext_words(p, kind);
+    if (n == 0) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_ciphertext_to_bincode: unknown ciphertext kind");
+    if (cap < 8 + 8 * n) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "spf_ciphertext_to_bincode: output buffer too small");
+    uint64_t v = n;
+    for (int b = 0; b < 8; b++) out[b] = (uint8_t)(v >> (8 * b));
+    for (size_t i = 0; i < n; i++)
+        for (int b = 0; b < 8; b++) out[8 + 8 * i + b] = (uint8_t)(words[i] >> (8 * b));
+    *written = 8 + 8 * n;
+    return SPF_OK;
+}
+
 // l1ggsw_zero / l1ggsw_one as `Evaluation::new` makes them (crypto/evaluation.rs:161-197): the circuit bootstrap
 // of the trivial level-0 LWE of the bit, under the loaded keys.  Built once per key set, kept in HBM.
 static spf_status ensure_ggsw_constants(spf_ctx* c)

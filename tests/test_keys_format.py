@@ -1,5 +1,6 @@
 """ComputeKey bincode layout (keys.rs:294-318 + safe_bincode.rs:16-28): round trip, exact byte
 layout on a tiny parameter set, and the size guards."""
+import os
 import struct
 
 import numpy as np
@@ -75,3 +76,64 @@ def test_bincode_loader_behind_the_c_abi_equals_field_by_field_loading():
             fresh.load_compute_key_bincode(broken)
     with pytest.raises(spf_amd.SpfError):           # nothing was loaded by the failed attempts
         fresh.keyswitch_circuit_bootstrap(lwe1)
+
+
+# ---- ciphertext half of f4: the serde newtypes of crypto/encryption.rs:23-110 through the C ABI (host only) ----
+
+_KINDS = {"L0LweCiphertext": 0, "L1LweCiphertext": 1, "L1GlweCiphertext": 2, "L1GlevCiphertext": 4}
+
+
+def _kats():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as f:
+        return json.load(f)["safe_bincode_malformed_length"]
+
+
+def test_ciphertext_bincode_sizes_match_getsize():
+    """GetSize (encryption.rs:454-519) = (words + 1) * 8 bytes; words at DEFAULT_128 as the entities define them."""
+    spf_amd.build_library()
+    for name, words in _kats()["words_default128"].items():
+        assert spf_amd.ciphertext_words(_KINDS[name]) == words, name
+        blob = spf_amd.ciphertext_to_bincode(_KINDS[name], np.zeros(words, dtype=np.uint64))
+        assert len(blob) == (words + 1) * 8
+        assert blob[:8] == struct.pack("<Q", words)
+
+
+def test_ciphertext_bincode_round_trip_like_can_safe_deserialize_ciphertexts():
+    """safe_bincode.rs:41-53 with non-trivial contents: serialize -> deserialize is the identity for all four
+    serializable newtypes; words are little-endian u64; trailing bytes are allowed (allow_trailing_bytes)."""
+    rng = np.random.default_rng(0xB1C0DE)
+    for name, kind in _KINDS.items():
+        n = spf_amd.ciphertext_words(kind)
+        w = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+        blob = spf_amd.ciphertext_to_bincode(kind, w)
+        assert blob[8:16] == struct.pack("<Q", int(w[0]))
+        assert np.array_equal(spf_amd.ciphertext_from_bincode(kind, blob), w), name
+        assert np.array_equal(spf_amd.ciphertext_from_bincode(kind, blob + b"\x01\x02\x03"), w), name
+
+
+def test_ciphertext_bincode_rejects_the_references_malformed_vector():
+    """rejects_malformed_serialized_ciphertext (safe_bincode.rs:58-77): the reference's own negative vector, for
+    every serializable kind; plus a count off by one either way, a truncated body, and a truncated count."""
+    bad = bytes(_kats()["bytes"])
+    for name, kind in _KINDS.items():
+        with pytest.raises(spf_amd.SpfError):
+            spf_amd.ciphertext_from_bincode(kind, bad)
+        n = spf_amd.ciphertext_words(kind)
+        good = spf_amd.ciphertext_to_bincode(kind, np.arange(n, dtype=np.uint64))
+        for broken in (struct.pack("<Q", n + 1) + good[8:] + b"\0" * 8,   # longer than GetSize allows
+                       struct.pack("<Q", n - 1) + good[8:],               # check_is_valid: wrong length
+                       good[:-1], good[:5], b""):
+            with pytest.raises(spf_amd.SpfError):
+                spf_amd.ciphertext_from_bincode(kind, broken)
+    # a ciphertext of one kind is not accepted as another
+    l0 = spf_amd.ciphertext_to_bincode(0, np.zeros(638, dtype=np.uint64))
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.ciphertext_from_bincode(1, l0)
+
+
+def test_l1ggsw_has_no_wire_format():
+    """L1GgswCiphertext derives only Clone (encryption.rs:93-97): refused, not invented."""
+    with pytest.raises(spf_amd.SpfError) as e:
+        spf_amd.ciphertext_from_bincode(3, b"\0" * 64)
+    assert e.value.status == 4
