@@ -4,7 +4,7 @@
 //       (ops/automorphisms/mod.rs:53-85: log2 N rounds of automorphism + FFT-domain GLWE
 //        keyswitch, ops/fft_ops.rs:457-495)
 //   scheme_switch_fft            (ops/fft_ops.rs:225-279, 403-442)  GLEV -> GGSW-FFT
-// Both kernels use the two-waves-per-ciphertext layout of blind_rotate2_kernel (wave w owns the
+// Both kernels use the two-waves-per-ciphertext layout of the blind rotation (wave w owns the
 // complex samples of parity w; one 4 KiB cross exchange per transform) and the same arithmetic
 // (DAG-I transforms, AVX-512-order complex_mad, reference rounding).  A work unit is one
 // (ciphertext, gadget level) pair; the automorphism / scheme-switch keys are small (2.1 MB /
@@ -103,7 +103,7 @@ __device__ __forceinline__ void pair_inverse(const PairCtx& c, uint32_t& seq, co
     }
 }
 
-// round(), mod 2^64, `as i64` of 16 values (see blind_rotate_kernel for the two exact paths)
+// round(), mod 2^64, `as i64` of 16 values (the two exact paths: spf_device.hpp)
 __device__ __forceinline__ void tv_to_torus(const double (&tv)[16], uint64_t (&out)[16])
 {
     double mn = __builtin_fabs(tv[0]);

@@ -224,37 +224,14 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
-    // variant 2 (default): two waves per ciphertext, 512-thread workgroups; variant 1: one wave
-    // per ciphertext, 256-thread workgroups.  Same results; SPF_BLIND_ROTATE_VARIANT picks.
-    static const int variant = [] {
-        const char* e = getenv("SPF_BLIND_ROTATE_VARIANT");
-        return (e && e[0] == '1') ? 1 : 2;
-    }();
-    // ciphertexts per workgroup of variant 2: four when the batch fills the chip that way, fewer to
-    // spread a small batch over more CUs (SPF_CTS_PER_WG overrides, for measurements)
-    static const int cts_override = [] {
-        const char* e = getenv("SPF_CTS_PER_WG");
-        return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0;
-    }();
-    // the small shapes run the two-transforms-at-once schedule (blind_rotate2w_kernel); SPF_WIDE=0 keeps
-    // the narrow schedule for A/B measurements
-    static const bool wide = [] { const char* e = getenv("SPF_WIDE"); return !(e && e[0] == '0'); }();
+    // Shape by batch size: at most one ciphertext per CU -> four waves per ciphertext (blind_rotate4_kernel, latency);
+    // up to two per CU -> the paired schedule with two ciphertexts per workgroup (blind_rotate2p2_kernel);
+    // beyond -> four ciphertexts per workgroup, one workgroup per CU, two waves per SIMD (blind_rotate2p_kernel).
     const size_t n_cu = (size_t)c->n_cu;
-    // up to two ciphertexts per CU: the latency schedule, one ciphertext per workgroup (two such
-    // workgroups share a CU when B > #CU: 65 KiB of LDS and one wave per SIMD each)
-    const int cts = cts_override ? cts_override : (B <= 2 * n_cu ? (wide ? 1 : (B <= n_cu ? 1 : 2)) : 4);
-    // at most one ciphertext per CU: four waves per ciphertext (blind_rotate4_kernel); SPF_QUAD=0 disables
-    static const bool quad_on = [] { const char* e = getenv("SPF_QUAD"); return !(e && e[0] == '0'); }();
-    // SPF_MID picks the shape between one and two ciphertexts per CU: "pair" (default) = the paired throughput
-    // schedule with two ciphertexts per workgroup, "quad" = two rounds of the four-wave kernel (from 1.2 per CU),
-    // "wide" = blind_rotate2w_kernel
-    static const int mid = [] { const char* e = getenv("SPF_MID"); return !e ? 2 : (e[0] == 'q' ? 1 : (e[0] == 'w' ? 0 : 2)); }();
-    const bool between = B > n_cu && B <= 2 * n_cu && variant == 2 && wide && !cts_override;
-    const bool pair2 = between && mid == 2;
-    const bool quad = variant == 2 && wide && quad_on && !cts_override &&
-                      (B <= n_cu || (mid == 1 && 10 * B > 12 * n_cu && B <= 2 * n_cu));
-    const size_t per_wg = pair2 ? 2 : (variant == 2 ? (size_t)cts : (size_t)kWavesPerBlock);
-    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(variant == 2 ? ((quad || pair2) ? 256 : 128 * cts) : 256);
+    const bool quad = B <= n_cu;
+    const bool pair2 = !quad && B <= 2 * n_cu;
+    const size_t per_wg = quad ? 1 : (pair2 ? 2 : 4);
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block((quad || pair2) ? 256 : 512);
     TimedLaunch tl{};
     if (c->timing) {
         spf_status st = get_events(c, &tl.start, &tl.stop);
@@ -265,32 +242,17 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     static uint64_t* d_stamps = nullptr;
     const size_t stamp_waves = quad ? 4 : 8;
     const size_t n_stamp = (size_t)grid.x * stamp_waves * 16;
-    if (cts == 4 || quad) {
+    if (!pair2) {
         if (d_stamps) (void)hipFree(d_stamps);
         HIPCHK(c, hipMalloc(&d_stamps, n_stamp * 8));
         HIPCHK(c, hipMemsetAsync(d_stamps, 0, n_stamp * 8, s));
         a.stamps = d_stamps;
     }
 #endif
-    // SPF_PAIRED=0 keeps the one-digit-at-a-time throughput kernel (blind_rotate2_kernel) for A/B runs
-    static const bool paired = [] { const char* e = getenv("SPF_PAIRED"); return !(e && e[0] == '0'); }();
 #define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
     if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16>), kBlindRotate4Lds);
     else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,6>", (blind_rotate2p2_kernel<2, 16, 6>), kBlindRotate2p2Lds);
-    else if (variant == 2 && cts == 4 && paired) {
-        static const int p_opt = [] { const char* e = getenv("SPF_P_OPT"); return e ? atoi(e) : 6; }();
-        switch (p_opt) {
-        case 0: SPF_LAUNCH("blind_rotate2p_kernel<2,16,0>", (blind_rotate2p_kernel<2, 16, 0>), kBlindRotate2pLds); break;
-        case 1: SPF_LAUNCH("blind_rotate2p_kernel<2,16,1>", (blind_rotate2p_kernel<2, 16, 1>), kBlindRotate2pLds); break;
-        case 2: SPF_LAUNCH("blind_rotate2p_kernel<2,16,2>", (blind_rotate2p_kernel<2, 16, 2>), kBlindRotate2pLds); break;
-        default: SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6>), kBlindRotate2pLds); break;
-        }
-    }
-    else if (variant == 2 && cts == 4) SPF_LAUNCH("blind_rotate2_kernel<2,16,4>", (blind_rotate2_kernel<2, 16, 4>), blind_rotate2_lds<4>());
-    else if (variant == 2 && wide && cts == 1) SPF_LAUNCH("blind_rotate2w_kernel<2,16,1>", (blind_rotate2w_kernel<2, 16, 1>), blind_rotate2w_lds<1>());
-    else if (variant == 2 && cts == 2) SPF_LAUNCH("blind_rotate2_kernel<2,16,2>", (blind_rotate2_kernel<2, 16, 2>), blind_rotate2_lds<2>());
-    else if (variant == 2) SPF_LAUNCH("blind_rotate2_kernel<2,16,1>", (blind_rotate2_kernel<2, 16, 1>), blind_rotate2_lds<1>());
-    else SPF_LAUNCH("blind_rotate_kernel<2,16>", (blind_rotate_kernel<2, 16>), kBlindRotateLds);
+    else SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
@@ -499,24 +461,12 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
         CK(hipMalloc((void**)&c->d_cbs_lut, lut.size() * 8));
         CK(hipMemcpy(c->d_cbs_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice));
     }
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate_kernel<2, 16>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotateLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 4>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<4>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            kKsLdsBytes));
-#define SPF_P_ATTR(O) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, O>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds))
-    SPF_P_ATTR(0); SPF_P_ATTR(1); SPF_P_ATTR(2); SPF_P_ATTR(6);
-#undef SPF_P_ATTR
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 6>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 6>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 2>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<2>()));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2_kernel<2, 16, 1>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2_lds<1>()));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2w_kernel<2, 16, 1>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, blind_rotate2w_lds<1>()));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 4>),

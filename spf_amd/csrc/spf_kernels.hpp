@@ -1,13 +1,17 @@
 // spf_kernels.hpp — gfx950 kernels of the bootstrap path.
 //
-// blind_rotate_kernel: ONE WAVEFRONT PER CIPHERTEXT.  The wave keeps the GLWE accumulator
-// (2 x 2048 u64) and the frequency-domain external-product accumulator (2 x 1024 c64) in its
-// registers for all n CMUX steps; LDS is used only as a 16 KiB per-wave tile for the negacyclic
-// rotation gather and the in-wave FFT exchanges.  There is no workgroup barrier inside the
-// loop: the four waves of a workgroup (four ciphertexts) only share the 32 KiB twiddle image.
-// The bootstrapping key is read in the reference's own layout (natural DFT bin order):
-// lane l touches bins l + 64 r, so every key load is a fully coalesced 1 KiB wave access, and
-// all workgroups walk the key in the same order, so it is served from L2 / Infinity Cache.
+// Blind rotation, TWO WAVEFRONTS PER CIPHERTEXT split by sample parity (wave w owns the complex samples of parity w —
+// polynomial coefficients c = half*1024 + 128*n1 + 2*lane + w — exactly the input of one of the two 512-point transforms
+// of DAG-I; the forward transform ends with, and the inverse starts with, an exchange between the two waves):
+//   blind_rotate2p_kernel   throughput shape: four ciphertexts per 512-thread workgroup, two waves per SIMD, key ring
+//   blind_rotate2p2_kernel  the same body with two ciphertexts per workgroup (one to two ciphertexts per CU)
+//   blind_rotate4_kernel    latency shape: four waves per ciphertext (parity x polynomial), at most one ciphertext per CU
+// and the CMUX-tree gates (cmux_kernel, cmux4_kernel), the int8-MFMA keyswitch, and the small streaming kernels.
+// Each wave keeps its share of the GLWE accumulator and of the frequency-domain product in registers for all n steps.
+// The bootstrapping key is read in the reference's own layout (natural DFT bin order): lane l touches bins l + 64 r,
+// every key access is a fully coalesced 1 KiB wave access, and all workgroups walk the key in the same order.
+// (r01's one-wave-per-ciphertext kernel, the one-digit-at-a-time two-wave kernel and the two-wave latency kernel were
+// retired in r03: no dispatch path selected them any more; their measurements are in DESIGN.md §5.)
 //
 // Reference path reproduced (sunscreen_tfhe/src):
 //   ops/bootstrapping/programmable_bootstrapping.rs:342-410  generalized_programmable_bootstrap
@@ -52,38 +56,7 @@ __device__ __forceinline__ uint32_t mod_switch_2n(uint64_t x, uint32_t log_chi, 
     return (uint32_t)(((x + round) & ((1u << log_modulus) - 1)) << log_v);
 }
 
-// Lane-private element e in [0,32) of a polynomial <-> coefficient index.
-//   e = half*16 + n1*2 + par ;  coefficient c = half*1024 + 128*n1 + 2*lane + par
-// i.e. complex sample (2*(64*n1+lane) + par) = (coef c, coef c + 1024), the layout the
-// parity-split FFT-512 pair of DAG-I wants (lane = n' mod 64, register = n' div 64).
-__device__ __forceinline__ int coef_of(int e, int lane)
-{
-    return (e >> 4) * 1024 + ((e >> 1) & 7) * 128 + 2 * lane + (e & 1);
-}
-
-// de-interleaved staging position of coefficient c inside the 16 KiB tile (u64 index)
-__device__ __forceinline__ int stage_pos(int c) { return ((c & 1) << 10) | (c >> 1); }
-
-// LDS map of blind_rotate_kernel (163 712 of the CU's 163 840 bytes, one workgroup per CU):
-//   [0, 32640)            twiddle image (spf_device.hpp)
-//   [32640, +4 x 16384)   per-wave tile: rotation staging / FFT exchanges
-//   [98176, +2 x 32768)   bootstrapping-key ring: the 32 KiB GLWE-FFT row pair the whole
-//                         workgroup multiplies by next, filled by LDS-DMA (global_load_lds)
-constexpr int kBskSlotBytes = 2 * kHalf * 16; // one (row, level): both output polynomials
-constexpr int kBlindRotateLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 2 * kBskSlotBytes;
-
-// issue this thread's share of the DMA that brings one 32 KiB key slot into LDS: 8 x 16 bytes
-// per lane, each wave-instruction lands 1 KiB contiguously (wave-uniform base + lane*16).
-__device__ __forceinline__ void bsk_slot_dma(const c64* src, char* slot, int tid)
-{
-    const int wave_base = tid & ~63;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + k * 256 + tid),
-            (__attribute__((address_space(3))) void*)(slot + (k * 256 + wave_base) * 16), 16, 0, 0);
-    }
-}
+constexpr int kBskSlotBytes = 2 * kHalf * 16; // one (row, level) of the bootstrapping key: both output polynomials
 
 // One LDS-DMA piece in the scalar-base form: 64 lanes x 16 bytes from `sbase + voff` (sbase wave-uniform
 // in an SGPR pair, voff this lane's 32-bit byte offset) to LDS bytes [lds, lds + 1024) (lds wave-uniform,
@@ -102,234 +75,6 @@ __device__ __forceinline__ uint32_t lds_address(const void* p)
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <int L, int LOGB> // gadget: L digits of LOGB bits, L*LOGB <= 32
-__global__ __launch_bounds__(256, 1) void blind_rotate_kernel(BlindRotateArgs a)
-{
-    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    c64* tab = reinterpret_cast<c64*>(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    char* wbuf = smem + kTableBytes + wave * kWaveBufBytes;
-    char* bskring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
-
-    // twiddle image -> LDS
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
-    }
-
-    // The four waves of a workgroup walk the key in lockstep (one barrier per digit), so a wave
-    // without a ciphertext of its own (ragged last workgroup) shadows the last one and skips
-    // the final store.
-    const uint32_t ct_raw = blockIdx.x * kWavesPerBlock + wave;
-    const bool owns_output = ct_raw < a.B;
-    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
-
-    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
-    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
-    uint64_t* stage = reinterpret_cast<uint64_t*>(wbuf);
-
-    // key slot for global digit index g = step*2L + m lives at
-    //   bsk[step][p][L-1-j][.][.]  with p = m / L, j = m % L  (GLEV rows consumed in reverse,
-    //   fft_ops.rs:92: digit j, least significant first, pairs with level L-1-j)
-    const uint32_t total_g = a.n * (2 * L);
-    auto slot_src = [&](uint32_t g) -> const c64* {
-        uint32_t step = g / (2 * L), m = g % (2 * L), p = m / L, j = m % L;
-        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf);
-    };
-    bsk_slot_dma(slot_src(0), bskring, tid);
-
-    // ---- acc = LUT * X^{-b~}  (programmable_bootstrapping.rs:385-390)
-    uint64_t acc[2][32];
-    {
-        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 32; e++) {
-                uint32_t idx = (uint32_t)coef_of(e, lane) + bt; // < 3N
-                uint64_t v = lut[p * kN + (idx & (kN - 1))];
-                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-            }
-    }
-    __syncthreads(); // twiddle image complete
-
-    uint64_t a_next = lwe[0];
-    uint32_t g = 0;
-    for (uint32_t step = 0; step < a.n; step++) {
-        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
-        a_next = lwe[step + 1]; // the body word on the last step: harmless, in bounds
-
-        // ---- external product in the frequency domain (fft_ops.rs:23-124)
-        c64 prod[2][16];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) prod[q][r] = {0.0, 0.0};
-
-#pragma unroll
-        for (int p = 0; p < 2; p++) { // GLWE polynomial: a then b (fft_ops.rs:43-55)
-            // ---- diff_p = (acc * X^{a~} - acc)_p, rounded and decomposed; the L digits of a
-            // coefficient are packed LOGB bits each into one register
-            uint32_t dig[32];
-#pragma unroll
-            for (int e = 0; e < 32; e++) stage[stage_pos(coef_of(e, lane))] = acc[p][e];
-            wave_lds_fence();
-#pragma unroll
-            for (int e = 0; e < 32; e++) {
-                uint32_t idx = (uint32_t)coef_of(e, lane) + 2 * kN - at; // in (0, 3N)
-                uint64_t v = stage[stage_pos((int)(idx & (kN - 1)))];
-                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                uint64_t diff = rot - acc[p][e];
-                // round (radix.rs:157-162): keep the top L*LOGB bits, add the bit below
-                constexpr int shift = 64 - L * LOGB;
-                uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
-                // vector_next_decomp (scalar.rs:52-71), all L digits; only the low L*LOGB
-                // bits of the rounded value can reach a digit
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < L; j++) {
-                    uint32_t d = s & ((1u << LOGB) - 1);
-                    s >>= LOGB;
-                    s += d >> (LOGB - 1);
-                    packed |= d << (j * LOGB); // digit value = sign-extended d
-                }
-                dig[e] = packed;
-            }
-            compiler_fence();
-
-#pragma unroll 1
-            for (int j = 0; j < L; j++, g++) { // digit, least significant first
-                const int sh = j * LOGB;
-                c64 E[8], O[8];
-#pragma unroll
-                for (int n1 = 0; n1 < 8; n1++) {
-#pragma unroll
-                    for (int par = 0; par < 2; par++) {
-                        int dre = ((int)(dig[n1 * 2 + par] << (32 - LOGB - sh))) >> (32 - LOGB);
-                        int dim = ((int)(dig[16 + n1 * 2 + par] << (32 - LOGB - sh))) >> (32 - LOGB);
-                        // PolynomialRef::fft: i64 -> f64, then complex_twist (scalar.rs:19-23)
-                        c64 z = cmul_nf({(double)dre, (double)dim}, tab[kTWOff + par * 512 + 64 * n1 + lane]);
-                        if (par == 0) E[n1] = z; else O[n1] = z;
-                    }
-                }
-                fft512_pair<+1>(E, O, wbuf, wbuf + 8192, tab, lane);
-                c64 X[16];
-#pragma unroll
-                for (int d = 0; d < 8; d++) {
-                    c64 t = cmul_tw<+1>(O[d], tab[kWCOff + lane + 64 * d]);
-                    X[d] = cadd(E[d], t);
-                    X[d + 8] = csub(E[d], t);
-                }
-                // key slot g has been in flight since the previous digit; make it visible to the
-                // whole workgroup, then start the DMA of slot g+1 into the other half of the ring
-                // (every wave is past its reads of that half: they precede this barrier).
-                // (an LDS-DMA is tracked by vmcnt; hipcc does not drain it at a barrier by itself)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (g + 1 < total_g) bsk_slot_dma(slot_src(g + 1), bskring + ((g + 1) & 1) * kBskSlotBytes, tid);
-                const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes);
-                // glwe_polynomial_mad (fft_ops.rs:107-124) -> complex_mad, c += a * b with
-                // a = key, b = digit transform, in the order of the reference's AVX-512 path
-                // (math/simd/x86_64/avx512.rs:54-57): re += a.re*b.re; im += a.re*b.im;
-                // re -= a.im*b.im; im += a.im*b.re — four FMAs.
-#pragma unroll
-                for (int q = 0; q < 2; q++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        c64 k = row[q * kHalf + lane + 64 * r];
-                        double re = __builtin_fma(k.re, X[r].re, prod[q][r].re);
-                        double im = __builtin_fma(k.re, X[r].im, prod[q][r].im);
-                        prod[q][r].re = __builtin_fma(-k.im, X[r].im, re);
-                        prod[q][r].im = __builtin_fma(k.im, X[r].re, im);
-                    }
-            }
-        }
-
-        // ---- back to the torus and acc = prod + acc (fft_ops.rs:176-180)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            c64 E[8], O[8];
-#pragma unroll
-            for (int d = 0; d < 8; d++) {
-                E[d] = cadd(prod[q][d], prod[q][d + 8]);
-                c64 dd = csub(prod[q][d], prod[q][d + 8]);
-                O[d] = cmul_tw<-1>(dd, tab[kWCOff + lane + 64 * d]);
-            }
-            fft512_pair<-1>(E, O, wbuf, wbuf + 8192, tab, lane);
-            // complex_untwist (scalar.rs:26-35): (x * n_inv) * twist_inv
-            double tv[32];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++)
-#pragma unroll
-                for (int par = 0; par < 2; par++) {
-                    c64 y = par ? O[n1] : E[n1];
-                    c64 xs = {y.re * (1.0 / 1024.0), y.im * (1.0 / 1024.0)};
-                    c64 t = cmul_nf_conj(xs, tab[kTWOff + par * 512 + 64 * n1 + lane]);
-                    tv[n1 * 2 + par] = t.re;
-                    tv[16 + n1 * 2 + par] = t.im;
-                }
-            // round(), mod 2^64, `as i64` (scalar.rs:32-33,75-119; torus.rs:177-192).  Products of
-            // real keys are ~2^80: every value is already an integer (|v| >= 2^52), for which a
-            // short exact conversion exists; the wave takes it only if ALL its values qualify,
-            // otherwise the literal sequence.  Both give identical words where both apply.
-            double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-            for (int e = 1; e < 32; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-            if (__all(mn >= 4503599627370496.0)) {
-#pragma unroll
-                for (int e = 0; e < 32; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 32; e++) acc[q][e] += f64_round_to_torus(tv[e]);
-            }
-        }
-    }
-
-    // ---- output
-    if (!owns_output) return;
-    if (!a.sample_extract) {
-        uint64_t* out = a.out + (size_t)ct * a.out_stride;
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 32; e += 2) {
-                ulonglong2 v2 = {acc[p][e], acc[p][e + 1]};
-                *reinterpret_cast<ulonglong2*>(out + p * kN + coef_of(e, lane)) = v2;
-            }
-    } else {
-        // sample_extract(., 0) (ops/ciphertext/glwe_ciphertext_ops.rs:31-76):
-        // a_lwe[0] = a[0]; a_lwe[j] = -a[N-j] (j >= 1); b_lwe = b[0]
-        uint64_t* out = a.out + (size_t)ct * a.out_stride;
-#pragma unroll
-        for (int e = 0; e < 32; e++) {
-            int c = coef_of(e, lane);
-            if (c == 0) {
-                out[0] = acc[0][e];
-                out[kN] = acc[1][e];
-            } else {
-                out[kN - c] = (uint64_t)0 - acc[0][e];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// blind_rotate2_kernel: TWO WAVEFRONTS PER CIPHERTEXT, eight waves (four ciphertexts) per
-// workgroup, i.e. two waves per SIMD, so one wave's LDS round trips and barrier waits hide under
-// its SIMD partner's f64 issue.  Wave w (0/1) of a ciphertext owns the complex samples of parity
-// w — polynomial coefficients c = half*1024 + 128*n1 + 2*lane + w — which is exactly the input of
-// one of the two 512-point transforms of DAG-I: the forward transform ends with, and the inverse
-// starts with, a 4 KiB exchange between the two waves (the radix-2 stage across parities); all
-// other FFT exchanges stay inside a wave.  Same arithmetic, bit for bit, as blind_rotate_kernel.
-//
-// The ciphertext's 16 KiB tile is two 8 KiB regions, region w written only by wave w:
-// rotation staging (region = coefficient parity), the wave's private FFT exchange image, and the
-// outgoing half of the cross exchange.  A workgroup barrier precedes every first write of a
-// region after a phase in which the partner reads it.
 // Two-wave rendezvous through an LDS word per wave (the two waves of one ciphertext): publish my
 // phase number, spin until the partner has published the same.  LDS services a CU's DS
 // instructions in order, so data written (and drained with lgkmcnt(0)) before the flag is
@@ -353,8 +98,7 @@ __device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, i
     asm volatile("" ::: "memory");
 }
 
-// Rendezvous of the latency shape: one ciphertext per workgroup, so the pair IS the workgroup and
-// s_barrier does it.  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
+// Hand-over as a bare workgroup barrier (LDS queue drained first).  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
 // loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
 __device__ __forceinline__ void pair_barrier_w()
 {
@@ -363,508 +107,12 @@ __device__ __forceinline__ void pair_barrier_w()
     asm volatile("" ::: "memory");
 }
 
-//
-// CTS = ciphertexts per workgroup (4, 2 or 1; 128 CTS threads).  Four fill the CU (two waves per
-// SIMD) and share each key slot four ways: the throughput shape.  For batches that do not fill
-// the chip that way (B < 1024) fewer ciphertexts per workgroup spread the batch over more CUs, and
-// a wave that has its SIMD to itself finishes a CMUX step sooner: the latency shape (one
-// 32-bit addition = a 64-wide bootstrap).  Same arithmetic, same results.
-template <int CTS>
-constexpr int blind_rotate2_lds() { return kTableBytes + CTS * kWaveBufBytes + 2 * kBskSlotBytes + 64; }
-
-template <int L, int LOGB, int CTS>
-__global__ __launch_bounds__(128 * CTS, (CTS + 1) / 2) void blind_rotate2_kernel(BlindRotateArgs a)
-{
-    static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
-    static_assert(CTS == 1 || CTS == 2 || CTS == 4, "1, 2 or 4 ciphertexts per workgroup");
-    constexpr int NT = 128 * CTS;
-    // twiddles prefetched per pass: all seven when a wave has its SIMD (and 512 registers) to itself;
-    // none at two waves per SIMD, where every prefetched value spills and the partner wave covers
-    // the round trips anyway (measured: 2 -> no change, 3 or 4 -> 1.5 % slower)
-    constexpr int kFftPre = CTS == 4 ? 0 : 7;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    c64* tab = reinterpret_cast<c64*>(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int cslot = wv >> 1;
-    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
-    char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
-    char* mine = tile + w * 8192;
-    char* theirs = tile + (w ^ 1) * 8192;
-    char* bskring = smem + kTableBytes + CTS * kWaveBufBytes;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(bskring + 2 * kBskSlotBytes);
-    uint32_t seq = 0;
-    const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
-
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
-        if (tid < 8) flags[tid] = 0;
-    }
-
-    const uint32_t ct_raw = blockIdx.x * CTS + cslot;
-    const bool owns_output = ct_raw < a.B;
-    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
-    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
-    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
-
-    const uint32_t total_g = a.n * (2 * L);
-    auto slot_src = [&](uint32_t g) -> const c64* {
-        uint32_t step = g / (2 * L), m = g % (2 * L), p = m / L, j = m % L;
-        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf);
-    };
-    auto slot_dma = [&](uint32_t g) {
-        const c64* src = slot_src(g);
-        char* dst = bskring + (g & 1) * kBskSlotBytes;
-        const int wave_base = tid & ~63;
-#pragma unroll
-        for (int k = 0; k < 2 * kHalf / NT; k++)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + k * NT + tid),
-                (__attribute__((address_space(3))) void*)(dst + (k * NT + wave_base) * 16), 16, 0, 0);
-    };
-    slot_dma(0);
-
-    // lane-private element e = half*8 + n1  <->  coefficient half*1024 + 128*n1 + 2*lane + w
-    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
-
-    uint64_t acc[2][16];
-    {
-        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint32_t idx = (uint32_t)coef2(e) + bt;
-                uint64_t v = lut[p * kN + (idx & (kN - 1))];
-                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-            }
-    }
-    __syncthreads();
-
-    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
-    const c64* twist = tab + kTWOff + w * 512 + lane;   // e^{+i pi (2n'+w)/2048}, n' = 64 n1 + lane
-    const c64* wc = tab + kWCOff + 256 * w + lane;       // W1024^{lane + 64 (4w + i)}
-    uint64_t a_next = lwe[0];
-    uint32_t g = 0;
-    for (uint32_t step = 0; step < a.n; step++) {
-        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
-        a_next = lwe[step + 1];
-
-        c64 prod[2][8]; // bins lane + 64 (4w + i) + 512 s  at index i + 4 s
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
-
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            uint32_t dig[16];
-            // partner must be done reading my region: for p = 0 the barrier ahead of the last
-            // inverse transform already guarantees it
-            if (p == 1) pair_barrier(flags, me, partner, seq);
-#pragma unroll
-            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
-            pair_barrier(flags, me, partner, seq); // both parities staged
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
-                uint32_t srcc = idx & (kN - 1);
-                uint64_t v = reinterpret_cast<const uint64_t*>(tile + (srcc & 1) * 8192)[srcc >> 1];
-                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
-            }
-
-#pragma unroll 1
-            for (int j = 0; j < L; j++, g++) {
-                c64 V[8];
-#pragma unroll
-                for (int n1 = 0; n1 < 8; n1++) V[n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[64 * n1]);
-                pair_barrier(flags, me, partner, seq); // partner is done gathering / done with my last cross data
-                fft512_single<+1, kFftPre>(V, mine, tab, lane);
-                // radix-2 stage across the two waves: wave 0 finishes bins with d < 4, wave 1 d >= 4
-                c64 Ei[4], Oi[4];
-                if (w == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[4 + i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[i];
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of key slot g has landed
-                __syncthreads();
-                if (g + 1 < total_g) slot_dma(g + 1);
-                if (w == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { Ei[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; Oi[i] = V[4 + i]; }
-                }
-                c64 X[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    c64 t = cmul_tw<+1>(Oi[i], wc[64 * i]);
-                    X[i] = cadd(Ei[i], t);
-                    X[i + 4] = csub(Ei[i], t);
-                }
-                const c64* row = reinterpret_cast<const c64*>(bskring + (g & 1) * kBskSlotBytes) + 256 * w + lane;
-                // key reads run two pairs ahead of the FMAs that consume them (left to itself
-                // the compiler reads two values, drains lgkmcnt, uses them: eight exposed LDS round
-                // trips per digit)
-                c64 kb[3][2];
-                auto key2 = [&](int grp, c64 (&dst)[2]) {
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
-                        dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
-                    }
-                };
-                key2(0, kb[0]);
-                key2(1, kb[1]);
-#pragma unroll
-                for (int grp = 0; grp < 8; grp++) {
-                    if (grp + 2 < 8) key2(grp + 2, kb[(grp + 2) % 3]);
-                    compiler_fence();
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
-                        const c64 k = kb[grp % 3][i];
-                        double re = __builtin_fma(k.re, X[r].re, prod[q][r].re);
-                        double im = __builtin_fma(k.re, X[r].im, prod[q][r].im);
-                        prod[q][r].re = __builtin_fma(-k.im, X[r].im, re);
-                        prod[q][r].im = __builtin_fma(k.im, X[r].re, im);
-                    }
-                }
-            }
-        }
-
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            c64 Ep[4], Op[4], V[8];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                Ep[i] = cadd(prod[q][i], prod[q][i + 4]);
-                c64 dd = csub(prod[q][i], prod[q][i + 4]);
-                Op[i] = cmul_tw<-1>(dd, wc[64 * i]);
-            }
-            if (q == 0) pair_barrier(flags, me, partner, seq); // partner is done with my last forward cross data
-            if (w == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Op[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = Ep[i];
-            }
-            pair_barrier(flags, me, partner, seq);
-            if (w == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { V[i] = Ep[i]; V[4 + i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { V[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; V[4 + i] = Op[i]; }
-            }
-            pair_barrier(flags, me, partner, seq); // both cross reads retired before either region is overwritten
-            fft512_single<-1, kFftPre>(V, mine, tab, lane);
-            double tv[16];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-                c64 t = cmul_nf_conj(xs, twist[64 * n1]);
-                tv[n1] = t.re;
-                tv[8 + n1] = t.im;
-            }
-            double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-            for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-            if (__all(mn >= 4503599627370496.0)) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[q][e] += f64_bigint_to_torus(tv[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[q][e] += f64_round_to_torus(tv[e]);
-            }
-        }
-    }
-
-    if (!owns_output) return;
-    uint64_t* out = a.out + (size_t)ct * a.out_stride;
-    if (!a.sample_extract) {
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            int c = coef2(e);
-            if (c == 0) {
-                out[0] = acc[0][e];
-                out[kN] = acc[1][e];
-            } else {
-                out[kN - c] = (uint64_t)0 - acc[0][e];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// blind_rotate2w_kernel: the LATENCY shape of blind_rotate2_kernel, for batches that leave most of
-// the chip idle (B <= 2 x #CU): ONE ciphertext per workgroup (two such workgroups share a CU when
-// B > #CU), one wave per SIMD, so a wave owns 512 registers and 16 KiB of LDS — enough to advance TWO
-// transforms at once.  Same split of a
-// ciphertext over two waves (sample parity), same arithmetic and results; what changes is the
-// schedule of one CMUX step:
-//   * both digits of a polynomial go through `fft512_pair` together (one transform's exchange round
-//     trip under the other's butterflies), their cross exchanges share one rendezvous, and both
-//     multiply-accumulates follow;
-//   * both output polynomials do the same on the way back;
-//   * no key ring and no workgroup barrier: so few waves share a key value that each reads its own
-//     bins straight into registers at the top of the polynomial (the LDS-DMA pieces of a ring cost a
-//     lone wave 16 % of its step just to issue); the rendezvous of the two waves does not touch
-//     vmcnt, so those loads stay in flight across it.
-// A lone wave of the narrow schedule issues only 38 % of the time (its own LDS round trips and
-// rendezvous); this schedule has two independent chains to interleave.
-template <int CTS>
-constexpr int blind_rotate2w_lds() { return kTableBytes + CTS * 2 * kWaveBufBytes; }
-
-template <int L, int LOGB, int CTS>
-__global__ __launch_bounds__(128 * CTS, 1) void blind_rotate2w_kernel(BlindRotateArgs a)
-{
-    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
-    static_assert(CTS == 1, "one ciphertext per workgroup: the pair rendezvous is s_barrier");
-    constexpr int NT = 128 * CTS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    c64* tab = reinterpret_cast<c64*>(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int cslot = wv >> 1;
-    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
-    // per ciphertext: [wave 0: image A, image B][wave 1: image A, image B], 8 KiB each
-    char* tile = smem + kTableBytes + cslot * 2 * kWaveBufBytes;
-    char* mine = tile + w * 16384;
-    char* mineB = mine + 8192;
-    char* theirs = tile + (w ^ 1) * 16384;
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
-    }
-    const uint32_t ct_raw = blockIdx.x * CTS + cslot;
-    const bool owns_output = ct_raw < a.B;
-    const uint32_t ct = owns_output ? ct_raw : a.B - 1;
-    const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
-    const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
-
-    // No key ring here: with one or two ciphertexts per workgroup a key value is used by one or two
-    // waves, so each wave reads the bins it multiplies straight from L2/HBM into registers (16 x 1 KiB
-    // per digit), at the top of the polynomial, and they land while it decomposes and transforms.
-    // Key row (step, p, level L-1-j): GLEV rows are consumed in reverse.
-    auto key_row = [&](uint32_t step, int p, int j) -> const c64* {
-        return a.bsk + ((size_t)step * (2 * L) + (p * L + (L - 1 - j))) * (2 * kHalf) + 256 * w + lane;
-    };
-    auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
-
-    uint64_t acc[2][16];
-    {
-        uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint32_t idx = (uint32_t)coef2(e) + bt;
-                uint64_t v = lut[p * kN + (idx & (kN - 1))];
-                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-            }
-    }
-
-    __syncthreads(); // twiddle image in place
-
-    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
-    // the twist factors and the cross-stage twiddles of a lane never change: with 512 registers they
-    // live in registers for the whole rotation (the narrow kernel re-reads them from the LDS image)
-    c64 twist[8], wc[4];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
-#pragma unroll
-    for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
-    uint64_t a_next = lwe[0];
-    for (uint32_t step = 0; step < a.n; step++) {
-        const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
-        a_next = lwe[step + 1];
-        c64 prod[2][8];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
-
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            // [digit][output polynomial * 8 + r]: this wave's bins of the two key rows, requested now
-            c64 key[2][16];
-            auto load_key = [&](int j) {
-                const c64* row = key_row(step, p, j);
-#pragma unroll
-                for (int q = 0; q < 2; q++)
-#pragma unroll
-                    for (int r = 0; r < 8; r++) key[j][q * 8 + r] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
-            };
-            load_key(0);
-            load_key(1);
-
-            uint32_t dig[16];
-            // partner must be done reading my region (staging and cross data live in image A): for
-            // p = 0 the rendezvous ahead of the last inverse transforms guarantees it
-            if (p == 1) pair_barrier_w();
-#pragma unroll
-            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[p][e];
-            pair_barrier_w(); // both parities staged
-            // all sixteen gather reads first (left alone the compiler issues them one at a time, each
-            // with its own lgkmcnt(0))
-            uint64_t gin[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint32_t srcc = ((uint32_t)coef2(e) + 2 * kN - at) & (kN - 1);
-                gin[e] = reinterpret_cast<const uint64_t*>(tile + (srcc & 1) * 16384)[srcc >> 1];
-            }
-            compiler_fence();
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                uint32_t idx = (uint32_t)coef2(e) + 2 * kN - at;
-                uint64_t v = gin[e];
-                uint64_t rot = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
-                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
-            }
-            c64 VV[2][8];
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
-            pair_barrier_w(); // partner is done gathering from my image A
-            fft512_pair<+1>(VV[0], VV[1], mine, mineB, tab, lane);
-            // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes
-            // bins with d < 4 and sends registers 4..7, wave 1 the other way round
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? VV[j][4 + i].re : VV[j][i].re,
-                                                                             w == 0 ? VV[j][4 + i].im : VV[j][i].im};
-            pair_barrier_w();
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                c64 X[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
-                    const c64 Ei = {w == 0 ? VV[j][i].re : in.re, w == 0 ? VV[j][i].im : in.im};
-                    const c64 Oi = {w == 0 ? in.re : VV[j][4 + i].re, w == 0 ? in.im : VV[j][4 + i].im};
-                    c64 t = cmul_tw<+1>(Oi, wc[i]);
-                    X[i] = cadd(Ei, t);
-                    X[i + 4] = csub(Ei, t);
-                }
-#pragma unroll
-                for (int r = 0; r < 8; r++) VV[j][r] = X[r];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-#pragma unroll
-                for (int q = 0; q < 2; q++)
-#pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const c64 k = key[j][q * 8 + r];
-                        double re = __builtin_fma(k.re, VV[j][r].re, prod[q][r].re);
-                        double im = __builtin_fma(k.re, VV[j][r].im, prod[q][r].im);
-                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
-                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
-                    }
-            }
-        }
-
-        // ---- back to the torus, both output polynomials together
-        c64 WW[2][8];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                       // Ep: kept by wave 0
-                WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wc[i]); // Op: kept by wave 1
-            }
-        pair_barrier_w(); // partner is done with my last forward cross data
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = {w == 0 ? WW[q][4 + i].re : WW[q][i].re,
-                                                                         w == 0 ? WW[q][4 + i].im : WW[q][i].im};
-        pair_barrier_w();
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const c64 in = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
-                WW[q][4 + i] = {w == 0 ? in.re : WW[q][4 + i].re, w == 0 ? in.im : WW[q][4 + i].im};
-                WW[q][i] = {w == 0 ? WW[q][i].re : in.re, w == 0 ? WW[q][i].im : in.im};
-            }
-        pair_barrier_w(); // both cross reads retired before either region is overwritten
-        fft512_pair<-1>(WW[0], WW[1], mine, mineB, tab, lane);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            uint64_t t[16];
-            untwist_to_torus(WW[q], twist, t);
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
-        }
-    }
-
-    if (!owns_output) return;
-    uint64_t* out = a.out + (size_t)ct * a.out_stride;
-    if (!a.sample_extract) {
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) out[p * kN + coef2(e)] = acc[p][e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            int c = coef2(e);
-            if (c == 0) {
-                out[0] = acc[0][e];
-                out[kN] = acc[1][e];
-            } else {
-                out[kN - c] = (uint64_t)0 - acc[0][e];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// blind_rotate2p_kernel: the THROUGHPUT shape with the paired schedule.  Same split as
-// blind_rotate2_kernel (two waves per ciphertext by sample parity, four ciphertexts per 512-thread
-// workgroup, two waves per SIMD, key ring in LDS) and the same arithmetic on every value; what
-// changes is the schedule of a CMUX step:
-//   * both digits of a polynomial are decomposed, twisted and transformed TOGETHER (`fft512_pair1`:
-//     one 8 KiB image, the two transforms taking turns on it), so inside a wave one transform's
-//     exchange travels under the other's butterflies, the pass twiddles / twist factors are read
-//     once for two transforms, and one cross exchange (8 KiB) serves both digits;
-//   * the ring holds the two key rows of the CURRENT polynomial (64 KiB contiguous in the reference
-//     layout: rows (p, level 0), (p, level 1)); it is refilled by LDS-DMA once per polynomial, issued
-//     right before the transform pair of the next polynomial and waited for at that polynomial's
-//     cross-exchange barrier;
-//   * both output polynomials go back through one transform pair as well.
-// Per step: 4 workgroup barriers (2 of them right behind each other's MADs) and 6 pair rendezvous,
-// against 4 and 12 in blind_rotate2_kernel.
 constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes;
 
-// OPT (A/B switches, SPF_P_OPT): bit 0 = exchange 2 of BOTH transforms of a pair in registers
-// (lane_transpose_hi3), bit 1 = of the second transform only (default: balances the LDS store path against
-// the VALU), bit 2 = two key pairs in flight in the MAD instead of three (default; 8 registers, 32 B of scratch
-// less).  Tried on this kernel and rejected (numbers in profiles/r02_experiments_blind_rotate.md): static and
-// alternating s_setprio for the younger SIMD partners, flat-polled and deferred pair rendezvous, and a
-// ping-pong schedule of the two ciphertext groups one slot apart.
+// OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
+// transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
+// three (8 registers, 32 B of scratch less).  The library instantiates OPT = 6 only; the A/B numbers of the others and of
+// everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
 template <int L, int LOGB, int OPT, int W, int CTS = 4>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
@@ -1469,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 //   out = d0 + IFFT( sum_{p,j} FFT(digit_j(d1 - d0)_p) . GGSW[p][L-1-j] ),
 // the operation `KeylessEvaluation::cmux` performs for every gate of a CMUX tree (GGSW in
 // cbs_radix shape, L = 4 digits of 4 bits at DEFAULT_128).  Same two-waves-per-ciphertext
-// arithmetic as blind_rotate2_kernel (one step, no rotation), but every ciphertext brings its own
+// arithmetic as blind_rotate2p_kernel (one step, no rotation), but every ciphertext brings its own
 // 2*L*2 polynomials of key (256 KiB at L = 4), read exactly once straight from HBM into registers:
 // algorithmic traffic 256 KiB + 3 x 32 KiB per CMUX makes this kernel HBM-bound.  No workgroup
 // barrier: the two waves of a ciphertext meet through pair_barrier only.
@@ -2307,6 +1555,6 @@ __global__ void gather_rows_kernel(const uint64_t* const* src, uint64_t* dst, ui
     dst[(size_t)r * words + j] = src[r][j];
 }
 
-// lwe_rotate (ops/homomorphisms/lwe.rs:9-20) is folded into blind_rotate_kernel's body_rotate.
+// lwe_rotate (ops/homomorphisms/lwe.rs:9-20) is folded into the blind-rotation kernels' body_rotate.
 
 } // namespace spf

@@ -50,41 +50,6 @@ def test_every_workgroup_shape_is_bit_equal(small, B):
     assert np.array_equal(got, ref)
 
 
-def _mid_batch_digest():
-    """(child process of the test below) checksum of a 300- and a 510-wide bootstrap, and an oracle check."""
-    ks = keyset(0x5EED0001, SMALL_N)
-    eng = spf_amd.Engine(to_engine_params(ks.params))
-    eng.load_bootstrap_key(ks.bsk_fft)
-    out = []
-    for B in (300, 510):
-        lwe = random_lwe_batch(5000 + B, B, SMALL_N)
-        got = eng.circuit_bootstrap_pbs(lwe)
-        assert np.array_equal(got[B - 1], O.cbs_pbs(lwe[B - 1], ks.bsk_fft, ks.params))
-        out.append(int(np.bitwise_xor.reduce(got.reshape(-1) * np.arange(1, got.size + 1, dtype=np.uint64))))
-    print("digest", out, eng.last_blind_rotate_kernel())
-
-
-@pytest.mark.parametrize("mid", ["pair", "quad", "wide"])
-def test_alternate_mid_batch_shapes_are_bit_equal(mid):
-    """Between one and two ciphertexts per CU three kernels can run (SPF_MID, read once per process, hence the child
-    processes): the two-ciphertext paired schedule (default), two rounds of the four-wave kernel, the two-wave
-    latency kernel.  Same words from all three."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    runs = {}
-    for m in ("pair", mid):
-        r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_parity as t; t._mid_batch_digest()"],
-                           capture_output=True, text=True, cwd=root, env=dict(os.environ, SPF_MID=m), timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        line = [l for l in r.stdout.splitlines() if l.startswith("digest")][-1]
-        runs[m] = line
-    kernel = {"pair": "blind_rotate2p2_kernel", "quad": "blind_rotate4_kernel", "wide": "blind_rotate2w_kernel"}[mid]
-    assert kernel in runs[mid], runs[mid]
-    assert runs[mid].split("]")[0] == runs["pair"].split("]")[0], (runs[mid], runs["pair"])
-
-
 @pytest.mark.parametrize("log_chi,log_v,rot", [(0, 0, 0), (0, 2, 1 << 62), (1, 1, 12345), (3, 0, M64)])
 def test_generalized_pbs_parity_per_ct_lut(small, log_chi, log_v, rot):
     ks, eng = small
