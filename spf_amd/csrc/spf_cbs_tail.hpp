@@ -4,11 +4,12 @@
 //       (ops/automorphisms/mod.rs:53-85: log2 N rounds of automorphism + FFT-domain GLWE
 //        keyswitch, ops/fft_ops.rs:457-495)
 //   scheme_switch_fft            (ops/fft_ops.rs:225-279, 403-442)  GLEV -> GGSW-FFT
-// Both kernels use the two-waves-per-ciphertext layout of the blind rotation (wave w owns the
-// complex samples of parity w; one 4 KiB cross exchange per transform) and the same arithmetic
-// (DAG-I transforms, AVX-512-order complex_mad, reference rounding).  A work unit is one
-// (ciphertext, gadget level) pair; the automorphism / scheme-switch keys are small (2.1 MB /
-// 0.5 MB), shared by every unit and read straight from L2 into registers.
+// Both kernels use the two-waves-per-ciphertext layout of the blind rotation (wave w owns the complex samples of
+// parity w) and the same arithmetic (DAG-I transforms, AVX-512-order complex_mad, reference rounding).  A work unit is
+// one (ciphertext, gadget level) pair, four units per 512-thread workgroup.  The trace runs on the schedule of the
+// throughput blind rotation (transform pairs, workgroup barriers, key rows through an LDS ring: cbs_trace_kernel
+// below); the scheme switch still runs one transform at a time with pair-local polled hand-overs and its 0.5 MB key
+// read from L2 into registers.
 #pragma once
 #include "spf_kernels.hpp"
 
@@ -24,10 +25,10 @@ struct PairCtx {
     int lane, w, me, partner;
 };
 
-// Hand-over between the two waves of a unit: the flat-polled word per wave pair.  Unlike the blind rotation the
-// four units of a workgroup share nothing (no key ring), so pair-local hand-overs let them drift apart and fill
-// each other's waits; a workgroup s_barrier here (compile with -DSPF_TAIL_BARRIER) measured 1.8 % SLOWER on the
-// whole circuit bootstrap (54.4 vs 53.5 ms per 4096) although a polled hand-over costs ≈ 2 000 cycles.
+// Hand-over between the two waves of a unit in scheme_switch_kernel: the flat-polled word per wave pair.  Its four
+// units share nothing (no key ring) and every wave waits for its own key rows from L2, so a workgroup s_barrier here
+// (compile with -DSPF_TAIL_BARRIER) ties eight waves to the slowest L2 round trip: it measured slower than polling
+// although a polled hand-over costs ≈ 2 000 cycles.  (The trace solved it the other way: key rows through a ring.)
 __device__ __forceinline__ void tail_sync(const PairCtx& c, uint32_t& seq)
 {
 #ifdef SPF_TAIL_BARRIER
@@ -69,67 +70,6 @@ __device__ __forceinline__ void pair_forward(const PairCtx& c, uint32_t& seq, c6
     }
 }
 
-// inverse transform of 8 bins per wave back to the wave's 16 coefficients, as rounded-but-not-yet-
-// reduced doubles: tv[n1] = coefficient (half 0, n1), tv[8+n1] = (half 1, n1)
-__device__ __forceinline__ void pair_inverse(const PairCtx& c, uint32_t& seq, const c64 (&P)[8], double (&tv)[16])
-{
-    const bool odd = c.w != 0;
-    c64 Ep[4], Op[4], V[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        Ep[i] = cadd(P[i], P[i + 4]);
-        c64 dd = csub(P[i], P[i + 4]);
-        Op[i] = cmul_tw<-1>(dd, c.wc[64 * i]);
-    }
-    tail_sync(c, seq);
-    // wave 0 keeps E'[0..3] and needs E'[4..7]; wave 1 keeps O'[4..7] and needs O'[0..3]
-#pragma unroll
-    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, Op[i], Ep[i]);
-    tail_sync(c, seq);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
-        V[i] = sel(odd, Ep[i], got);
-        V[4 + i] = sel(odd, got, Op[i]);
-    }
-    tail_sync(c, seq);
-    fft512_single<-1>(V, c.mine, c.tab, c.lane);
-#pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) {
-        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-        c64 t = cmul_nf_conj(xs, c.twist[64 * n1]);
-        tv[n1] = t.re;
-        tv[8 + n1] = t.im;
-    }
-}
-
-// round(), mod 2^64, `as i64` of 16 values (the two exact paths: spf_device.hpp)
-__device__ __forceinline__ void tv_to_torus(const double (&tv)[16], uint64_t (&out)[16])
-{
-    double mn = __builtin_fabs(tv[0]);
-#pragma unroll
-    for (int e = 1; e < 16; e++) mn = __builtin_fmin(mn, __builtin_fabs(tv[e]));
-    if (__all(mn >= 4503599627370496.0)) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) out[e] = f64_bigint_to_torus(tv[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) out[e] = f64_round_to_torus(tv[e]);
-    }
-}
-
-// complex_mad in the reference's AVX-512 order (math/simd/x86_64/avx512.rs:54-57)
-__device__ __forceinline__ void mad8(c64 (&acc)[8], const c64 (&k)[8], const c64 (&X)[8])
-{
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        double re = __builtin_fma(k[r].re, X[r].re, acc[r].re);
-        double im = __builtin_fma(k[r].re, X[r].im, acc[r].im);
-        acc[r].re = __builtin_fma(-k[r].im, X[r].im, re);
-        acc[r].im = __builtin_fma(k[r].im, X[r].re, im);
-    }
-}
-
 // acc += key_row * X over this wave's 8 bins, the key streamed 4 bins at a time so that only 16
 // registers of key are live at once
 __device__ __forceinline__ void mad_row(c64 (&acc)[8], const c64* row_w_lane, const c64 (&X)[8])
@@ -150,12 +90,6 @@ __device__ __forceinline__ void mad_row(c64 (&acc)[8], const c64* row_w_lane, co
     }
 }
 
-// this wave's 8 bins of a 1024-bin row: index r -> bin lane + 64(4w + (r&3)) + 512(r>>2)
-__device__ __forceinline__ void load_bins(c64 (&k)[8], const c64* row_w_lane)
-{
-#pragma unroll
-    for (int r = 0; r < 8; r++) k[r] = row_w_lane[64 * (r & 3) + 512 * (r >> 2)];
-}
 __device__ __forceinline__ void store_bins(c64* row_w_lane, const c64 (&x)[8])
 {
 #pragma unroll
@@ -179,7 +113,6 @@ template <int LOGB> __device__ __forceinline__ int next_digit(uint64_t& s)
 }
 
 constexpr int kTailLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
-constexpr int kTraceLds = kTailLds + 8 * 8192; // + the parked mask half of each wave's accumulator
 
 struct TraceArgs {
     const uint64_t* glwe_in; // B x 4096: lo-noise GLWE out of the bootstrap
@@ -190,26 +123,47 @@ struct TraceArgs {
     uint32_t cbs_count, cbs_radix_log;
 };
 
-template <int L, int LOGB> // trace radix: L digits of LOGB bits
-__global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
+// ---------------------------------------------------------------------------------------------------------------
+// cbs_trace_kernel: the trace on the schedule of the throughput blind rotation (r03; r02's kernel — one digit at a time,
+// flat-polled pair hand-overs, key rows from L2 into registers, mask half parked in LDS — took 5.86 ms per 4096 against 4.49).
+//
+// One automorphism round = one GLWE keyswitch in the FFT domain (ops/fft_ops.rs:457-495): the six 7-bit digits of
+// the automorphed mask go through THREE transform pairs (`fft512_pair1`, both digits of a pair on one 8 KiB image,
+// exchange 2 of the second in registers), the two output polynomials come back as one inverse pair, the body is
+// compiled once per sample parity (no value selects), every hand-over is a bare workgroup `s_barrier`, and the
+// automorphism key rides a 64 KiB LDS ring: the rows of a digit pair — levels (L-2-2m, L-1-2m), 2 x 2 x 16 KiB,
+// contiguous in the reference layout [round][level][poly][bin] — are brought in by LDS-DMA one pair ahead and waited
+// for at the cross-exchange barrier, exactly as the bootstrapping key in `blind_rotate2p_kernel`.  That is what lets a
+// workgroup barrier replace the flat-polled pair hand-overs (≈ 2 000 cycles each, 22 per round): with the key rows
+// coming from L2 straight into registers (r02) every wave arrived at a barrier with its own L2 latency, and a barrier
+// tied to eight such waves measured slower than polling.
+// The automorphism X -> X^k (k odd) maps each coefficient parity class onto itself, so the gather of a wave reads only
+// what the wave itself staged: staging and gather need no hand-over at all.  Eight barriers per round.
+// The mask half of the accumulator stays in registers (r02 parked it in the LDS the ring now occupies): after the
+// gather only the REMAINING digit state is kept, 28 bits = one register per coefficient once the first pair's digits
+// are out.  Same arithmetic in the same order as r02's kernel (and the oracle): same words.
+constexpr int kTraceLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 2 * kBskSlotBytes;
+
+template <int L, int LOGB, int W>
+__device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cslot = wv >> 1;
-    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    static_assert(L == 6 && LOGB == 7, "three digit pairs; the state after the first pair fits 32 bits");
+    constexpr int XP = 2;
+    constexpr int NT = 512;
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cslot = wv >> 1;
+    constexpr int w = W;
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes);
-    PairCtx pc;
-    pc.mine = tile + w * 8192; pc.theirs = tile + (w ^ 1) * 8192;
-    pc.tab = reinterpret_cast<const c64*>(smem);
-    pc.twist = pc.tab + kTWOff + w * 512 + lane; pc.wc = pc.tab + kWCOff + 256 * w + lane;
-    pc.flags = flags; pc.lane = lane; pc.w = w;
-    pc.me = __builtin_amdgcn_readfirstlane(wv); pc.partner = pc.me ^ 1;
-    uint32_t seq = 0;
+    char* mine = tile + w * 8192;
+    char* theirs = tile + (w ^ 1) * 8192;
+    char* ring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
-        if (tid < 8) flags[tid] = 0;
+        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
     }
     const uint32_t unit_raw = blockIdx.x * kWavesPerBlock + cslot;
     const bool owns_output = unit_raw < a.units;
@@ -217,12 +171,22 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
     const uint32_t ct = unit / a.cbs_count, lvl = unit % a.cbs_count;
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
-    // x = shr_round( (glwe with body coefficients 0..lvl un-rotated) * X^-lvl , log2 N ).
-    // The accumulator's body half lives in registers (acc_b); its mask half, touched only twice
-    // per round, is parked in this wave's private 8 KiB of the LDS the key ring uses elsewhere
-    // (park[e*64 + lane]): that keeps the kernel inside 256 VGPRs without scratch.
-    uint64_t* park = reinterpret_cast<uint64_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes + 64 + wv * 8192);
-    uint64_t acc_b[16];
+    // key chunk c = 3 (round - 1) + m: the 64 KiB [level L-2-2m | level L-1-2m] of that round, copied as it lies: the
+    // first digit of the pair (j = 2m, level L-1-2m) is the ring's second half
+    const uint32_t dma_voff = (uint32_t)tid * 16u;
+    const uint32_t dma_dst = lds_address(ring) + wv * 1024;
+    auto ring_dma = [&](uint32_t chunk) {
+        const uint32_t rnd = chunk / 3, m = chunk % 3;
+        const char* src = reinterpret_cast<const char*>(a.ak) +
+                          (size_t)__builtin_amdgcn_readfirstlane(rnd * L + (L - 2 - 2 * m)) * kBskSlotBytes;
+#pragma unroll
+        for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
+            lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
+    };
+    ring_dma(0);
+
+    // x = shr_round( (glwe with body coefficients 0..lvl un-rotated) * X^-lvl , log2 N )
+    uint64_t accm[16], accb[16];
     {
         const uint64_t* g = a.glwe_in + (size_t)ct * 2 * kN;
 #pragma unroll
@@ -236,79 +200,243 @@ __global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
                     v += (uint64_t)1 << (64 - (a.cbs_radix_log * (src + 1) + 1));
                 v = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
                 v = (v >> 11) + ((v >> 10) & 1); // glwe_mod_switch_and_expand_pow_2
-                if (p == 0) park[e * 64 + lane] = v; else acc_b[e] = v;
+                if (p == 0) accm[e] = v; else accb[e] = v;
             }
     }
     __syncthreads();
+    uint32_t opaque_zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+    auto rendezvous = [&]() { // bare s_barrier; the never-repeating loop gives each phase its own basic block
+        do {
+            pair_barrier_w();
+        } while (opaque_zero != 0);
+    };
 
-    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(pc.mine);
+    uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
+    const c64* twist = tab + kTWOff + w * 512 + lane;
+    const c64* wc = tab + kWCOff + 256 * w + lane;
+    uint32_t chunk = 0;
+    constexpr uint32_t total_chunks = 11 * 3;
+    // The accumulator (64 registers) is idle from the gather to the end of a round; beside the digit state, one
+    // transform pair and the frequency-domain product it does not fit 256 registers, and hipcc's own spilling put
+    // 492 B per lane in scratch with reloads in the middle of the transforms.  Its BODY half is parked explicitly
+    // instead, in the unit's own 32 KiB of the OUTPUT buffer (written for real only at the very end), fully
+    // coalesced: word (w * 16 + e) * 64 + lane.  A padding unit of a ragged last workgroup (a duplicate of the last
+    // real unit) does not store there; what it reads back only feeds its own discarded arithmetic.
+    gu64_ptr park = global_view(a.glev_out + (size_t)unit * 2 * kN) + (size_t)(w * 16) * 64 + lane;
+
 #pragma unroll 1
     for (uint32_t it = 1; it <= 11; it++) {
-        // automorphism X -> X^kk, kk = N/2^(it-1) + 1 (ops/polynomial/mod.rs:62-84): out[d] = +-in[c],
-        // c*kk = d mod 2N  <=>  c' = d*kk^-1 mod 2N, c = c' mod N, sign = c' >= N
+        // automorphism X -> X^kk, kk = N/2^(it-1) + 1 (ops/polynomial/mod.rs:62-84): out[d] = +-in[c], c kk = d mod 2N
+        // <=> c' = d kk^-1 mod 2N, c = c' mod N, sign = c' >= N.  kk^-1 is odd: c' has the parity of d, so every source
+        // lies in this wave's own staging region.
         const uint32_t kk = (kN >> (it - 1)) + 1;
         uint32_t kinv = kk; // Newton iteration for the inverse of an odd number mod 2^12
         kinv *= 2 - kk * kinv; kinv *= 2 - kk * kinv; kinv *= 2 - kk * kinv; kinv *= 2 - kk * kinv;
         kinv &= 2 * kN - 1;
-        uint64_t st[16];
+        const uint32_t cp0 = (uint32_t)(2 * lane + w) * kinv;
+        uint32_t st[16];  // digit state of the mask coefficients once digits 0 and 1 are out (28 bits)
+        uint32_t d01[16]; // digits 0 and 1, sign-extended 16-bit halves
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            tail_sync(pc, seq);
 #pragma unroll
-            for (int e = 0; e < 16; e++)
-                stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = p == 0 ? park[e * 64 + lane] : acc_b[e];
-            tail_sync(pc, seq);
+            for (int e = 0; e < 16; e++) stage_mine[(e >> 3) * 512 + (e & 7) * 64 + lane] = p == 0 ? accm[e] : accb[e];
+            wave_lds_fence(); // own writes, own reads: in-order LDS needs no barrier
+            uint64_t gin[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                uint32_t cp = ((uint32_t)coef2(e) * kinv) & (2 * kN - 1);
-                uint32_t src = cp & (kN - 1);
-                uint64_t v = reinterpret_cast<const uint64_t*>(tile + (src & 1) * 8192)[src >> 1];
-                v = (cp >> 11) ? (uint64_t)0 - v : v;
-                if (p == 0) st[e] = radix_round_state<L, LOGB>(v); // keyswitch decomposes the mask
-                else acc_b[e] += v;                                 // out.b += trivial(b_k) ...
+                const uint32_t cp = cp0 + (uint32_t)((e >> 3) * 1024 + (e & 7) * 128) * kinv;
+                gin[e] = *reinterpret_cast<const uint64_t*>(mine + ((cp << 2) & 0x1FF8u));
             }
+            compiler_fence();
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t cp = cp0 + (uint32_t)((e >> 3) * 1024 + (e & 7) * 128) * kinv;
+                const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)cp << 52) >> 63); // bit 11 of c', spread
+                const uint64_t v = (gin[e] ^ sgn) - sgn;
+                if (p == 0) { // keyswitch decomposes the mask
+                    uint64_t s64 = radix_round_state<L, LOGB>(v);
+                    const int d0 = next_digit<LOGB>(s64);
+                    const int d1 = next_digit<LOGB>(s64);
+                    d01[e] = ((uint32_t)d0 & 0xFFFFu) | ((uint32_t)d1 << 16);
+                    st[e] = (uint32_t)s64;
+                } else {
+                    accb[e] += v; // out.b += trivial(b_k) ...
+                }
+            }
+            if (p == 1 && owns_output) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) park[(size_t)e * 64] = accb[e];
+            }
+            wave_lds_fence(); // gathered: the region may be overwritten (next staging / the exchange image)
         }
+
         c64 prod[2][8];
+#pragma unroll
+        for (int m = 0; m < 3; m++, chunk++) {
+            c64 VV[2][8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                int dre[2], dim[2];
+                if (m == 0) {
+                    dre[0] = (int)(int16_t)(d01[n1] & 0xFFFFu); dre[1] = (int)d01[n1] >> 16;
+                    dim[0] = (int)(int16_t)(d01[8 + n1] & 0xFFFFu); dim[1] = (int)d01[8 + n1] >> 16;
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        uint64_t sr = st[n1], si = st[8 + n1];
+                        dre[jj] = next_digit<LOGB>(sr);
+                        dim[jj] = next_digit<LOGB>(si);
+                        st[n1] = (uint32_t)sr;
+                        st[8 + n1] = (uint32_t)si;
+                    }
+                }
+                const c64 tw = twist[64 * n1];
+                VV[0][n1] = cmul_nf({(double)dre[0], (double)dim[0]}, tw);
+                VV[1][n1] = cmul_nf({(double)dre[1], (double)dim[1]}, tw);
+            }
+            // the ring is free since the barrier behind the previous MADs: rows of this pair (those of a round's first
+            // pair were requested ahead of the previous round's inverse transforms)
+            if (m > 0) ring_dma(chunk);
+            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+            // radix-2 stage across the two waves, both digits in one exchange
+            if constexpr (w == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][4 + i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
+            __syncthreads();
+            if constexpr (w == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                        const c64 t = cmul_tw<+1>(in, wc[64 * i]);
+                        const c64 Ei = VV[j][i];
+                        VV[j][i] = cadd(Ei, t);
+                        VV[j][i + 4] = csub(Ei, t);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const c64 Ei = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                        const c64 t = cmul_tw<+1>(VV[j][4 + i], wc[64 * i]);
+                        VV[j][i] = cadd(Ei, t);
+                        VV[j][i + 4] = csub(Ei, t);
+                    }
+            }
+            if (m == 2) {
+                // the parked body half comes back under the last multiply-accumulate and the inverse cross exchange
+#pragma unroll
+                for (int e = 0; e < 16; e++) accb[e] = park[(size_t)e * 64];
+            }
+            // ... - sum_j <digit_j(a), glev row L-1-j>, digits in order, both output polynomials (fft_ops.rs:489-494)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const c64* row = reinterpret_cast<const c64*>(ring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
+                c64 kb[2][2];
+                auto key2 = [&](int grp, c64 (&dst)[2]) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                    }
+                };
+                key2(0, kb[0]);
+#pragma unroll
+                for (int grp = 0; grp < 8; grp++) {
+                    if (grp + 1 < 8) key2(grp + 1, kb[(grp + 1) % 2]);
+                    compiler_fence();
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                        const c64 k = kb[grp % 2][i];
+                        const bool first = m == 0 && j == 0;
+                        double re = __builtin_fma(k.re, VV[j][r].re, first ? 0.0 : prod[q][r].re);
+                        double im = __builtin_fma(k.re, VV[j][r].im, first ? 0.0 : prod[q][r].im);
+                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
+                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
+                    }
+                }
+            }
+            __syncthreads(); // every wave is done with the ring and with its partner's cross data
+        }
+
+        // ---- back to the torus, both output polynomials together
+        c64 WW[2][8];
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
-        const c64* key = a.ak + (size_t)(it - 1) * (L * 2 * kHalf) + 256 * w + lane;
-#pragma unroll 1
-        for (int j = 0; j < L; j++) {
-            const c64* row = key + (size_t)((L - 1 - j) * 2) * kHalf; // GLEV rows in reverse
-            c64 V[8], X[8];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                int dre = next_digit<LOGB>(st[n1]);
-                int dim = next_digit<LOGB>(st[8 + n1]);
-                V[n1] = cmul_nf({(double)dre, (double)dim}, pc.twist[64 * n1]);
+            for (int i = 0; i < 4; i++) {
+                const c64 wci = wc[64 * i];
+                WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);
+                WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wci);
             }
-            pair_forward(pc, seq, V, X);
-            // key rows are shared by every unit (L2-resident); the SIMD partner covers the trip
-            mad_row(prod[0], row, X);
-            mad_row(prod[1], row + kHalf, X);
+        if constexpr (w == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
         }
-        // ... - sum_i <decomp(a_i), glev_i>  (fft_ops.rs:489-494)
+        rendezvous();
+        if constexpr (w == 0) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            double tv[16];
-            uint64_t s[16];
-            pair_inverse(pc, seq, prod[q], tv);
-            tv_to_torus(tv, s);
+            for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                if (q == 0) park[e * 64 + lane] -= s[e]; else acc_b[e] -= s[e];
-            }
+                for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+        }
+        rendezvous(); // both cross reads retired before either region is overwritten
+        // the accumulator has landed BEFORE the next key rows are requested: vmcnt counts in order, a wait for it behind
+        // the request would wait for the rows as well
+#pragma unroll
+        for (int e = 0; e < 16; e++) asm volatile("" : "+v"(accb[e]));
+        if (chunk < total_chunks) ring_dma(chunk); // rows of the next round's first digit pair
+        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
+        {
+            uint64_t t[16];
+            untwist_to_torus_bits(WW[0], twist, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) accm[e] -= t[e];
+            untwist_to_torus_bits(WW[1], twist, t);
+#pragma unroll
+            for (int e = 0; e < 16; e++) accb[e] -= t[e];
         }
     }
     if (!owns_output) return;
     uint64_t* out = a.glev_out + (size_t)unit * 2 * kN;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        out[coef2(e)] = park[e * 64 + lane];
-        out[kN + coef2(e)] = acc_b[e];
+        out[coef2(e)] = accm[e];
+        out[kN + coef2(e)] = accb[e];
     }
+}
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(512, 2) void cbs_trace_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cbs_trace_body<L, LOGB, 1>(a, smem);
+    else cbs_trace_body<L, LOGB, 0>(a, smem);
 }
 
 struct SchemeSwitchArgs {

@@ -1,10 +1,11 @@
 #!/bin/bash
 # SQ counters of blind-rotation variants for the experiments log: kernel trace + two PMC passes per variant
-# (each pass its own process; --pmc never beside a trace domain).  usage: bash tools/gpu_counters_ab.sh <tag> "<VAR=VAL>" ...
+# (each pass its own process; --pmc never beside a trace domain).  usage: [KFILTER=cbs_trace BENCH_EXTRA=--with-cbs] bash tools/gpu_counters_ab.sh <tag> "<VAR=VAL>" ...
 set -o pipefail
 TAG=$1; shift
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras"
+CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras ${BENCH_EXTRA:-}"
+export KFILTER=${KFILTER:-blind_rotate}
 for V in "$@"; do
   N=$(echo "$V" | tr -c 'A-Za-z0-9\n' '_')
   OUT=$PWD/gpurun_out/cnt_${TAG}_$N
@@ -15,16 +16,16 @@ for V in "$@"; do
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || exit 1
   unset ${V%%=*}
   python3 - "$OUT" "$V" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 out, v = sys.argv[1], sys.argv[2]
 ms = None
 for r in csv.DictReader(open(glob.glob(out + "/trace/*/*_kernel_stats.csv")[0])):
-    if "blind_rotate" in r["Name"]:
+    if os.environ["KFILTER"] in r["Name"]:
         ms, name = float(r["AverageNs"]) / 1e6, r["Name"].split("(")[0].replace("void spf::", "")
 acc = collections.defaultdict(list)
 for d in ("pmc1", "pmc2"):
     for r in csv.DictReader(open(glob.glob(f"{out}/{d}/*/*_counter_collection.csv")[0])):
-        if "blind_rotate" in r["Kernel_Name"]:
+        if os.environ["KFILTER"] in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 c = {k: sum(x) / len(x) for k, x in acc.items()}
 cyc = ms * 1e-3 * 2.39e9
