@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Launch ONE entry point of the library `reps` times at a FIXED batch, device-resident, for rocprofv3: every dispatch of a
+kernel in the trace then has the same grid, so per-kernel averages are roofline-grade numbers.
+usage: python tools/kernel_bench.py <cmux|keyswitch|cbs|pbs> <B> [reps]
+  cmux       spf_cmux_dev                 (cmux_kernel; cmux4_kernel for B <= #CU)
+  keyswitch  spf_keyswitch_lwe_l1_lwe_l0_dev (ks_digits_kernel + ks_gemm_lds_kernel)
+  cbs        spf_circuit_bootstrap_dev    (blind rotation + cbs_trace_kernel + scheme_switch_kernel)
+  pbs        spf_circuit_bootstrap_pbs_dev (blind rotation only: blind_rotate4 / 2p2 / 2p by batch size)
+Prints one JSON line with the hipEvent time per call."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import spf_amd
+
+what, B = sys.argv[1], int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+P = spf_amd.DEFAULT_128
+dev = torch.device("cuda", 0)
+eng = spf_amd.Engine(P, device=0)
+g = torch.Generator(device=dev).manual_seed(5)
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def rnd_i64(*shape):
+    return torch.randint(-(2 ** 63), 2 ** 63 - 1, shape, generator=g, device=dev, dtype=torch.int64)
+
+
+def key(which, scale):
+    ptr, nbytes = eng.key_blob(which)
+    from spf_amd.sharding import _DevArray
+    t = torch.as_tensor(_DevArray(ptr, nbytes), device=dev)
+    if which == 1:
+        t.copy_(rnd_i64(nbytes // 8).view(torch.uint8))
+    else:
+        t.copy_((torch.randn(nbytes // 8, generator=g, device=dev, dtype=torch.float64) * scale).view(torch.uint8))
+    eng.key_blob_commit(which)
+
+
+if what == "cmux":
+    gg = torch.randn((B, P.cbs_ggsw_complex * 2), generator=g, device=dev, dtype=torch.float64) * (2.0 ** 60)
+    da, db = rnd_i64(B, P.glwe_words), rnd_i64(B, P.glwe_words)
+    dc = torch.empty_like(da)
+    call = lambda: eng.cmux_dev(stream, B, gg.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr())
+elif what == "keyswitch":
+    key(1, 0)
+    lwe1 = rnd_i64(B, P.lwe1_words)
+    out = torch.empty((B, P.lwe0_words), device=dev, dtype=torch.int64)
+    call = lambda: eng.keyswitch_dev(stream, B, lwe1.data_ptr(), out.data_ptr())
+elif what in ("cbs", "pbs"):
+    for which in ((0, 2, 3) if what == "cbs" else (0,)):
+        key(which, 2.0 ** 67)
+    lwe0 = rnd_i64(B, P.lwe0_words)
+    if what == "cbs":
+        out = torch.empty((B, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
+        call = lambda: eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), out.data_ptr())
+    else:
+        out = torch.empty((B, P.glwe_words), device=dev, dtype=torch.int64)
+        call = lambda: eng.circuit_bootstrap_pbs_dev(stream, B, lwe0.data_ptr(), out.data_ptr())
+else:
+    raise SystemExit(__doc__)
+
+call()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    call()
+e1.record()
+torch.cuda.synchronize()
+print(json.dumps({"what": what, "B": B, "reps": reps, "ms_per_call": round(e0.elapsed_time(e1) / reps, 4)}))
