@@ -677,6 +677,8 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         STAMP4(10);
         // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
     }
+    // the last step requested key rows nobody uses (its own again): they have landed before the registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
@@ -896,6 +898,13 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 #pragma unroll
         for (int r = 0; r < 8; r++) k1[r] = gload(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
     }
+    // The last round re-requested its own row pair (an L2 hit) rather than branching around the loads (a branch there
+    // makes hipcc wait for every row right where it is requested: 0.31 -> 0.61 ms per 4096).  Those sixteen loads are
+    // dead; they are waited for here with their registers still held, so that nothing the inverse transforms put into
+    // those registers can be overwritten by a row landing late.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 8; r++) asm volatile("" :: "v"(k0[r].re), "v"(k0[r].im), "v"(k1[r].re), "v"(k1[r].im));
 
     // ---- both output polynomials back to the torus as ONE transform pair (`fft512_pair1`: each exchange of one
     // transform travels under a butterfly pass of the other; one cross exchange, three hand-overs instead of five)
