@@ -5,91 +5,16 @@
 //        keyswitch, ops/fft_ops.rs:457-495)
 //   scheme_switch_fft            (ops/fft_ops.rs:225-279, 403-442)  GLEV -> GGSW-FFT
 // Both kernels use the two-waves-per-ciphertext layout of the blind rotation (wave w owns the complex samples of
-// parity w) and the same arithmetic (DAG-I transforms, AVX-512-order complex_mad, reference rounding).  A work unit is
-// one (ciphertext, gadget level) pair, four units per 512-thread workgroup.  The trace runs on the schedule of the
-// throughput blind rotation (transform pairs, workgroup barriers, key rows through an LDS ring: cbs_trace_kernel
-// below); the scheme switch still runs one transform at a time with pair-local polled hand-overs and its 0.5 MB key
-// read from L2 into registers.
+// parity w) and the same arithmetic (DAG-I transforms, AVX-512-order complex_mad, reference rounding), on the schedule
+// of the throughput blind rotation: transform pairs, one body per sample parity, bare workgroup barriers, key rows
+// through a 64 KiB LDS ring filled by LDS-DMA.  A work unit is one (ciphertext, gadget level) pair, four units per
+// 512-thread workgroup, one workgroup per CU.
 #pragma once
 #include "spf_kernels.hpp"
 
 namespace spf {
 
-struct PairCtx {
-    char* mine;
-    char* theirs;
-    const c64* tab;
-    const c64* twist; // tab + kTWOff + w*512 + lane
-    const c64* wc;    // tab + kWCOff + 256*w + lane
-    volatile uint32_t* flags;
-    int lane, w, me, partner;
-};
-
-// Hand-over between the two waves of a unit in scheme_switch_kernel: the flat-polled word per wave pair.  Its four
-// units share nothing (no key ring) and every wave waits for its own key rows from L2, so a workgroup s_barrier here
-// (compile with -DSPF_TAIL_BARRIER) ties eight waves to the slowest L2 round trip: it measured slower than polling
-// although a polled hand-over costs ≈ 2 000 cycles.  (The trace solved it the other way: key rows through a ring.)
-__device__ __forceinline__ void tail_sync(const PairCtx& c, uint32_t& seq)
-{
-#ifdef SPF_TAIL_BARRIER
-    (void)seq;
-    pair_barrier_w();
-#else
-    pair_barrier(c.flags, c.me, c.partner, seq);
-#endif
-}
-
-// value select on the (wave-uniform) parity: written with scalar selects rather than branches on
-// purpose — branching over struct copies makes hipcc select between *addresses* of register
-// arrays, which pins them in scratch memory.
-__device__ __forceinline__ c64 sel(bool pick_b, c64 a, c64 b)
-{
-    return {pick_b ? b.re : a.re, pick_b ? b.im : a.im};
-}
-
-// forward negacyclic transform of the ciphertext's 16 samples per lane pair: wave w brings its 8
-// twisted samples V and leaves with its 8 bins X (bin = lane + 64(4w + (r&3)) + 512(r>>2)).
-__device__ __forceinline__ void pair_forward(const PairCtx& c, uint32_t& seq, c64 (&V)[8], c64 (&X)[8])
-{
-    const bool odd = c.w != 0;
-    tail_sync(c, seq); // partner is done reading my region
-    fft512_single<+1>(V, c.mine, c.tab, c.lane);
-    // radix-2 stage across the two waves: wave 0 finishes bins d < 4 (keeps E[0..3], needs O[0..3]),
-    // wave 1 bins d >= 4 (keeps O[4..7], needs E[4..7])
-#pragma unroll
-    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(c.mine)[i * 64 + c.lane] = sel(odd, V[4 + i], V[i]);
-    tail_sync(c, seq);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        c64 got = reinterpret_cast<const c64*>(c.theirs)[i * 64 + c.lane];
-        c64 Ei = sel(odd, V[i], got);
-        c64 Oi = sel(odd, got, V[4 + i]);
-        c64 t = cmul_tw<+1>(Oi, c.wc[64 * i]);
-        X[i] = cadd(Ei, t);
-        X[i + 4] = csub(Ei, t);
-    }
-}
-
-// acc += key_row * X over this wave's 8 bins, the key streamed 4 bins at a time so that only 16
-// registers of key are live at once
-__device__ __forceinline__ void mad_row(c64 (&acc)[8], const c64* row_w_lane, const c64 (&X)[8])
-{
-#pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
-        c64 k[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) k[i] = row_w_lane[64 * i + 512 * hh];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = i + 4 * hh;
-            double re = __builtin_fma(k[i].re, X[r].re, acc[r].re);
-            double im = __builtin_fma(k[i].re, X[r].im, acc[r].im);
-            acc[r].re = __builtin_fma(-k[i].im, X[r].im, re);
-            acc[r].im = __builtin_fma(k[i].im, X[r].re, im);
-        }
-    }
-}
-
+// this wave's 8 bins of a 1024-bin row: index r -> bin lane + 64(4w + (r&3)) + 512(r>>2)
 __device__ __forceinline__ void store_bins(c64* row_w_lane, const c64 (&x)[8])
 {
 #pragma unroll
@@ -112,7 +37,6 @@ template <int LOGB> __device__ __forceinline__ int next_digit(uint64_t& s)
     return (int)d - (int)(carry << LOGB);
 }
 
-constexpr int kTailLds = kTableBytes + kWavesPerBlock * kWaveBufBytes + 64;
 
 struct TraceArgs {
     const uint64_t* glwe_in; // B x 4096: lo-noise GLWE out of the bootstrap
@@ -447,26 +371,33 @@ struct SchemeSwitchArgs {
     uint32_t units, cbs_count;
 };
 
-template <int L, int LOGB> // scheme-switch radix
-__global__ __launch_bounds__(512, 2) void scheme_switch_kernel(SchemeSwitchArgs a)
+// ---------------------------------------------------------------------------------------------------------------
+// scheme_switch_kernel: scheme_switch_fft on the same schedule as cbs_trace_kernel (r03; r02 ran one transform at a time with
+// flat-polled pair hand-overs and key rows from L2 into registers: 1.035 ms per 4096 against 1.00) — the two full-range
+// transforms as one pair, the fifteen 3-bit digits of the mask as seven pairs and a half pair, body per sample parity,
+// bare workgroup barriers, the scheme-switch key through the 64 KiB LDS ring (levels (L-2-j, L-1-j) of a digit pair are
+// contiguous in [level][poly][bin]).  Same arithmetic in the same order as scheme_switch_kernel: same words.
+template <int L, int LOGB, int W>
+__device__ __forceinline__ void scheme_switch_body(const SchemeSwitchArgs& a, char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cslot = wv >> 1;
-    const int w = __builtin_amdgcn_readfirstlane(wv & 1);
+    static_assert(L == 15 && LOGB == 3, "seven digit pairs and one single digit");
+    constexpr int XP = 2;
+    constexpr int NT = 512;
+    constexpr int PAIRS = (L + 1) / 2;
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cslot = wv >> 1;
+    constexpr int w = W;
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + kWavesPerBlock * kWaveBufBytes);
-    PairCtx pc;
-    pc.mine = tile + w * 8192; pc.theirs = tile + (w ^ 1) * 8192;
-    pc.tab = reinterpret_cast<const c64*>(smem);
-    pc.twist = pc.tab + kTWOff + w * 512 + lane; pc.wc = pc.tab + kWCOff + 256 * w + lane;
-    pc.flags = flags; pc.lane = lane; pc.w = w;
-    pc.me = __builtin_amdgcn_readfirstlane(wv); pc.partner = pc.me ^ 1;
-    uint32_t seq = 0;
+    char* mine = tile + w * 8192;
+    char* theirs = tile + (w ^ 1) * 8192;
+    char* ring = smem + kTableBytes + kWavesPerBlock * kWaveBufBytes;
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
-        if (tid < 8) flags[tid] = 0;
+        for (int i = tid; i < kTableEntries; i += NT) dst[i] = src[i];
     }
     const uint32_t unit_raw = blockIdx.x * kWavesPerBlock + cslot;
     const bool owns_output = unit_raw < a.units;
@@ -477,51 +408,150 @@ __global__ __launch_bounds__(512, 2) void scheme_switch_kernel(SchemeSwitchArgs 
     // GGSW-FFT [row][level][poly][bin]; this wave's bins start at 256*w + lane
     c64* out_row0 = a.ggsw_out + (size_t)ct * (2 * a.cbs_count * 2 * kHalf) + (size_t)(lvl * 2) * kHalf + 256 * w + lane;
     c64* out_row1 = out_row0 + (size_t)a.cbs_count * 2 * kHalf;
+
+    // key chunk c: the rows of digits 2c and 2c+1 = levels (L-2-2c, L-1-2c), 64 KiB as they lie; the first digit of a
+    // pair (level L-1-2c) is the ring's second half.  The last chunk holds the single digit L-1 (level 0): second half only.
+    const uint32_t dma_voff = (uint32_t)tid * 16u;
+    const uint32_t dma_dst = lds_address(ring) + wv * 1024;
+    auto ring_dma = [&](int c) {
+        if (2 * c + 1 < L) {
+            const char* src = reinterpret_cast<const char*>(a.ssk) + (size_t)(L - 2 - 2 * c) * kBskSlotBytes;
+#pragma unroll
+            for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
+                lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
+        } else {
+            const char* src = reinterpret_cast<const char*>(a.ssk);
+#pragma unroll
+            for (int k = 0; k < kBskSlotBytes / (NT * 16); k++)
+                lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + kBskSlotBytes + k * NT * 16);
+        }
+    };
+    ring_dma(0);
     __syncthreads();
 
-    // PolynomialRef::fft of a full-range polynomial: u64 -> i64 -> f64 (round to nearest even)
-    auto full_fft = [&](int p, c64 (&X)[8]) {
-        c64 V[8];
+    const c64* twist = tab + kTWOff + w * 512 + lane;
+    const c64* wc = tab + kWCOff + 256 * w + lane;
+    // forward transform pair with the radix-2 stage across the two waves; leaves this wave's bins in VV
+    auto forward_pair = [&](c64 (&VV)[2][8]) {
+        fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+        if constexpr (w == 0) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; n1++) {
-            double re = (double)(long long)x[p * kN + coef2(n1)];
-            double im = (double)(long long)x[p * kN + coef2(8 + n1)];
-            V[n1] = cmul_nf({re, im}, pc.twist[64 * n1]);
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][4 + i];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
         }
-        pair_forward(pc, seq, V, X);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
+        __syncthreads();
+        if constexpr (w == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                    const c64 t = cmul_tw<+1>(in, wc[64 * i]);
+                    const c64 Ei = VV[j][i];
+                    VV[j][i] = cadd(Ei, t);
+                    VV[j][i + 4] = csub(Ei, t);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const c64 Ei = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                    const c64 t = cmul_tw<+1>(VV[j][4 + i], wc[64 * i]);
+                    VV[j][i] = cadd(Ei, t);
+                    VV[j][i + 4] = csub(Ei, t);
+                }
+        }
     };
+
     c64 prod[2][8];
     {
-        // last row (j == k): plain FFT of both polynomials (fft_ops.rs:243-247)
-        c64 Xa[8];
-        full_fft(0, Xa);
-        if (owns_output) store_bins(out_row1, Xa);
-        full_fft(1, prod[0]); // also the start of row 0: y.a[0] = FFT(x.b) (fft_ops.rs:225-241)
-        if (owns_output) store_bins(out_row1 + kHalf, prod[0]);
+        // last GGSW row (j == k): plain transforms of both polynomials (fft_ops.rs:243-247); FFT(x.b) also starts
+        // row 0: y.a[0] = FFT(x.b) (fft_ops.rs:225-241).  PolynomialRef::fft of a full-range polynomial: u64 -> i64 -> f64.
+        c64 VV[2][8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) prod[1][r] = {0.0, 0.0};
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) {
+                const double re = (double)(long long)x[p * kN + coef2(n1)];
+                const double im = (double)(long long)x[p * kN + coef2(8 + n1)];
+                VV[p][n1] = cmul_nf({re, im}, twist[64 * n1]);
+            }
+        forward_pair(VV);
+        if (owns_output) {
+            store_bins(out_row1, VV[0]);
+            store_bins(out_row1 + kHalf, VV[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) prod[0][r] = VV[1][r];
+        __syncthreads(); // cross data consumed: the regions may be overwritten
     }
     uint64_t st[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) st[e] = radix_round_state<L, LOGB>(x[coef2(e)]);
-    const c64* key = a.ssk + 256 * w + lane;
 #pragma unroll 1
-    for (int j = 0; j < L; j++) {
-        const c64* row = key + (size_t)((L - 1 - j) * 2) * kHalf;
-        c64 V[8], X[8];
+    for (int c = 0; c < PAIRS; c++) {
+        const bool single = 2 * c + 1 >= L;
+        c64 VV[2][8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) {
-            int dre = next_digit<LOGB>(st[n1]);
-            int dim = next_digit<LOGB>(st[8 + n1]);
-            V[n1] = cmul_nf({(double)dre, (double)dim}, pc.twist[64 * n1]);
+            const int dre0 = next_digit<LOGB>(st[n1]), dim0 = next_digit<LOGB>(st[8 + n1]);
+            const int dre1 = next_digit<LOGB>(st[n1]), dim1 = next_digit<LOGB>(st[8 + n1]);
+            const c64 tw = twist[64 * n1];
+            VV[0][n1] = cmul_nf({(double)dre0, (double)dim0}, tw);
+            VV[1][n1] = cmul_nf({(double)dre1, (double)dim1}, tw); // the half pair transforms whatever the exhausted state yields; unused
         }
-        pair_forward(pc, seq, V, X);
-        mad_row(prod[0], row, X);
-        mad_row(prod[1], row + kHalf, X);
+        if (c > 0) ring_dma(c); // the ring is free since the barrier behind the previous MADs
+        forward_pair(VV);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (j == 1 && single) break;
+            const c64* row = reinterpret_cast<const c64*>(ring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
+            c64 kb[2][2];
+            auto key2 = [&](int grp, c64 (&dst)[2]) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                    dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
+                }
+            };
+            key2(0, kb[0]);
+#pragma unroll
+            for (int grp = 0; grp < 8; grp++) {
+                if (grp + 1 < 8) key2(grp + 1, kb[(grp + 1) % 2]);
+                compiler_fence();
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int r = (grp * 2 + i) & 7, q = grp >> 2;
+                    const c64 k = kb[grp % 2][i];
+                    const bool zero = c == 0 && j == 0 && q == 1; // row 0's second polynomial starts from zero
+                    double re = __builtin_fma(k.re, VV[j][r].re, zero ? 0.0 : prod[q][r].re);
+                    double im = __builtin_fma(k.re, VV[j][r].im, zero ? 0.0 : prod[q][r].im);
+                    prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
+                    prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
+                }
+            }
+        }
+        __syncthreads(); // every wave is done with the ring and with its partner's cross data
     }
     if (!owns_output) return;
     store_bins(out_row0, prod[0]);
     store_bins(out_row0 + kHalf, prod[1]);
+}
+
+template <int L, int LOGB>
+__global__ __launch_bounds__(512, 2) void scheme_switch_kernel(SchemeSwitchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) scheme_switch_body<L, LOGB, 1>(a, smem);
+    else scheme_switch_body<L, LOGB, 0>(a, smem);
 }
 
 } // namespace spf

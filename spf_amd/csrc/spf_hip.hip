@@ -478,7 +478,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cbs_trace_kernel<6, 7>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kTraceLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scheme_switch_kernel<15, 3>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds));
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kTraceLds));
 #undef CK
     *out = c;
     return SPF_OK;
@@ -653,7 +653,7 @@ static spf_status launch_scheme_switch(spf_ctx* c, hipStream_t s, size_t B, cons
     TimedScope ts(c, s, T_SS);
     spf_status st = ts.begin();
     if (st != SPF_OK) return st;
-    hipLaunchKernelGGL((scheme_switch_kernel<15, 3>), grid, block, kTailLds, s, a);
+    hipLaunchKernelGGL((scheme_switch_kernel<15, 3>), grid, block, kTraceLds, s, a);
     HIPCHK(c, hipGetLastError());
     return ts.end();
 }

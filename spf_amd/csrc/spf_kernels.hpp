@@ -75,29 +75,6 @@ __device__ __forceinline__ uint32_t lds_address(const void* p)
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-// Two-wave rendezvous through an LDS word per wave (the two waves of one ciphertext): publish my
-// phase number, spin until the partner has published the same.  LDS services a CU's DS
-// instructions in order, so data written (and drained with lgkmcnt(0)) before the flag is
-// visible to whoever has seen the flag; reads drained before the flag are complete.  Unlike
-// s_barrier this does not re-align the four ciphertexts of the workgroup with each other.
-// `flags` is deliberately a generic pointer: the compiler then reaches the words with flat_load /
-// flat_store (sc0 sc1), which travel through the vector-memory path instead of queueing in order
-// behind the DS traffic of the transforms.  Declaring them address_space(3) (ds_read / ds_write
-// polling) measured 2 % slower on the whole kernel.
-__device__ __forceinline__ void pair_barrier(volatile uint32_t* flags, int me, int partner, uint32_t& seq)
-{
-    seq++;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // publish without waiting for the store to complete (a volatile store is followed by
-    // s_waitcnt vmcnt(0): one more round trip in every rendezvous)
-    asm volatile("flat_store_dword %0, %1 sc0 sc1" ::"v"(const_cast<uint32_t*>(flags + me)), "v"(seq) : "memory");
-    // no s_sleep between polls: a poll already parks the wave for a flat round trip, and the extra
-    // 64 cycles only delay the rendezvous (measured: -2 % on the small-batch shapes, -0.3 % at B = 4096)
-    while ((int)(__builtin_amdgcn_readfirstlane(flags[partner]) - seq) < 0) {
-    }
-    asm volatile("" ::: "memory");
-}
-
 // Hand-over as a bare workgroup barrier (LDS queue drained first).  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
 // loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
 __device__ __forceinline__ void pair_barrier_w()
@@ -752,23 +729,13 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     char* tile = smem + kTableBytes + cslot * kWaveBufBytes;
     char* mine = tile + w * 8192;
     char* theirs = tile + (w ^ 1) * 8192;
-    volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kTableBytes + G * kWaveBufBytes);
-    [[maybe_unused]] uint32_t seq = 0;
-    [[maybe_unused]] const int me = __builtin_amdgcn_readfirstlane(wv), partner = me ^ 1;
     // hand-over between the two waves of a gate: every wave of the workgroup runs the same sequence, so a bare
-    // s_barrier does it (0.355 vs 0.366 ms per 4096 gates against r01's flat-polled word per pair; -DSPF_CMUX_POLL)
-    auto cmux_sync = [&]() {
-#ifdef SPF_CMUX_POLL
-        pair_barrier(flags, me, partner, seq);
-#else
-        pair_barrier_w();
-#endif
-    };
+    // s_barrier does it (r01's flat-polled word per pair: 0.366 vs 0.355 ms per 4096 gates)
+    auto cmux_sync = [&]() { pair_barrier_w(); };
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int i = tid; i < kTableEntries; i += 128 * G) dst[i] = src[i];
-        if (tid < 8) flags[tid] = 0;
     }
     const uint32_t ct_raw = blockIdx.x * G + cslot;
     const bool owns_output = ct_raw < a.B;
@@ -814,7 +781,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             }
             dig[p][e] = packed;
         }
-    __syncthreads(); // twiddle image and flags ready
+    __syncthreads(); // twiddle image ready
 
     const c64* twist = tab + kTWOff + w * 512 + lane;
     const c64* wc = tab + kWCOff + 256 * w + lane;
