@@ -72,6 +72,9 @@ def main() -> int:
     ap.add_argument("--with-add32", type=int, default=-1, metavar="K",
                     help="time K independent 32-bit encrypted additions as ONE gate graph (BASELINE config 3); "
                          "default 1 on a single GPU")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="skip the rocprofv3 --pmc child runs that measure roofline.traffic and the SQ busy fractions of the "
+                         "dominant kernel for THIS build on THIS box (three short child processes, about a minute)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -330,12 +333,17 @@ def main() -> int:
     per_launch_s = kernel_ms * 1e-3 if launches else float("nan")
     achieved_tflops = FLOP_PER_PBS * B / per_launch_s / 1e12
     alg_bytes = P.bsk_complex * 16 + B * (P.lwe0_words * 8 + P.glwe_words * 8)
-    # HBM bytes per launch and the SQ busy counters come from rocprofv3 PMC passes of this same command (separate
-    # runs, scripts_profile.sh; FETCH_SIZE doubled per the gfx950 correction) stored by tools_summarize_prof.py:
-    # they are NOT measured by this run, and are only attached when the stored profile is of the same kernel and batch
-    traffic, stored = None, None
+    # HBM bytes per launch and the SQ busy fractions of the dominant kernel: measured NOW, by this run, with rocprofv3 --pmc
+    # child processes of this same script (one per pass, never beside a trace domain; FETCH_SIZE doubled per the gfx950
+    # correction, MI355X_MICROARCH.md §HBM).  Falls back to the stored passes of profiles/latest_counters.json (labelled)
+    # when rocprofv3 is not on the box or --no-live-counters is given.
+    traffic, stored, live = None, None, None
+    if rank == 0 and world == 1 and not args.no_live_counters:
+        live = leg("live_counters", lambda: _live_counters(kernel_name, B, kernel_ms))
+        if live:
+            traffic = live.get("hbm_bytes_per_launch")
     tpath = os.path.join(ROOT, "profiles", "latest_counters.json")
-    if os.path.exists(tpath):
+    if live is None and os.path.exists(tpath):
         with open(tpath) as f:
             stored = json.load(f)
         if stored.get("kernel") != kernel_name or stored.get("batch") != B:
@@ -345,13 +353,14 @@ def main() -> int:
     roofline = {
         "bound": "fp64", "achieved": round(achieved_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-        "issue_bound_frac": (stored or {}).get("valu_busy_frac"),
-        "stored_profile": stored, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 3),
+        "issue_bound_frac": (live or stored or {}).get("valu_busy_frac"),
+        "counters": live, "stored_profile": stored, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 3),
         "kernel_ms_min_max_over_ranks": [round(x, 3) for x in kernel_ms_minmax], "launches": launches,
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
         "note": "the f64 butterflies and MADs run on the VALU (v_fma_f64 / v_add_f64 / v_mul_f64, zero MFMA instructions); "
                 "MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and MFMA alike; issue_bound_frac = share of the kernel's "
-                "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / time), from the stored profile",
+                "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / time); `counters` = this run's own rocprofv3 --pmc "
+                "passes (child processes), `stored_profile` = the committed passes, used only when no live pass ran",
         "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": round(alg_bytes / per_launch_s / 1e9, 2),
                 "peak_GBs": HBM_PEAK_GBS},
     }
@@ -447,6 +456,54 @@ def main() -> int:
 
 
 DATA_DIR = os.path.join(ROOT, "spf_amd", "data")
+
+
+def _live_counters(kernel_name, B, kernel_ms):
+    """rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-extras` (the headline step only) as CHILD processes,
+    one pass per process: HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KB counters) and the SQ busy / wait fractions
+    of the blind-rotation kernel.  The program behind `--` is python3 itself (no env / shell hop)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    passes = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
+               "SQ_LDS_BANK_CONFLICT"]]
+    base = kernel_name.split("<")[0]
+    acc = collections.defaultdict(list)
+    env = dict(os.environ, TMPDIR="/tmp")
+    with tempfile.TemporaryDirectory(prefix="spf_pmc_", dir="/tmp") as tmp:
+        for i, counters in enumerate(passes):
+            out = os.path.join(tmp, f"p{i}")
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--batch", str(B), "--no-extras", "--no-cpu-baseline", "--no-live-counters"]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+            if r.returncode != 0:
+                raise RuntimeError(f"rocprofv3 pass {counters} failed: {r.stderr[-300:]}")
+            for f in glob.glob(os.path.join(out, "*", "*_counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    if base in row["Kernel_Name"]:
+                        acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    c = {k: sum(v) / len(v) for k, v in acc.items() if v}
+    if "FETCH_SIZE" not in c:
+        raise RuntimeError("no counter rows for " + base)
+    cyc = kernel_ms * 1e-3 * 2.39e9   # un-profiled kernel time of this run x the in-kernel clock (DESIGN.md §5)
+    out = {"hbm_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2 + c.get("WRITE_SIZE", 0.0) * 1024,
+           "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c.get("WRITE_SIZE"),
+           "source": "rocprofv3 --pmc child passes of this run (FETCH_SIZE | WRITE_SIZE | SQ_*), per dispatch of " + base}
+    if "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 4)
+        out["lds_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / 256 / cyc, 4)
+        out["wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+        out["issue_stall_frac"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+        out["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]
+        out["SQ_LDS_BANK_CONFLICT"] = c["SQ_LDS_BANK_CONFLICT"]
+    return out
 
 
 def _bench_mul8_pool(eng, P, rank, world, per_gpu=8):
