@@ -152,3 +152,41 @@ def test_config4_shard_8192_default128(full):
     ref = np.concatenate([eng.circuit_bootstrap_pbs(lwe[i:i + 1024]) for i in range(0, B, 1024)])
     bad = np.nonzero((got != ref).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} ciphertexts differ between one 8192-launch and eight 1024-launches, first {bad[:8]}"
+
+
+def test_big_batches_are_bit_stable_run_to_run(full):
+    """Determinism at bench sizes (r03): a hazard that shows as ONE wrong register in one unit out of a thousand — a
+    register reused while a load into it is still in flight, as r02's cmux_kernel allowed for the dead selector-row
+    loads of a gate's last round — passes every small parity test.  Same inputs, three runs, every word equal, for the
+    streaming CMUX at 4096 gates (2048 workgroups) and for the whole circuit bootstrap (blind rotation, trace with its
+    parked accumulator half, scheme switch) at 2048 ciphertexts; plus the first and last unit against the oracle."""
+    ks, eng = full
+    P = ks.params
+    rng = np.random.default_rng(0xD37)
+    B = 4096
+    a = random_glwe(41, B, P.glwe_len)
+    b = random_glwe(42, B, P.glwe_len)
+    n = 2 * 4 * 2 * 1024
+    g = ((rng.standard_normal((B, n)) + 1j * rng.standard_normal((B, n))) * 2.0 ** 60).astype(np.complex128)
+    first = eng.cmux(g, a, b)
+    for _ in range(2):
+        again = eng.cmux(g, a, b)
+        bad = np.nonzero((again != first).any(axis=1))[0]
+        assert bad.size == 0, f"cmux: {bad.size} gates differ between two runs on the same inputs, first {bad[:8]}"
+    for i in (0, B - 1):
+        assert np.array_equal(first[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+    del first, again, g
+
+    r = O.Rng(0x7A11)
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    B = 2048
+    lwe = random_lwe_batch(0xD38, B, 637)
+    first = eng.circuit_bootstrap(lwe)
+    again = eng.circuit_bootstrap(lwe)
+    bad = np.nonzero((again.reshape(B, -1).view(np.uint64) != first.reshape(B, -1).view(np.uint64)).any(axis=1))[0]
+    assert bad.size == 0, f"circuit bootstrap: {bad.size} ciphertexts differ between two runs, first {bad[:8]}"
+    for i in (0, B - 1):
+        exp = O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P)
+        assert np.array_equal(first[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), i
