@@ -471,6 +471,11 @@ def _live_counters(kernel_name, B, kernel_ms):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
+    # never nest: under a profiler this process carries its preloaded tool library, a child launcher would inherit it,
+    # initialise the GPU before it execs python3, and that exec is refused on this pool (and pointless anyway)
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+            any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ):
+        raise RuntimeError("already running under a profiler: live counter passes skipped")
     passes = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
                "SQ_LDS_BANK_CONFLICT"]]

@@ -8,7 +8,7 @@ ARGS=${3---no-extras}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline $ARGS"
+CMD="python3 bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline --no-live-counters $ARGS"
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?"

@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_$TAG.log
 : > $OUT
 for V in "$@"; do
   echo "== $V" >> $OUT
-  env $V timeout -k 10 240 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | python3 -c "
+  env $V timeout -k 10 240 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-counters 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     l=l.strip()

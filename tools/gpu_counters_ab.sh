@@ -4,7 +4,7 @@
 set -o pipefail
 TAG=$1; shift
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras ${BENCH_EXTRA:-}"
+CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras --no-live-counters ${BENCH_EXTRA:-}"
 export KFILTER=${KFILTER:-blind_rotate}
 for V in "$@"; do
   N=$(echo "$V" | tr -c 'A-Za-z0-9\n' '_')

@@ -5,7 +5,7 @@ set -o pipefail
 for V in "$@"; do
   echo "== $V"
   env $V timeout -k 10 400 python -m pytest tests/test_gpu_cbs_tail.py -x -q -m gpu 2>&1 | tail -2 || exit 1
-  env $V timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --with-cbs 2>&1 | python3 -c "
+  env $V timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-counters --no-extras --with-cbs 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

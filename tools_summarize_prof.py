@@ -41,6 +41,28 @@ def main():
             lines.append(f"| `{short(r['Name'])[:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | "
                          f"{float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
         lines.append("")
+    # the same trace grouped by (kernel, workgroups per launch): the bench launches several kernels at more than one
+    # batch size (host-pointer slices of 1024, gate-graph levels), and an average over unlike launches says nothing
+    kt = glob.glob(os.path.join(src, "trace/*/*_kernel_trace.csv"))
+    if kt:
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(kt[0])):
+            k = short(r["Kernel_Name"])
+            if k.startswith(("__amd", "at::", "void at::")) or "elementwise" in k or "distribution" in k or "Cijk" in k:
+                continue
+            wgs = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+            by[(k, wgs)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        lines += ["## --kernel-trace, by kernel AND grid (workgroups per launch)", "",
+                  "| kernel | workgroups | launches | avg ms | min ms | max ms |", "|---|---|---|---|---|---|"]
+        names = sorted({k for k, _ in by})
+        for k in names:
+            groups = sorted(((g, v) for (kk, g), v in by.items() if kk == k), key=lambda gv: -sum(gv[1]))
+            for g, v in groups[:6]:   # the six heaviest shapes of a kernel
+                lines.append(f"| `{k[:70]}` | {g} | {len(v)} | {sum(v)/len(v):.4f} | {min(v):.4f} | {max(v):.4f} |")
+            if len(groups) > 6:
+                rest = [x for _, v in groups[6:] for x in v]
+                lines.append(f"| `{k[:70]}` | ({len(groups) - 6} more shapes) | {len(rest)} | {sum(rest)/len(rest):.4f} | {min(rest):.4f} | {max(rest):.4f} |")
+        lines.append("")
     lines += ["## PMC passes (one rocprofv3 --pmc run per pass; per-dispatch averages, summed over the chip)", "",
               "| pass | kernel | counter | dispatches | avg per dispatch |", "|---|---|---|---|---|"]
     allacc = collections.defaultdict(dict)
