@@ -90,7 +90,7 @@ constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlot
 // transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
 // three (8 registers, 32 B of scratch less).  The library instantiates OPT = 6 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
-template <int L, int LOGB, int OPT, int W, int CTS = 4>
+template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
     constexpr int XP = (OPT & 1) ? 1 : ((OPT & 2) ? 2 : 0);
@@ -170,6 +170,14 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             pair_barrier_w();
         } while (opaque_zero != 0);
     };
+    // MIX = 0: every rotation amount is even (log_v >= 1), an even rotation keeps the coefficient parity, a wave gathers
+    // only what it staged itself and in-order LDS needs no hand-over for that; the block structure stays the same
+    auto rendezvous_if_mixing = [&]() {
+        do {
+            if constexpr (MIX) pair_barrier_w();
+            else asm volatile("" ::: "memory");
+        } while (opaque_zero != 0);
+    };
 
     uint64_t* stage_mine = reinterpret_cast<uint64_t*>(mine);
     const c64* twist = tab + kTWOff + w * 512 + lane;   // e^{+i pi (2n'+w)/2048}, n' = 64 n1 + lane
@@ -194,7 +202,9 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             // my region is free: for p = 0 the partner's last reads of it (inverse cross data) were
             // followed by a rendezvous, for p = 1 by the workgroup barrier behind the MADs
             stage(p);
-            rendezvous(); // both parities staged
+            // With log_v >= 1 (MIX = 0: the modulus switch clears the low log_v bits — the circuit bootstrap uses log_v = 2)
+            // the two gather hand-overs of a polynomial are not needed: four of the ten barriers of a step go.
+            rendezvous_if_mixing(); // both parities staged
             STAMP(0);
             uint32_t dig[16];
             {
@@ -225,7 +235,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 VV[1][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 1, tw);
             }
             STAMP(1);
-            rendezvous(); // partner is done gathering from my region
+            rendezvous_if_mixing(); // partner is done gathering from my region
             STAMP(2);
             // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
             // of polynomial 0 were requested ahead of the previous step's inverse transforms)
@@ -387,24 +397,24 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 // The body is instantiated once per sample parity (w = 0 / 1): every parity-dependent choice (which half
 // of the cross exchange a wave keeps, table offsets) is then static — no value selects, no branches that
 // merge register arrays (those end up in scratch), parity-dependent LDS offsets as immediates.
-template <int L, int LOGB, int OPT>
+template <int L, int LOGB, int OPT, int MIX = 1>
 __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1>(a, smem);
-    else blind_rotate2p_body<L, LOGB, OPT, 0>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 4, MIX>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0, 4, MIX>(a, smem);
 }
 
 // The same schedule with TWO ciphertexts per workgroup (four waves, one per SIMD, one workgroup per CU): for batches
 // between one and two ciphertexts per CU, where the four-ciphertext shape would leave CUs idle and the four-wave
 // latency kernel needs two rounds.  The pair shares each key chunk through the ring; same words.
 constexpr int kBlindRotate2p2Lds = kTableBytes + 2 * kWaveBufBytes + 2 * kBskSlotBytes;
-template <int L, int LOGB, int OPT>
+template <int L, int LOGB, int OPT, int MIX = 1>
 __global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 2>(a, smem);
-    else blind_rotate2p_body<L, LOGB, OPT, 0, 2>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 2, MIX>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0, 2, MIX>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs
 // a step ahead.  The whole 160 KiB of LDS: twiddles, 4 x 2 exchange images, 4 staging / spectra regions.
 constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192 + 4 * 16384; // exchange images + staging / spectra regions
 
-template <int L, int LOGB, int W>
+template <int L, int LOGB, int W, int MIX = 1>
 __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, char* smem)
 {
     static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
@@ -512,7 +522,10 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         uint64_t* stage = reinterpret_cast<uint64_t*>(spectra(w, h));
 #pragma unroll
         for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
-        wg_barrier(); // 1: both parities of both polynomials staged
+        // 1: both parities of both polynomials staged.  Not needed when every rotation amount is even (MIX = 0, log_v >= 1:
+        // an even rotation keeps the coefficient parity, the wave gathers only from the region it staged itself)
+        if constexpr (MIX) wg_barrier();
+        else compiler_fence();
         STAMP4(0);
         SPF_KEY_PIECE(6);
         uint32_t dig[16];
@@ -683,12 +696,12 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
 }
 
 // one copy of the body per sample parity (see blind_rotate2p_kernel)
-template <int L, int LOGB>
+template <int L, int LOGB, int MIX = 1>
 __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate4_body<L, LOGB, 1>(a, smem);
-    else blind_rotate4_body<L, LOGB, 0>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate4_body<L, LOGB, 1, MIX>(a, smem);
+    else blind_rotate4_body<L, LOGB, 0, MIX>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
