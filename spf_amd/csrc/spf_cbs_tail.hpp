@@ -306,35 +306,51 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
                 WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);
                 WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wci);
             }
-        if constexpr (w == 0) {
+        // The inverse cross exchange goes through the KEY RING (free between the barrier behind the last MADs and the next
+        // refill): wave v writes its outgoing half into slot v (8 KiB), reads slot v^1 behind ONE barrier and then refills
+        // exactly that slot with its 8 KiB of the next key chunk — the slot's only reader is the wave that overwrites it,
+        // in program order, so no second barrier ("cross reads retired") is needed; the transforms run in the tile.
+        {
+            c64* slot_mine = reinterpret_cast<c64*>(ring + wv * 8192);
+            const c64* slot_theirs = reinterpret_cast<const c64*>(ring + (wv ^ 1) * 8192);
+            if constexpr (w == 0) {
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+                for (int q = 0; q < 2; q++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
-        } else {
+                    for (int i = 0; i < 4; i++) slot_mine[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+            } else {
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+                for (int q = 0; q < 2; q++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
+                    for (int i = 0; i < 4; i++) slot_mine[(q * 4 + i) * 64 + lane] = WW[q][i];
+            }
+            rendezvous();
+            if constexpr (w == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][4 + i] = slot_theirs[(q * 4 + i) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][i] = slot_theirs[(q * 4 + i) * 64 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's contents are in registers
         }
-        rendezvous();
-        if constexpr (w == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
-        }
-        rendezvous(); // both cross reads retired before either region is overwritten
-        // the accumulator has landed BEFORE the next key rows are requested: vmcnt counts in order, a wait for it behind
-        // the request would wait for the rows as well
+        // the parked accumulator half has landed BEFORE the next key rows are requested: vmcnt counts in order, a wait for
+        // it behind the request would wait for the rows as well
 #pragma unroll
         for (int e = 0; e < 16; e++) asm volatile("" : "+v"(accb[e]));
-        if (chunk < total_chunks) ring_dma(chunk); // rows of the next round's first digit pair
+        if (chunk < total_chunks) { // rows of the next round's first digit pair, this wave's share = the slot it just read
+            const uint32_t rnd = chunk / 3;
+            const char* src = reinterpret_cast<const char*>(a.ak) +
+                              (size_t)__builtin_amdgcn_readfirstlane(rnd * L + (L - 2)) * kBskSlotBytes + (wv ^ 1) * 8192;
+            const uint32_t lane16 = (uint32_t)lane * 16u;
+            const uint32_t dst = lds_address(ring) + (wv ^ 1) * 8192;
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds_dma_piece(src + k * 1024, lane16, dst + k * 1024);
+        }
         fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
         {
             uint64_t t[16];

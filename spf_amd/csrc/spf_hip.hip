@@ -253,10 +253,10 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     // log_v >= 1 makes every rotation amount even: the kernels then skip the hand-overs around the rotation gather (",even")
     if (quad && log_v == 0) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16, 1>), kBlindRotate4Lds);
     else if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16,even>", (blind_rotate4_kernel<2, 16, 0>), kBlindRotate4Lds);
-    else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,6>", (blind_rotate2p2_kernel<2, 16, 6, 1>), kBlindRotate2p2Lds);
-    else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,6,even>", (blind_rotate2p2_kernel<2, 16, 6, 0>), kBlindRotate2p2Lds);
-    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16,6>", (blind_rotate2p_kernel<2, 16, 6, 1>), kBlindRotate2pLds);
-    else SPF_LAUNCH("blind_rotate2p_kernel<2,16,6,even>", (blind_rotate2p_kernel<2, 16, 6, 0>), kBlindRotate2pLds); // even rotations only
+    else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14>", (blind_rotate2p2_kernel<2, 16, 14, 1>), kBlindRotate2p2Lds);
+    else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14,even>", (blind_rotate2p2_kernel<2, 16, 14, 0>), kBlindRotate2p2Lds);
+    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16,14>", (blind_rotate2p_kernel<2, 16, 14, 1>), kBlindRotate2pLds);
+    else SPF_LAUNCH("blind_rotate2p_kernel<2,16,14,even>", (blind_rotate2p_kernel<2, 16, 14, 0>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->timing) {
@@ -467,13 +467,13 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            kKsLdsBytes));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 6, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 14, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 6, 0>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 14, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 6, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 6, 0>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));

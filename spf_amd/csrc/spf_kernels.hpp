@@ -88,7 +88,8 @@ constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlot
 
 // OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
 // transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
-// three (8 registers, 32 B of scratch less).  The library instantiates OPT = 6 only; the A/B numbers of the others and of
+// three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
+// two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
@@ -327,32 +328,80 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 WW[q][i] = cadd(prod[q][i], prod[q][i + 4]);                      // Ep: kept by wave 0
                 WW[q][4 + i] = cmul_tw<-1>(csub(prod[q][i], prod[q][i + 4]), wci); // Op: kept by wave 1
             }
-        if constexpr (w == 0) {
+        if constexpr ((OPT & 8) != 0) {
+            // The inverse cross exchange goes through the KEY RING (free between the barrier behind the last MADs and the
+            // next refill): wave v writes its outgoing half into slot v (8 KiB), reads slot v^1 behind ONE barrier, and then
+            // refills exactly that slot with its 8 KiB of the next key chunk — the only reader of the slot is the wave that
+            // overwrites it, in program order, so the second barrier of the exchange ("cross reads retired before the
+            // image is overwritten") is not needed: the transforms run in the tile, which nobody else touches any more.
+            c64* slot_mine = reinterpret_cast<c64*>(bskring + wv * 8192);
+            const c64* slot_theirs = reinterpret_cast<const c64*>(bskring + (wv ^ 1) * 8192);
+            if constexpr (w == 0) {
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+                for (int q = 0; q < 2; q++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+                    for (int i = 0; i < 4; i++) slot_mine[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) slot_mine[(q * 4 + i) * 64 + lane] = WW[q][i];
+            }
+            rendezvous();
+            if constexpr (w == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][4 + i] = slot_theirs[(q * 4 + i) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][i] = slot_theirs[(q * 4 + i) * 64 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's contents are in registers
+            STAMP(8);
+            if (chunk < total_chunks) {
+                const char* src = reinterpret_cast<const char*>(a.bsk) +
+                                  (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes);
+                const uint32_t lane16 = (uint32_t)lane * 16u;
+                const uint32_t ring0 = lds_address(bskring);
+#pragma unroll
+                for (int k = 0; k < 8; k++) // the slot just read
+                    lds_dma_piece(src + (wv ^ 1) * 8192 + k * 1024, lane16, ring0 + (wv ^ 1) * 8192 + k * 1024);
+#pragma unroll
+                for (int k = 0; k < (2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024); k++) // (fewer waves than slots: the rest of the ring)
+                    lds_dma_piece(src + 2 * CTS * 8192 + (wv * ((2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024)) + k) * 1024, lane16,
+                                  ring0 + 2 * CTS * 8192 + (wv * ((2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024)) + k) * 1024);
+            }
         } else {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
+            if constexpr (w == 0) {
+    #pragma unroll
+                for (int q = 0; q < 2; q++)
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][4 + i];
+            } else {
+    #pragma unroll
+                for (int q = 0; q < 2; q++)
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(q * 4 + i) * 64 + lane] = WW[q][i];
+            }
+            rendezvous();
+            if constexpr (w == 0) {
+    #pragma unroll
+                for (int q = 0; q < 2; q++)
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+            } else {
+    #pragma unroll
+                for (int q = 0; q < 2; q++)
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
+            }
+            rendezvous(); // both cross reads retired before either region is overwritten
+            STAMP(8);
+            if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
-        rendezvous();
-        if constexpr (w == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) WW[q][4 + i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
-        }
-        rendezvous(); // both cross reads retired before either region is overwritten
-        STAMP(8);
-        if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
         STAMP(9);
 #pragma unroll
