@@ -111,7 +111,7 @@ def main():
         f = lambda x: "—" if x is None else f"{x:.3f}"
         lines.append(f"| `{k[:60]}` | {ms:.4f} | {f(d.get('valu_busy_frac'))} | {f(d.get('mfma_busy_frac'))} | {f(d.get('lds_busy_frac'))} | "
                      f"{f(d.get('wait_frac'))} | {f(d.get('issue_stall_frac'))} | "
-                     f"{d['hbm_bytes_per_launch']:.4g}" + (" |" if 'hbm_bytes_per_launch' in d else "— |"))
+                     (f"{d['hbm_bytes_per_launch']:.4g}" if 'hbm_bytes_per_launch' in d else "—") + " |")
     os.makedirs("profiles", exist_ok=True)
     open(os.path.join("profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     dom = [k for k in derived if k.startswith("blind_rotate")]
