@@ -110,7 +110,7 @@ def main():
         derived[k] = d
         f = lambda x: "—" if x is None else f"{x:.3f}"
         lines.append(f"| `{k[:60]}` | {ms:.4f} | {f(d.get('valu_busy_frac'))} | {f(d.get('mfma_busy_frac'))} | {f(d.get('lds_busy_frac'))} | "
-                     f"{f(d.get('wait_frac'))} | {f(d.get('issue_stall_frac'))} | "
+                     f"{f(d.get('wait_frac'))} | {f(d.get('issue_stall_frac'))} | " +
                      (f"{d['hbm_bytes_per_launch']:.4g}" if 'hbm_bytes_per_launch' in d else "—") + " |")
     os.makedirs("profiles", exist_ok=True)
     open(os.path.join("profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
@@ -118,7 +118,8 @@ def main():
     if dom:
         k = max(dom, key=lambda x: derived[x]["kernel_ms"])
         # the name bench.py gets from spf_last_blind_rotate_kernel: template arguments without spaces
-        out = dict(derived[k], kernel=k.replace(", ", ","), batch=batch, tag=tag, date=time.strftime("%Y-%m-%d"),
+        lib_name = k.replace(", ", ",").replace(",14,0>", ",14,even>").replace(",14,1>", ",14>")
+        out = dict(derived[k], kernel=lib_name, batch=batch, tag=tag, date=time.strftime("%Y-%m-%d"),
                    source=f"profiles/{tag}_summary.md: rocprofv3 --kernel-trace and --pmc passes of `bench.py --steps 2 "
                           f"--warmup 1 --no-cpu-baseline --no-extras --batch {batch}` (separate runs); FETCH_SIZE x2 "
                           "(gfx950 128-B requests tallied at 64 B)")
