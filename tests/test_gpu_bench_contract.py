@@ -36,6 +36,13 @@ def test_bench_line_has_the_contract_fields():
         assert isinstance(d.get(leg), dict), leg
     assert d["pcie_inclusive"]["same_words_as_device_path"] is True
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # traffic / busy fractions are this run's own rocprofv3 --pmc passes when the profiler is on the box, else the
+    # committed passes (attached only for the same kernel and batch — not this batch size — so then traffic is null)
+    if roof.get("counters"):
+        assert roof["traffic"] == roof["counters"]["hbm_bytes_per_launch"] > 0
+        assert 0.0 < roof["counters"]["valu_busy_frac"] < 1.0
+    else:
+        assert "live_counters" in (d.get("leg_errors") or {}) or roof["traffic"] is None
     cpu = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
