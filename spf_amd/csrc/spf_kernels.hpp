@@ -91,6 +91,17 @@ constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlot
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
 // two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
+// s_setprio PRIO for the waves whose flag is set, as ONE opaque instruction group: a C++ branch on the (runtime, wave-uniform)
+// flag makes hipcc restructure the step loop around it (the same unswitching that a conditional barrier provokes)
+template <int PRIO>
+__device__ __forceinline__ void young_prio(uint32_t flag) {
+    uint32_t tmp; // (hipcc hands an "s" INPUT over in a VGPR when it keeps the flag there: read it back explicitly)
+    if constexpr (PRIO != 0)
+        asm volatile("v_readfirstlane_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lprio%=\n\ts_setprio 1\n.Lprio%=:" : "=&s"(tmp) : "v"(flag) : "scc");
+    else
+        asm volatile("v_readfirstlane_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lprio%=\n\ts_setprio 0\n.Lprio%=:" : "=&s"(tmp) : "v"(flag) : "scc");
+}
+
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
@@ -157,6 +168,14 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
     }
     __syncthreads();
+    // Issue priority, swapped in the middle of each long barrier-to-barrier stretch.  A SIMD holds wave v and wave v + 4 of
+    // the workgroup and the arbiter prefers the older one, which then reaches the next barrier thousands of cycles early and
+    // idles there while its partner runs ALONE (nobody fills that wave's LDS round trips).  The younger waves take priority
+    // 1 for the first part of a stretch and give it back for the rest, so both arrive together: 44.9 -> 42.7 ms per 4096
+    // (profiles/r03_experiments_blind_rotate.md, "issue priority"; with ten barriers a step the stretches were too short
+    // for this to pay — r02 measured it as a loss).
+    constexpr bool PRIO = CTS == 4; // (two waves per SIMD only with four ciphertexts per workgroup)
+    const uint32_t is_young = __builtin_amdgcn_readfirstlane(wv >= CTS ? 1u : 0u);
     uint32_t opaque_zero;
     asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
     // Every hand-over between the two waves of a ciphertext is a bare s_barrier of the whole workgroup
@@ -240,6 +259,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             STAMP(2);
             // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
             // of polynomial 0 were requested ahead of the previous step's inverse transforms)
+            if constexpr (PRIO) { // (2) polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger
+                if (p == 0) young_prio<0>(is_young);
+                else young_prio<1>(is_young);
+            }
             if (p == 1) ring_dma(chunk);
             fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
             STAMP(3);
@@ -256,6 +279,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
                     for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
             }
+            if constexpr (PRIO) { if (p == 1) young_prio<0>(is_young); } // (3)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
             __syncthreads();
             STAMP(4);
@@ -361,6 +385,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's contents are in registers
             STAMP(8);
+            if constexpr (PRIO) young_prio<1>(is_young); // (1) the long stretch starts: the younger waves lead
             if (chunk < total_chunks) {
                 const char* src = reinterpret_cast<const char*>(a.bsk) +
                                   (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes);
