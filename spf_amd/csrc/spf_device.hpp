@@ -29,6 +29,8 @@ __device__ __forceinline__ gc64_ptr global_view(const c64* p) { return (gc64_ptr
 __device__ __forceinline__ gu64_cptr global_view(const uint64_t* p) { return (gu64_cptr)(uintptr_t)p; }
 __device__ __forceinline__ gu64_ptr global_view(uint64_t* p) { return (gu64_ptr)(uintptr_t)p; }
 __device__ __forceinline__ c64 gload(gc64_ptr p) { f64x2_t v = *p; return {v.x, v.y}; }
+// read-once data (a gate's selector rows): streaming hint, 6.2 -> 7.0 TB/s for the bare read pattern (tools/microbench)
+__device__ __forceinline__ c64 gload_stream(gc64_ptr p) { f64x2_t v = __builtin_nontemporal_load(p); return {v.x, v.y}; }
 
 __device__ __forceinline__ c64 cadd(c64 a, c64 b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ c64 csub(c64 a, c64 b) { return {a.re - b.re, a.im - b.im}; }

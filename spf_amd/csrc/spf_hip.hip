@@ -481,6 +481,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 4>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, cmux_lds_bytes(4)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           cmux_lds_bytes(2)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, cmux_lds_bytes(2)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux4_kernel<4, 4>),
@@ -811,7 +813,44 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
         // the two halves drift apart, so one half's selector requests fly while the other computes, and a barrier
         // ties four waves instead of eight (0.329 -> 0.316 ms per 4096 gates; SPF_CMUX_GATES=4 for the old shape)
         static const int gates = [] { const char* e = getenv("SPF_CMUX_GATES"); return e ? atoi(e) : 2; }();
-        if (gates == 2)
+#ifdef SPF_STAMPS
+        // diagnostic build: per-phase cycles of the first few streaming-shape launches (median over waves)
+        static int reported_s = 0;
+        if (reported_s < 2 && gates == 2 && a.B >= 1024) {
+            const size_t waves = (size_t)((a.B + 1) / 2) * 4;
+            uint64_t* d_st = nullptr;
+            (void)hipMalloc(&d_st, waves * 16 * 8);
+            (void)hipMemsetAsync(d_st, 0, waves * 16 * 8, s);
+            CmuxArgs b = a;
+            b.stamps = d_st;
+            hipLaunchKernelGGL((cmux_kernel<4, 4, 2>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, b);
+            (void)hipStreamSynchronize(s);
+            std::vector<uint64_t> h(waves * 16);
+            (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(d_st);
+            static const char* nm[12] = {"entry: table copy, operand loads, decomposition", "barrier (table in place)", "digit + twist x8",
+                "hand-over (cross data consumed) x7", "forward transform x8", "cross write + hand-over x8", "cross read + combine x8",
+                "wait for the round's selector rows x8", "MAD + next rows requested x8", "inverse cross exchange (3 hand-overs)",
+                "inverse transform pair", "untwist + d0 + store issue"};
+            fprintf(stderr, "[cmux stamps] B=%u (cycles per gate, median over %zu waves)\n", a.B, waves);
+            double tot = 0;
+            for (int i = 0; i < 12; i++) {
+                std::vector<uint64_t> v;
+                for (size_t wv = 0; wv < waves; wv++) v.push_back(h[wv * 16 + i]);
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "[cmux stamps] %-52s %8llu\n", nm[i], (unsigned long long)v[v.size() / 2]);
+                tot += (double)v[v.size() / 2];
+            }
+            fprintf(stderr, "[cmux stamps] total %.0f cycles\n", tot);
+            reported_s++;
+            return;
+        }
+#endif
+        // selectors of the launch beyond the 256 MB Infinity Cache (one 256 KiB selector per per_ggsw units): streaming loads
+        const bool stream = !a.ptrs && (size_t)(a.B / (a.per_ggsw ? a.per_ggsw : 1)) * (256u << 10) > ((size_t)256 << 20);
+        if (gates == 2 && stream)
+            hipLaunchKernelGGL((cmux_kernel<4, 4, 2, true>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
+        else if (gates == 2)
             hipLaunchKernelGGL((cmux_kernel<4, 4, 2>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
         else
             hipLaunchKernelGGL((cmux_kernel<4, 4, 4>), dim3((a.B + 3) / 4), dim3(512), cmux_lds_bytes(4), s, a);

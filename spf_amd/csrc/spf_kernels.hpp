@@ -784,9 +784,11 @@ __global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a
 // the operation `KeylessEvaluation::cmux` performs for every gate of a CMUX tree (GGSW in
 // cbs_radix shape, L = 4 digits of 4 bits at DEFAULT_128).  Same two-waves-per-ciphertext
 // arithmetic as blind_rotate2p_kernel (one step, no rotation), but every ciphertext brings its own
-// 2*L*2 polynomials of key (256 KiB at L = 4), read exactly once straight from HBM into registers:
-// algorithmic traffic 256 KiB + 3 x 32 KiB per CMUX makes this kernel HBM-bound.  No workgroup
-// barrier: the two waves of a ciphertext meet through pair_barrier only.
+// 2*L*2 polynomials of key (256 KiB at L = 4), read exactly once straight from HBM into registers
+// (streaming loads): algorithmic traffic 256 KiB + 3 x 32 KiB per CMUX makes this kernel HBM-bound.
+// tools/microbench/ggsw_read_patterns.hip replays exactly this traffic without any arithmetic: 0.26 ms per
+// 4096 gates (5.65 TB/s; the 9 % of the bytes that are WRITES cost a quarter of that time), against
+// 0.295 ms for the kernel — 88 % of its own traffic ceiling.
 struct CmuxArgs {
     const c64* ggsw;      // B x [2][L][2][1024]
     const uint64_t* d0;   // B x 4096 (selected when the GGSW encrypts 0)
@@ -803,10 +805,17 @@ struct CmuxArgs {
 };
 constexpr int cmux_lds_bytes(int gates) { return kTableBytes + gates * kWaveBufBytes + 64; }
 
-template <int L, int LOGB, int G, int W>
+template <int L, int LOGB, int G, int W, bool STREAM>
 __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 {
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
+#ifdef SPF_STAMPS
+    uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMPS_(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMPS_(i) do { } while (0)
+#endif
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -819,11 +828,6 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     // hand-over between the two waves of a gate: every wave of the workgroup runs the same sequence, so a bare
     // s_barrier does it (r01's flat-polled word per pair: 0.366 vs 0.355 ms per 4096 gates)
     auto cmux_sync = [&]() { pair_barrier_w(); };
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 128 * G) dst[i] = src[i];
-    }
     const uint32_t ct_raw = blockIdx.x * G + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
@@ -848,14 +852,31 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     const gu64_ptr gout = global_view(out_ct);
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
-    uint32_t dig[2][16];
+    // All 64 operand words are requested before anything else happens (left to itself hipcc keeps about fourteen loads
+    // in flight and decomposes one value per round trip: 19 us of the 62 us a gate spent in this kernel), the twiddle
+    // image is copied while they fly, and the decomposition starts when they are in.
+    uint64_t x1[2][16], x0[2][16];
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int c = p * kN + coef2(e);
-            const uint64_t x1 = gd1[c], x0 = gd0[c]; // d0 aliases d1 when it is the zero ciphertext: no branch around the load
-            uint64_t diff = x1 - (d0_zero ? 0 : x0); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
+            x1[p][e] = gd1[c];
+            x0[p][e] = gd0[c]; // d0 aliases d1 when it is the zero ciphertext: no branch around the load
+        }
+    sched_fence();
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < kTableEntries; i += 128 * G) dst[i] = src[i];
+    }
+    sched_fence();
+    uint32_t dig[2][16];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            uint64_t diff = x1[p][e] - (d0_zero ? 0 : x0[p][e]); // sub_glwe_ciphertexts(diff, d_1, d_0) (fft_ops.rs:168)
             constexpr int shift = 64 - L * LOGB;
             uint32_t s = (uint32_t)(diff >> shift) + (uint32_t)((diff >> (shift - 1)) & 1);
             uint32_t packed = 0;
@@ -868,7 +889,9 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             }
             dig[p][e] = packed;
         }
+    STAMPS_(0);
     __syncthreads(); // twiddle image ready
+    STAMPS_(1);
 
     const c64* twist = tab + kTWOff + w * 512 + lane;
     const c64* wc = tab + kWCOff + 256 * w + lane;
@@ -886,13 +909,16 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
         const int p = m / L, j = m - p * L;
         return gkey + (size_t)((p * L + (L - 1 - j)) * 2) * kHalf;
     };
+    // STREAM: the launch's selectors exceed the 256 MB Infinity Cache and are read once — streaming loads (0.317 -> 0.298 ms per
+    // 4096 gates); below that, repeated selectors and cache-resident ones are better served by plain loads (0.041 -> 0.038 per 512)
+    auto key_load = [&](gc64_ptr p) -> c64 { return STREAM ? gload_stream(p) : gload(p); };
     c64 k0[8], k1[8];
     {
         const gc64_ptr row = key_row(0);
 #pragma unroll
-        for (int r = 0; r < 8; r++) k0[r] = gload(row + 64 * (r & 3) + 512 * (r >> 2));
+        for (int r = 0; r < 8; r++) k0[r] = key_load(row + 64 * (r & 3) + 512 * (r >> 2));
 #pragma unroll
-        for (int r = 0; r < 8; r++) k1[r] = gload(row + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+        for (int r = 0; r < 8; r++) k1[r] = key_load(row + kHalf + 64 * (r & 3) + 512 * (r >> 2));
     }
 #pragma unroll 1
     for (int m = 0; m < 2 * L; m++) {
@@ -908,8 +934,11 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             int dim = ((int)(wim << (32 - LOGB - sh))) >> (32 - LOGB);
             V[n1] = cmul_nf({(double)dre, (double)dim}, twist[64 * n1]);
         }
+        STAMPS_(2);
         if (m > 0) cmux_sync(); // partner is done with my last cross data
+        STAMPS_(3);
         fft512_single<+1>(V, mine, tab, lane);
+        STAMPS_(4);
         c64 Ei[4], Oi[4];
         if (w == 0) {
 #pragma unroll
@@ -919,6 +948,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[i * 64 + lane] = V[i];
         }
         cmux_sync();
+        STAMPS_(5);
         if (w == 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) { Ei[i] = V[i]; Oi[i] = reinterpret_cast<const c64*>(theirs)[i * 64 + lane]; }
@@ -933,6 +963,11 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             X[i] = cadd(Ei[i], t);
             X[i + 4] = csub(Ei[i], t);
         }
+        STAMPS_(6);
+#ifdef SPF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // diagnostic: time spent waiting for this round's selector rows
+        STAMPS_(7);
+#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             double re = __builtin_fma(k0[r].re, X[r].re, prod[0][r].re);
@@ -941,7 +976,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             prod[0][r].im = __builtin_fma(k0[r].im, X[r].re, im);
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) k0[r] = gload(next + 64 * (r & 3) + 512 * (r >> 2));
+        for (int r = 0; r < 8; r++) k0[r] = key_load(next + 64 * (r & 3) + 512 * (r >> 2));
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             double re = __builtin_fma(k1[r].re, X[r].re, prod[1][r].re);
@@ -950,7 +985,8 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             prod[1][r].im = __builtin_fma(k1[r].im, X[r].re, im);
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) k1[r] = gload(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+        for (int r = 0; r < 8; r++) k1[r] = key_load(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+        STAMPS_(8);
     }
     // The last round re-requested its own row pair (an L2 hit) rather than branching around the loads (a branch there
     // makes hipcc wait for every row right where it is requested: 0.31 -> 0.61 ms per 4096).  Those sixteen loads are
@@ -1005,7 +1041,9 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             for (int i = 0; i < 4; i++) WW[q][i] = reinterpret_cast<const c64*>(theirs)[(q * 4 + i) * 64 + lane];
     }
     cmux_sync(); // both cross reads retired before either image is overwritten
+    STAMPS_(9);
     fft512_pair1<-1, 2>(WW[0], WW[1], mine, tab, lane);
+    STAMPS_(10);
     // (the second polynomial's words only now: all 32 across the transform pair do not fit the registers, and a
     // spilled load waits for everything in flight; they land under the first polynomial's conversion)
 #pragma unroll
@@ -1020,14 +1058,22 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             if (owns_output) gout[q * kN + coef2_late(e)] = v;
         }
     }
+    STAMPS_(11);
+#ifdef SPF_STAMPS
+    if (a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * (2 * G) + wv) * 16 + i] = st_acc[i];
+    }
+#endif
+#undef STAMPS_
 }
 
-template <int L, int LOGB, int G>
+template <int L, int LOGB, int G, bool STREAM = false>
 __global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cmux_body<L, LOGB, G, 1>(a, smem);
-    else cmux_body<L, LOGB, G, 0>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cmux_body<L, LOGB, G, 1, STREAM>(a, smem);
+    else cmux_body<L, LOGB, G, 0, STREAM>(a, smem);
 
 }
 
