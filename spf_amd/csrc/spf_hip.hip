@@ -846,8 +846,9 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
             return;
         }
 #endif
-        // selectors of the launch beyond the 256 MB Infinity Cache (one 256 KiB selector per per_ggsw units): streaming loads
-        const bool stream = !a.ptrs && (size_t)(a.B / (a.per_ggsw ? a.per_ggsw : 1)) * (256u << 10) > ((size_t)256 << 20);
+        // selectors of the launch (one 256 KiB selector per per_ggsw units) that, with the operands, no longer fit the 256 MB
+        // Infinity Cache: streaming loads (measured cross-over between 768 and 1024 gates)
+        const bool stream = !a.ptrs && (size_t)(a.B / (a.per_ggsw ? a.per_ggsw : 1)) * (256u << 10) >= ((size_t)224 << 20);
         if (gates == 2 && stream)
             hipLaunchKernelGGL((cmux_kernel<4, 4, 2, true>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
         else if (gates == 2)
