@@ -292,6 +292,12 @@ inline spf_status plan(spf_graph* g)
         HIPCHK(c, hipMalloc((void**)&g->d_ptrs, table.size() * sizeof(void*)));
         HIPCHK(c, hipMemcpy(g->d_ptrs, table.data(), table.size() * sizeof(void*), hipMemcpyHostToDevice));
     }
+    if (getenv("SPF_GRAPH_WIDTHS")) { // diagnostic: CMUX-family launch widths (units) of the plan
+        std::map<size_t, size_t> hist;
+        for (auto& gr : g->groups)
+            if (is_cmux_family(gr.op)) hist[gr.members.size() * (gr.op == SPF_OP_GLEV_CMUX ? g->prm.cbs_radix_count : 1)]++;
+        for (auto& kv : hist) fprintf(stderr, "[graph widths] %zu units x %zu launches\n", kv.first, kv.second);
+    }
     g->h_inputs.assign(g->inputs_bytes, 0);
     g->planned = true;
     return SPF_OK;
