@@ -286,9 +286,15 @@ def main() -> int:
         gbs = cm_bytes / ms / 1e6
         return {"cmux_per_s": round(B / ms * 1e3, 1), "kernel_ms": round(ms, 4),
                 "algorithmic_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                "roofline": {"bound": "hbm", "kernel": "cmux_kernel<4,4,2>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "roofline": {"bound": "hbm",
+                             # streaming loads from 224 MB of selectors up (launch_cmux_args, spf_hip.hip)
+                             "kernel": "cmux_kernel<4,4,2,stream>" if B * P.cbs_ggsw_complex * 16 >= (224 << 20) else "cmux_kernel<4,4,2>",
+                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                             "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B}}
+                             "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B,
+                             "traffic_ceiling_GBs": 5650.0,
+                             "traffic_ceiling_note": "the same reads and writes with no arithmetic at 4096 gates: 0.261 ms "
+                                                     "(tools/microbench/ggsw_read_patterns.hip, profiles/r03_experiments_blind_rotate.md r03e)"}}
 
     gate = leg("gate", _gate) if args.with_keyswitch else None
     cbs = leg("circuit_bootstrap", _cbs) if args.with_cbs else None
