@@ -268,7 +268,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         HIPCHK(c, hipStreamSynchronize(s));
         std::vector<uint64_t> h(n_stamp);
         HIPCHK(c, hipMemcpy(h.data(), a.stamps, n_stamp * 8, hipMemcpyDeviceToHost));
-        static const char* names[12] = {"stage+rendezvous", "gather+decomp+twist", "rendezvous(gathered)", "fwd transform pair",
+        static const char* names[12] = {"stage+rendezvous", "gather+decomp+twist", "rendezvous(gathered) + key-row wait", "fwd transform pair",
             "cross write+key barrier", "cross read+combine", "MAD x2", "ring barrier", "inverse cross exchange",
             "inv transform pair", "untwist+convert+acc", "step head"};
         static const char* names4[12] = {"key issue+stage+barrier1", "gather+decomp+twist", "barrier2", "fwd transform pair",

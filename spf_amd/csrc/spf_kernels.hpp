@@ -280,6 +280,11 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
             }
             if constexpr (PRIO) { if (p == 1) young_prio<0>(is_young); } // (3)
+#ifdef SPF_STAMPS
+            STAMP(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(2); // diagnostic: the wait for the key rows alone (slot 2 is otherwise empty for even rotations)
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
             __syncthreads();
             STAMP(4);
