@@ -45,6 +45,7 @@ struct TraceArgs {
     const c64* tables;
     uint32_t units;          // B * cbs_count
     uint32_t cbs_count, cbs_radix_log;
+    uint64_t* stamps;        // diagnostic builds (-DSPF_STAMPS): [workgroup][wave][16] cycle sums per phase, else null
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -72,6 +73,13 @@ template <int L, int LOGB, int W>
 __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
 {
     static_assert(L == 6 && LOGB == 7, "three digit pairs; the state after the first pair fits 32 bits");
+#ifdef SPF_STAMPS
+    uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMPT(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMPT(i) do { } while (0)
+#endif
     constexpr int XP = 2;
     constexpr int NT = 512;
     c64* tab = reinterpret_cast<c64*>(smem);
@@ -198,6 +206,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             wave_lds_fence(); // gathered: the region may be overwritten (next staging / the exchange image)
         }
 
+        STAMPT(0);
         c64 prod[2][8];
 #pragma unroll
         for (int m = 0; m < 3; m++, chunk++) {
@@ -224,10 +233,12 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             }
             // the ring is free since the barrier behind the previous MADs: rows of this pair (those of a round's first
             // pair were requested ahead of the previous round's inverse transforms)
+            STAMPT(1);
             if (m == 0) young_prio<0>(is_young);
             if (m == 2) young_prio<1>(is_young);
             if (m > 0) ring_dma(chunk);
             fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+            STAMPT(2);
             // radix-2 stage across the two waves, both digits in one exchange
             if constexpr (w == 0) {
 #pragma unroll
@@ -243,6 +254,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             if (m == 2) young_prio<0>(is_young);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
             __syncthreads();
+            STAMPT(3);
             if constexpr (w == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; j++)
@@ -299,7 +311,9 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
                     }
                 }
             }
+            STAMPT(4);
             __syncthreads(); // every wave is done with the ring and with its partner's cross data
+            STAMPT(5);
         }
 
         // ---- back to the torus, both output polynomials together
@@ -343,6 +357,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
                     for (int i = 0; i < 4; i++) WW[q][i] = slot_theirs[(q * 4 + i) * 64 + lane];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's contents are in registers
+            STAMPT(6);
             young_prio<1>(is_young);
         }
         // the parked accumulator half has landed BEFORE the next key rows are requested: vmcnt counts in order, a wait for
@@ -358,7 +373,9 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
 #pragma unroll
             for (int k = 0; k < 8; k++) lds_dma_piece(src + k * 1024, lane16, dst + k * 1024);
         }
+        STAMPT(7);
         fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
+        STAMPT(8);
         {
             uint64_t t[16];
             untwist_to_torus_bits(WW[0], twist, t);
@@ -368,7 +385,15 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
 #pragma unroll
             for (int e = 0; e < 16; e++) accb[e] -= t[e];
         }
+        STAMPT(9);
     }
+#ifdef SPF_STAMPS
+    if (a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 8 + wv) * 16 + i] = st_acc[i];
+    }
+#endif
+#undef STAMPT
     if (!owns_output) return;
     uint64_t* out = a.glev_out + (size_t)unit * 2 * kN;
 #pragma unroll

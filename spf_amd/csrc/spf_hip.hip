@@ -650,6 +650,39 @@ static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64
     TimedScope ts(c, s, T_TRACE);
     spf_status st = ts.begin();
     if (st != SPF_OK) return st;
+#ifdef SPF_STAMPS
+    static int reported_t = 0;
+    if (reported_t < 1 && a.units >= 4096) { // diagnostic build: per-phase cycles per round, median over waves
+        const size_t waves = (size_t)grid.x * 8;
+        uint64_t* d_st = nullptr;
+        HIPCHK(c, hipMalloc(&d_st, waves * 16 * 8));
+        HIPCHK(c, hipMemsetAsync(d_st, 0, waves * 16 * 8, s));
+        a.stamps = d_st;
+        hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTraceLds, s, a);
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::vector<uint64_t> h(waves * 16);
+        HIPCHK(c, hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_st);
+        static const char* nm[10] = {"round head: stage, gather, digits 0-1 (+park)", "digits + twist x3", "fwd transform pair x3",
+            "cross write + key barrier x3", "cross read + combine + MAD x3", "ring barrier x3", "inverse cross exchange",
+            "next rows requested", "inv transform pair", "untwist + convert + acc"};
+        fprintf(stderr, "[trace stamps] per automorphism round, median over %zu waves (cycles | waves 0-3 | waves 4-7)\n", waves);
+        double tot = 0;
+        for (int i = 0; i < 10; i++) {
+            std::vector<uint64_t> v, vo, vy;
+            for (size_t wv = 0; wv < waves; wv++) {
+                v.push_back(h[wv * 16 + i]);
+                ((wv % 8) < 4 ? vo : vy).push_back(h[wv * 16 + i]);
+            }
+            std::sort(v.begin(), v.end()); std::sort(vo.begin(), vo.end()); std::sort(vy.begin(), vy.end());
+            fprintf(stderr, "[trace stamps] %-48s %8.0f | %8.0f | %8.0f\n", nm[i], v[v.size() / 2] / 11.0, vo[vo.size() / 2] / 11.0, vy[vy.size() / 2] / 11.0);
+            tot += v[v.size() / 2] / 11.0;
+        }
+        fprintf(stderr, "[trace stamps] total %.0f\n", tot);
+        reported_t++;
+        return ts.end();
+    }
+#endif
     hipLaunchKernelGGL((cbs_trace_kernel<6, 7>), grid, block, kTraceLds, s, a);
     HIPCHK(c, hipGetLastError());
     return ts.end();
