@@ -86,11 +86,6 @@ __device__ __forceinline__ void pair_barrier_w()
 
 constexpr int kBlindRotate2pLds = kTableBytes + 4 * kWaveBufBytes + 2 * kBskSlotBytes;
 
-// OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
-// transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
-// three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
-// two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
-// everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
 // s_setprio PRIO for the waves whose flag is set, as ONE opaque instruction group: a C++ branch on the (runtime, wave-uniform)
 // flag makes hipcc restructure the step loop around it (the same unswitching that a conditional barrier provokes)
 template <int PRIO>
@@ -102,6 +97,11 @@ __device__ __forceinline__ void young_prio(uint32_t flag) {
         asm volatile("v_readfirstlane_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lprio%=\n\ts_setprio 0\n.Lprio%=:" : "=&s"(tmp) : "v"(flag) : "scc");
 }
 
+// OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
+// transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
+// three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
+// two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
+// everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
