@@ -86,6 +86,27 @@ def test_config3_streaming_cmux_515(full):
         assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
 
 
+def test_streaming_cmux_large_launch_uses_streaming_loads_and_same_words(full):
+    """From 224 MB of selectors in one launch (896 gates) the streaming shape reads its selector rows with streaming
+    (non-temporal) loads — another instantiation, `cmux_kernel<4,4,2,true>`: 1024 gates in ONE call against the same gates in
+    two calls of 512 (plain loads), word for word, and a sample against the oracle."""
+    ks, eng = full
+    P = ks.params
+    B = 1024
+    nrng = np.random.default_rng(1024)
+    a = random_glwe(41, B, P.glwe_len)
+    b = random_glwe(42, B, P.glwe_len)
+    n = 2 * 4 * 2 * 1024
+    g = np.empty((B, n), dtype=np.complex128)
+    for lo in range(0, B, 128):  # (in slices: the normal deviates of all 1024 selectors at once are 0.5 GB of temporaries)
+        g[lo:lo + 128] = (nrng.standard_normal((128, n)) + 1j * nrng.standard_normal((128, n))) * 2.0 ** 60
+    whole = eng.cmux(g, a, b)
+    halves = np.concatenate([eng.cmux(g[:512], a[:512], b[:512]), eng.cmux(g[512:], a[512:], b[512:])])
+    assert np.array_equal(whole, halves)
+    for i in (0, 511, 512, 1023):
+        assert np.array_equal(whole[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+
+
 def _torus_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     d = (a.astype(np.uint64) - b.astype(np.uint64)).astype(np.int64)
     return np.abs(d.astype(np.float64)) / 2.0 ** 64
