@@ -378,10 +378,10 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
         STAMPT(8);
         {
             uint64_t t[16];
-            untwist_to_torus_bits(WW[0], twist, t);
+            untwist_to_torus_bits<true>(WW[0], twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) accm[e] -= t[e];
-            untwist_to_torus_bits(WW[1], twist, t);
+            untwist_to_torus_bits<true>(WW[1], twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) accb[e] -= t[e];
         }
