@@ -646,6 +646,20 @@ __device__ __forceinline__ uint32_t gadget_digits_packed(uint64_t x)
 
 // complex sample of digit j: re from the packed word of coefficient c, im from that of c + N/2,
 // sign-extended, converted to f64 and twisted (entities/polynomial.rs:257-274, scalar.rs:19-23)
+// The two-digit case (L = 2, LOGB = 16) without the packed form: the rounded top word s itself is kept, and
+//   digit 0 = sext16(s),   digit 1 = sext16((s >> 16) + bit15(s)) = (int)(s + 0x8000) >> 16
+// (radix.rs:157-162: digit, shift, carry of digit >= B/2 into the next, digits as two's-complement small integers).
+__device__ __forceinline__ uint32_t gadget_round_top32(uint64_t x)
+{
+    return (uint32_t)(x >> 32) + (uint32_t)((x >> 31) & 1);
+}
+__device__ __forceinline__ c64 twisted_digit_top32(uint32_t s_re, uint32_t s_im, int j, c64 tw)
+{
+    const int dre = j == 0 ? (int)(int16_t)(s_re & 0xFFFFu) : (int)(s_re + 0x8000u) >> 16;
+    const int dim = j == 0 ? (int)(int16_t)(s_im & 0xFFFFu) : (int)(s_im + 0x8000u) >> 16;
+    return cmul_nf({(double)dre, (double)dim}, tw);
+}
+
 template <int LOGB>
 __device__ __forceinline__ c64 twisted_digit(uint32_t packed_re, uint32_t packed_im, int j, c64 tw)
 {

@@ -114,7 +114,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #else
 #define STAMP(i) do { } while (0)
 #endif
-    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
+    static_assert(L == 2 && LOGB == 16, "two 16-bit digits, taken straight from the rounded top word and processed as a pair");
     constexpr int NT = 128 * CTS; // CTS ciphertexts per workgroup, two waves each
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
@@ -244,15 +244,15 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
                     const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
                     const uint64_t rot = (gin[e] ^ sgn) - sgn;
-                    dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[p][e]);
+                                        dig[e] = gadget_round_top32(rot - acc[p][e]); // the rounded top word; its two digits are taken at the twist
                 }
             }
             c64 VV[2][8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) {
                 const c64 tw = twist[64 * n1];
-                VV[0][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 0, tw);
-                VV[1][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 1, tw);
+                VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, tw);
+                VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, tw);
             }
             STAMP(1);
             rendezvous_if_mixing(); // partner is done gathering from my region
