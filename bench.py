@@ -217,14 +217,16 @@ def main() -> int:
         gate_step()
         sync()
         eng.set_timing(True)
-        tg = time.perf_counter()
-        for _ in range(args.steps):
-            gate_step()
-        sync()
-        tg = time.perf_counter() - tg
-        ks_ms, _ = eng.last_kernel_ms("keyswitch")
-        eng.last_kernel_ms("pbs")
-        eng.set_timing(False)
+        try:
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                gate_step()
+            sync()
+            tg = time.perf_counter() - tg
+        finally:
+            eng.set_timing(False)
+            ks_ms, _ = eng.last_kernel_ms("keyswitch")   # (draining: the event pairs are destroyed here)
+            eng.last_kernel_ms("pbs")
         ks_ops = 2.0 * B * (P.glwe_size * P.polynomial_degree * P.ks_radix_count) * P.lwe0_words * 8   # int8 MACs x 2 over the 8 byte planes
         ks_tops = ks_ops / (ks_ms * 1e-3) / 1e12 if ks_ms else None
         return {"_seconds": tg, "_units": B * args.steps, "_rate_key": "gates_per_s",
@@ -241,15 +243,17 @@ def main() -> int:
         eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
         sync()
         eng.set_timing(True)
-        tc = time.perf_counter()
-        for _ in range(args.steps):
-            eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
-        sync()
-        tc = time.perf_counter() - tc
-        tr_ms, _ = eng.last_kernel_ms("trace")
-        ss_ms, _ = eng.last_kernel_ms("scheme_switch")
-        eng.last_kernel_ms("pbs")
-        eng.set_timing(False)
+        try:
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                eng.circuit_bootstrap_dev(stream, B, lwe0.data_ptr(), ggsw.data_ptr())
+            sync()
+            tc = time.perf_counter() - tc
+        finally:
+            eng.set_timing(False)
+            tr_ms, _ = eng.last_kernel_ms("trace")
+            ss_ms, _ = eng.last_kernel_ms("scheme_switch")
+            eng.last_kernel_ms("pbs")
         out = {"_seconds": tc, "_units": B * args.steps, "_rate_key": "circuit_bootstraps_per_s",
                "ms_per_batch": round(tc / args.steps * 1e3, 3)}
         if tr_ms:
@@ -264,6 +268,51 @@ def main() -> int:
                                              "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                              "frac": round(tf / FP64_PEAK_TFLOPS, 4),
                                              "flop_per_unit": SCHEME_SWITCH_FLOP_PER_CT, "units_per_launch": B}
+        return out
+
+    def _pbs_univariate():
+        # SURVEY 8(d)'s secondary number and the unit of the reference's own bench (sunscreen_tfhe/benches/ops.rs:86-123):
+        # programmable_bootstrap_univariate (programmable_bootstrapping.rs:291-318) = generalized PBS with log_chi = log_v = 0
+        # + sample_extract(., 0), identity LUT of one plaintext bit (generate_lut, :129-185).  With log_v = 0 the rotation
+        # amounts are odd as often as even: the dispatch takes the instantiation of the blind rotation that keeps the two
+        # hand-overs around each rotation gather (nine barriers a step instead of five).
+        lut_h = spf_amd.generate_lut([[0, 1]], 1, P)
+        d_lut = torch.from_numpy(lut_h.view(np.int64)).to(dev)
+        lwe1_out = torch.empty((B, P.lwe1_words), device=dev, dtype=torch.int64)
+
+        def uni_step():
+            eng.pbs_univariate_dev(stream, B, lwe0.data_ptr(), d_lut.data_ptr(), 0, lwe1_out.data_ptr())
+
+        uni_step()
+        sync()
+        eng.set_timing(True)
+        try:
+            tu = time.perf_counter()
+            for _ in range(args.steps):
+                uni_step()
+            sync()
+            tu = time.perf_counter() - tu
+        finally:
+            eng.set_timing(False)
+            u_ms, _ = eng.last_kernel_ms("pbs")
+        name = eng.last_blind_rotate_kernel()
+        tf = FLOP_PER_PBS * B / (u_ms * 1e-3) / 1e12
+        out = {"_seconds": tu, "_units": B * args.steps, "_rate_key": "pbs_per_s", "kernel_ms": round(u_ms, 3),
+               "ms_per_step": round(tu / args.steps * 1e3, 3),
+               "vs_headline_kernel": round(u_ms / kernel_ms, 4) if kernel_ms else None,
+               "lut": "generate_lut(identity, PlaintextBits(1)), shared; output = L1 LWE (sample_extract fused)",
+               "roofline": {"bound": "fp64", "kernel": name, "kernel_ms": round(u_ms, 3), "achieved": round(tf, 3),
+                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                            "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # parity on a sample: the oracle's univariate PBS on 64 of the bench ciphertexts (one per host thread)
+            import oracle as O
+            cnt = min(B, 64)
+            bsk_host = blobs[0].cpu().numpy().view(np.complex128)
+            _, exp = O.bench_generalized_pbs(lwe0[:cnt].cpu().numpy().view(np.uint64), lut_h, bsk_host, O.DEFAULT_128,
+                                             max(1, min(os.cpu_count() or 1, 64)), 0, 0, extract=True, native=True)
+            out["gpu_outputs_bit_equal_on_sample"] = bool(np.array_equal(exp, lwe1_out[:cnt].cpu().numpy().view(np.uint64)))
+            out["sample"] = f"{cnt} of the {B} bench ciphertexts against oracle/spf_oracle.c (spfo_pbs_univariate)"
         return out
 
     def _cmux():
@@ -286,17 +335,13 @@ def main() -> int:
         gbs = cm_bytes / ms / 1e6
         return {"cmux_per_s": round(B / ms * 1e3, 1), "kernel_ms": round(ms, 4),
                 "algorithmic_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                "roofline": {"bound": "hbm",
-                             # streaming loads from 224 MB of selectors up (launch_cmux_args, spf_hip.hip)
-                             "kernel": "cmux_kernel<4,4,2,stream>" if B * P.cbs_ggsw_complex * 16 >= (224 << 20) else "cmux_kernel<4,4,2>",
+                "roofline": {"bound": "hbm", "kernel": eng.last_cmux_kernel(),   # the kernel the library actually launched
                              "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                             "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B,
-                             "traffic_ceiling_GBs": 5650.0,
-                             "traffic_ceiling_note": "the same reads and writes with no arithmetic at 4096 gates: 0.261 ms "
-                                                     "(tools/microbench/ggsw_read_patterns.hip, profiles/r03_experiments_blind_rotate.md r03e)"}}
+                             "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B}}
 
     gate = leg("gate", _gate) if args.with_keyswitch else None
+    uni = leg("pbs_univariate", _pbs_univariate) if extras else None
     cbs = leg("circuit_bootstrap", _cbs) if args.with_cbs else None
     add32 = None
     if args.with_add32 > 0 and rank == 0:
@@ -309,7 +354,8 @@ def main() -> int:
     leg("restore", restore_headline_output)
 
     # one collective for all legs: MAX of the per-rank seconds (inf where a rank failed)
-    timed_legs = [("gate", gate), ("circuit_bootstrap", cbs), ("mul8_gate_pool", mul8), ("mul32_gate_pool", mul32)]
+    timed_legs = [("gate", gate), ("circuit_bootstrap", cbs), ("mul8_gate_pool", mul8), ("mul32_gate_pool", mul32),
+                  ("pbs_univariate", uni)]
     secs = [(d["_seconds"] if d else float("inf")) for _, d in timed_legs]
     if world > 1:
         t = torch.tensor(secs, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -329,7 +375,7 @@ def main() -> int:
             d["gates_per_s"] = round(d.pop("_gates") * world / sec, 1)
         if name.endswith("_pool"):
             d["ms_per_pool_run"] = round(sec * 1e3, 3)
-    gate, cbs, mul8, mul32 = [(d or None) for _, d in timed_legs]
+    gate, cbs, mul8, mul32, uni = [(d or None) for _, d in timed_legs]
 
     total_units = world * B * args.steps
     value = total_units / dt
@@ -345,7 +391,8 @@ def main() -> int:
     # when rocprofv3 is not on the box or --no-live-counters is given.
     traffic, stored, live = None, None, None
     if rank == 0 and world == 1 and not args.no_live_counters:
-        live = leg("live_counters", lambda: _live_counters(kernel_name, B, kernel_ms))
+        n_cu = torch.cuda.get_device_properties(local_dev).multi_processor_count
+        live = leg("live_counters", lambda: _live_counters(kernel_name, B, kernel_ms, n_cu))
         if live:
             traffic = live.get("hbm_bytes_per_launch")
     tpath = os.path.join(ROOT, "profiles", "latest_counters.json")
@@ -365,8 +412,9 @@ def main() -> int:
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
         "note": "the f64 butterflies and MADs run on the VALU (v_fma_f64 / v_add_f64 / v_mul_f64, zero MFMA instructions); "
                 "MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and MFMA alike; issue_bound_frac = share of the kernel's "
-                "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / time); `counters` = this run's own rocprofv3 --pmc "
-                "passes (child processes), `stored_profile` = the committed passes, used only when no live pass ran",
+                "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles of the profiled dispatch, GRBM_GUI_ACTIVE / 8); "
+                "`counters` = this run's own rocprofv3 --pmc passes (child processes, at most ~150 s in all), `stored_profile` = "
+                "the committed passes, used only when no live pass ran",
         "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBs": round(alg_bytes / per_launch_s / 1e9, 2),
                 "peak_GBs": HBM_PEAK_GBS},
     }
@@ -441,6 +489,8 @@ def main() -> int:
             "pcie_inclusive": pcie,
             "setup_s": round(t_bcast0 - t_keys0, 2),
         }
+        if uni:
+            line["pbs_univariate"] = uni
         if gate:
             line["gate"] = gate
         if cmux:
@@ -464,10 +514,13 @@ def main() -> int:
 DATA_DIR = os.path.join(ROOT, "spf_amd", "data")
 
 
-def _live_counters(kernel_name, B, kernel_ms):
+def _live_counters(kernel_name, B, kernel_ms, n_cu, budget_s=150.0):
     """rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-extras` (the headline step only) as CHILD processes,
     one pass per process: HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KB counters) and the SQ busy / wait fractions
-    of the blind-rotation kernel.  The program behind `--` is python3 itself (no env / shell hop)."""
+    of the blind-rotation kernel.  The program behind `--` is python3 itself (no env / shell hop).  Busy fractions divide the
+    SQ counters by the cycles of the PROFILED dispatch they were counted in (GRBM_GUI_ACTIVE / 8 XCDs, collected in the same
+    pass; MI355X_MICROARCH.md, DVFS give-back) — not by an assumed clock — and the SIMD / CU counts come from the device.
+    The whole thing is bounded by `budget_s` of wall time: a pass that would not fit is skipped and named in `skipped`."""
     import collections
     import csv
     import glob
@@ -482,34 +535,58 @@ def _live_counters(kernel_name, B, kernel_ms):
     if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
             any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ):
         raise RuntimeError("already running under a profiler: live counter passes skipped")
-    passes = [["FETCH_SIZE"], ["WRITE_SIZE"],
-              ["SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
-               "SQ_LDS_BANK_CONFLICT"]]
+    passes = [["SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
+               "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"],
+              ["FETCH_SIZE"], ["WRITE_SIZE"]]
     base = kernel_name.split("<")[0]
     acc = collections.defaultdict(list)
     env = dict(os.environ, TMPDIR="/tmp")
+    t_start, longest, skipped, child_ms = time.time(), 0.0, [], None
     with tempfile.TemporaryDirectory(prefix="spf_pmc_", dir="/tmp") as tmp:
         for i, counters in enumerate(passes):
+            left = budget_s - (time.time() - t_start)
+            if left < max(20.0, 1.3 * longest):
+                skipped.append(counters[0])
+                continue
             out = os.path.join(tmp, f"p{i}")
             cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "2", "--warmup", "1", "--batch", str(B), "--no-extras", "--no-cpu-baseline", "--no-live-counters"]
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+            t0 = time.time()
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                skipped.append(counters[0] + " (timed out)")
+                break
+            longest = max(longest, time.time() - t0)
             if r.returncode != 0:
-                raise RuntimeError(f"rocprofv3 pass {counters} failed: {r.stderr[-300:]}")
+                skipped.append(counters[0] + f" (rc {r.returncode}: {r.stderr[-160:]})")
+                break
+            if i == 0:   # the SQ pass: its own hipEvent kernel time, i.e. the time of the dispatches the counters belong to
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("{"):
+                        child_ms = json.loads(ln)["roofline"]["kernel_ms"]
             for f in glob.glob(os.path.join(out, "*", "*_counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
                     if base in row["Kernel_Name"]:
                         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     c = {k: sum(v) / len(v) for k, v in acc.items() if v}
-    if "FETCH_SIZE" not in c:
-        raise RuntimeError("no counter rows for " + base)
-    cyc = kernel_ms * 1e-3 * 2.39e9   # un-profiled kernel time of this run x the in-kernel clock
-    out = {"hbm_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2 + c.get("WRITE_SIZE", 0.0) * 1024,
-           "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c.get("WRITE_SIZE"),
-           "source": "rocprofv3 --pmc child passes of this run (FETCH_SIZE | WRITE_SIZE | SQ_*), per dispatch of " + base}
-    if "SQ_ACTIVE_INST_VALU" in c:
-        out["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 4)
-        out["lds_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / 256 / cyc, 4)
+    if not c:
+        raise RuntimeError("no counter rows for " + base + (": " + "; ".join(skipped) if skipped else ""))
+    out = {"source": "rocprofv3 --pmc child passes of this run (SQ_* + GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE), per dispatch of " + base,
+           "wall_s": round(time.time() - t_start, 1)}
+    if skipped:
+        out["skipped"] = skipped
+    if "FETCH_SIZE" in c:
+        out["FETCH_SIZE_KB"], out["WRITE_SIZE_KB"] = c["FETCH_SIZE"], c.get("WRITE_SIZE")
+        if "WRITE_SIZE" in c:
+            out["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0            # cycles of the profiled dispatch (the counter sums the 8 XCDs)
+        n_simd = 4 * n_cu
+        out["profiled_kernel_ms"] = child_ms
+        out["profiled_clock_GHz"] = round(cyc / (child_ms * 1e-3) / 1e9, 3) if child_ms else None
+        out["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / n_simd / cyc, 4)   # SQ_ACTIVE_* count quad-cycles
+        out["lds_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / n_cu / cyc, 4)
         out["wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         out["issue_stall_frac"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         out["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]

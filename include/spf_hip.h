@@ -366,10 +366,22 @@ spf_status spf_ciphertext_to_bincode(const spf_params *params, spf_value_kind ki
  * (k+1)*l_cbs*(k+1)*N/2 complex) that `Evaluation::new` obtains by circuit-bootstrapping the trivial L0 LWE of
  * the bit (:161-197).  Computed on first use after the keys were (re)loaded, cached in HBM. */
 spf_status spf_l1ggsw_constant(spf_ctx *ctx, int bit, double *ggsw_fft_out);
+/* Device buffers for a caller that chains the `_dev` entry points but has no HIP binding of its own (the Rust shim of
+ * INTEGRATION.md): hipMalloc / hipFree / hipMemcpy on the context's GPU.  `spf_device_download` first waits for everything
+ * enqueued on `stream` (the stream the producing `_dev` call was given; NULL = the default stream), then copies.  No
+ * reference counterpart (the reference keeps every ciphertext in host memory, crypto/encryption.rs:143-165). */
+spf_status spf_device_alloc(spf_ctx *ctx, size_t bytes, void **dev_ptr);
+spf_status spf_device_free(spf_ctx *ctx, void *dev_ptr);
+spf_status spf_device_upload(spf_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+spf_status spf_device_download(spf_ctx *ctx, void *stream, void *host_dst, const void *dev_src, size_t bytes);
 /* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
  * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
  * shape).  For measurement records; never NULL. */
 const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
+/* The same for the CMUX family (spf_cmux*, spf_glev_cmux*, spf_multiply_glwe_ggsw*, gate graphs): four waves per gate up
+ * to one gate per CU, the streaming shape beyond, with streaming (non-temporal) selector loads once a launch's selectors
+ * exceed the Infinity Cache.  Never NULL. */
+const char *spf_last_cmux_kernel(spf_ctx *ctx);
 
 /* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */
 const char *spf_version(void);

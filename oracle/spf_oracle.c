@@ -1111,3 +1111,46 @@ double spfo_bench_cbs_pbs(const uint64_t *lwe_in, size_t count, const spfo_c64 *
     free(th); free(jobs);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* the same driver for the plain PBS (generalized_programmable_bootstrap with any (log_chi, log_v) and a shared
+ * or per-ciphertext LUT, programmable_bootstrapping.rs:342-410; `extract` != 0 appends sample_extract(.,0) =
+ * programmable_bootstrap_univariate, :291-318): `count` independent bootstraps on `threads` pthreads. */
+typedef struct {
+    const uint64_t *lwe_in, *lut; uint64_t *out; const spfo_c64 *bsk;
+    size_t begin, end, n, N, k, lut_stride, out_stride; uint32_t prl, pc, log_chi, log_v; int extract;
+} gpbs_job;
+
+static void *gpbs_worker(void *arg)
+{
+    gpbs_job *j = (gpbs_job *)arg;
+    for (size_t i = j->begin; i < j->end; i++) {
+        const uint64_t *lwe = j->lwe_in + i * (j->n + 1), *lut = j->lut + i * j->lut_stride;
+        uint64_t *o = j->out + i * j->out_stride;
+        if (j->extract) spfo_pbs_univariate(o, lwe, lut, j->bsk, j->n, j->N, j->k, j->prl, j->pc);
+        else spfo_generalized_pbs(o, lwe, lut, j->bsk, j->n, j->N, j->k, j->prl, j->pc, j->log_chi, j->log_v);
+    }
+    return NULL;
+}
+
+double spfo_bench_generalized_pbs(const uint64_t *lwe_in, size_t count, const uint64_t *lut, size_t lut_stride,
+                                  const spfo_c64 *bsk_fft, size_t n, size_t N, size_t k, uint32_t prl, uint32_t pc,
+                                  uint32_t log_chi, uint32_t log_v, int extract, int threads, uint64_t *out)
+{
+    pthread_once(&tab_once, init_tables);
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    gpbs_job *jobs = (gpbs_job *)malloc(sizeof(gpbs_job) * (size_t)threads);
+    const size_t out_stride = extract ? k * N + 1 : (k + 1) * N;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (gpbs_job){lwe_in, lut, out, bsk_fft, count * (size_t)t / (size_t)threads,
+                             count * (size_t)(t + 1) / (size_t)threads, n, N, k, lut_stride, out_stride,
+                             prl, pc, log_chi, log_v, extract};
+        pthread_create(&th[t], NULL, gpbs_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th); free(jobs);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -221,6 +221,13 @@ double spfo_bench_cbs_pbs(const uint64_t *lwe_in, size_t count, const spfo_c64 *
                           uint32_t cbs_radix_log, uint32_t cbs_count, int threads,
                           uint64_t *glwe_out);
 
+/* the same for generalized_programmable_bootstrap with any (log_chi, log_v) and a shared (lut_stride 0) or
+ * per-ciphertext LUT; extract != 0: programmable_bootstrap_univariate (out rows of k*N+1 words) */
+double spfo_bench_generalized_pbs(const uint64_t *lwe_in, size_t count, const uint64_t *lut, size_t lut_stride,
+                                  const spfo_c64 *bsk_fft, size_t n, size_t N, size_t k, uint32_t pbs_radix_log,
+                                  uint32_t pbs_count, uint32_t log_chi, uint32_t log_v, int extract, int threads,
+                                  uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

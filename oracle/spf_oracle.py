@@ -124,6 +124,7 @@ def _declare(lib):
     f("spfo_encode", u64, u64, u32)
     f("spfo_decode", u64, u64, u32)
     f("spfo_bench_cbs_pbs", dbl, P, sz, P, sz, sz, sz, u32, u32, u32, u32, C.c_int, P)
+    f("spfo_bench_generalized_pbs", dbl, P, sz, P, sz, P, sz, sz, sz, u32, u32, u32, u32, C.c_int, C.c_int, P)
 
 
 def _p(a: np.ndarray):
@@ -435,6 +436,22 @@ def bench_cbs_pbs(lwe_batch, bsk_fft, params: Params, threads: int, native: bool
     secs = lib.spfo_bench_cbs_pbs(_p(lwe_batch), count, _p(bsk_fft), n, params.N, params.k,
                                   params.pbs_radix_log, params.pbs_count, params.cbs_radix_log,
                                   params.cbs_count, threads, _p(out))
+    return float(secs), out
+
+
+def bench_generalized_pbs(lwe_batch, lut, bsk_fft, params: Params, threads: int, log_chi: int = 0, log_v: int = 0,
+                          extract: bool = False, native: bool = False):
+    """Many independent generalized / univariate bootstraps on `threads` host threads: returns (seconds, outputs).
+    `lut` is one GLWE (shared) or one per ciphertext."""
+    lib = _load(native=native)
+    lwe_batch, bsk_fft, lut = _u(lwe_batch), _c(bsk_fft), _u(lut)
+    count, n = lwe_batch.shape[0], lwe_batch.shape[1] - 1
+    stride = 0 if lut.ndim == 1 else params.glwe_len
+    assert lut.size == (params.glwe_len if stride == 0 else count * params.glwe_len)
+    out = np.zeros((count, params.k * params.N + 1 if extract else params.glwe_len), dtype=np.uint64)
+    secs = lib.spfo_bench_generalized_pbs(_p(lwe_batch), count, _p(lut), stride, _p(bsk_fft), n, params.N, params.k,
+                                          params.pbs_radix_log, params.pbs_count, log_chi, log_v, int(extract), threads,
+                                          _p(out))
     return float(secs), out
 
 

@@ -101,6 +101,11 @@ SYMBOLS = [
     ("spf_set_timing", _I, [_P, _I]),
     ("spf_last_kernel_ms", _I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
     ("spf_last_blind_rotate_kernel", C.c_char_p, [_P]),
+    ("spf_last_cmux_kernel", C.c_char_p, [_P]),
+    ("spf_device_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
+    ("spf_device_free", _I, [_P, _P]),
+    ("spf_device_upload", _I, [_P, _P, _P, _SZ]),
+    ("spf_device_download", _I, [_P, _P, _P, _P, _SZ]),
     ("spf_l1ggsw_constant", _I, [_P, _I, _P]),
     ("spf_generate_lut", _I, [C.POINTER(_CParams), _P, _SZ, _U32, _P]),
     ("spf_load_compute_key_bincode", _I, [_P, _P, _SZ]),
@@ -440,6 +445,24 @@ class Engine:
     def sample_extract_l1_dev(self, stream, B, d_glwe, idx, d_out):
         self._ck(self._lib.spf_sample_extract_l1_dev(self._h, stream, B, d_glwe, idx, d_out))
 
+    # -- device buffers (for chaining the _dev forms without a HIP binding of one's own)
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._ck(self._lib.spf_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def device_free(self, ptr: int):
+        self._ck(self._lib.spf_device_free(self._h, ptr))
+
+    def device_upload(self, ptr: int, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        self._ck(self._lib.spf_device_upload(self._h, ptr, _ptr(host), host.nbytes))
+
+    def device_download(self, stream, host: np.ndarray, ptr: int):
+        """waits for `stream` (None = the default stream), then copies host.nbytes bytes from `ptr`"""
+        assert host.flags.c_contiguous
+        self._ck(self._lib.spf_device_download(self._h, stream, _ptr(host), ptr, host.nbytes))
+
     # -- measurement
     def set_timing(self, enabled: bool):
         self._ck(self._lib.spf_set_timing(self._h, 1 if enabled else 0))
@@ -457,6 +480,9 @@ class Engine:
 
     def last_blind_rotate_kernel(self) -> str:
         return (self._lib.spf_last_blind_rotate_kernel(self._h) or b"").decode()
+
+    def last_cmux_kernel(self) -> str:
+        return (self._lib.spf_last_cmux_kernel(self._h) or b"").decode()
 
     def last_kernel_ms(self, kernel: str = "pbs"):
         ms, n = C.c_double(), C.c_int()

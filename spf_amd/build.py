@@ -25,7 +25,7 @@ def _hipcc() -> str:
 def _sources():
     d = os.path.join(_HERE, "csrc")
     inc = os.path.join(os.path.dirname(_HERE), "include", "spf_hip.h")
-    return [os.path.join(d, f) for f in os.listdir(d)] + [inc]
+    return [p for p in (os.path.join(d, f) for f in os.listdir(d)) if os.path.isfile(p)] + [inc]
 
 
 def is_stale() -> bool:

@@ -420,8 +420,11 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
 // XP: which transforms keep exchange 2 in registers (registers c <-> lane bits 5..3 = b; the lanes are
 // (b, k1) before and (c, k1) after: exactly `lane_transpose_hi3`) instead of sending it through the
 // image: 0 none, 1 both, 2 only B (balances the LDS store path against the VALU).
-template <int DIR, int XP = 0>
-__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
+struct no_hook { __device__ __forceinline__ void operator()() const {} };
+// `mid` is called once, half-way through the pair (behind pass 2 of A): a hook for the issue-priority schedule of the
+// callers, which swap the roles of the two waves of a SIMD in the middle of a long barrier-to-barrier stretch
+template <int DIR, int XP = 0, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
 {
     constexpr bool XA = XP == 1, XB = XP == 1 || XP == 2;
     const int hi3 = lane >> 3, lo3 = lane & 7;
@@ -453,6 +456,7 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
 #pragma unroll
     for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
     sched_fence();
+    mid();
 #pragma unroll
     for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
     sched_fence();

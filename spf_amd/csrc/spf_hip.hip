@@ -75,11 +75,11 @@ struct spf_ctx {
     hipStream_t stream = nullptr;  // stream of the host-pointer entry points
     uint64_t buf_epoch = 0;            // bumped whenever a scratch buffer is reallocated (captured gate graphs hold their addresses)
     const char* last_pbs_kernel = "";  // name of the blind-rotation kernel the last launch used
+    const char* last_cmux_kernel = ""; // ... and of the CMUX kernel
     hipStream_t copy_stream = nullptr; // device-to-host copies of finished slices, under the next slice's kernel
     std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
     bool timing = false;
     std::vector<TimedLaunch> timed[T_COUNT];
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
 
 #include "spf_pool.hpp"
@@ -196,16 +196,25 @@ struct TimedScope {
         if (!c->timing) return SPF_OK;
         spf_status st = get_events(c, &tl.start, &tl.stop);
         if (st != SPF_OK) return st;
-        HIPCHK(c, hipEventRecord(tl.start, s));
         on = true;
+        HIPCHK(c, hipEventRecord(tl.start, s));
         return SPF_OK;
     }
     spf_status end()
     {
         if (!on) return SPF_OK;
-        HIPCHK(c, hipEventRecord(tl.stop, s));
+        on = false;
+        hipError_t e = hipEventRecord(tl.stop, s);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(tl.start); (void)hipEventDestroy(tl.stop);
+            return fail(c, SPF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+        }
         c->timed[which].push_back(tl);
         return SPF_OK;
+    }
+    ~TimedScope() // a launch failed between begin() and end(): the pair goes back instead of leaking
+    {
+        if (on) { (void)hipEventDestroy(tl.start); (void)hipEventDestroy(tl.stop); }
     }
 };
 
@@ -232,11 +241,10 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     const bool pair2 = !quad && B <= 2 * n_cu;
     const size_t per_wg = quad ? 1 : (pair2 ? 2 : 4);
     dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block((quad || pair2) ? 256 : 512);
-    TimedLaunch tl{};
-    if (c->timing) {
-        spf_status st = get_events(c, &tl.start, &tl.stop);
+    TimedScope ts(c, s, T_PBS);
+    {
+        spf_status st = ts.begin();
         if (st != SPF_OK) return st;
-        HIPCHK(c, hipEventRecord(tl.start, s));
     }
 #ifdef SPF_STAMPS
     static uint64_t* d_stamps = nullptr;
@@ -259,9 +267,9 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     else SPF_LAUNCH("blind_rotate2p_kernel<2,16,14,even>", (blind_rotate2p_kernel<2, 16, 14, 0>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(tl.stop, s));
-        c->timed[T_PBS].push_back(tl);
+    {
+        spf_status st = ts.end();
+        if (st != SPF_OK) return st;
     }
 #ifdef SPF_STAMPS
     if (a.stamps) { // diagnostic build: median over waves of the per-phase cycle sums, per CMUX step
@@ -304,7 +312,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
 bool ks_mfma_ok(const spf_params& p)
 {
     const uint64_t K = (uint64_t)p.glwe_size * p.polynomial_degree * p.ks_radix_count;
-    return p.ks_radix_log <= 8 && K % 256 == 0 && K * ((uint64_t)1 << (p.ks_radix_log - 1)) * 128 < ((uint64_t)1 << 31); // K: rounds of 2 x 128 in ks_gemm_kernel
+    return p.ks_radix_log <= 8 && K % 256 == 0 && K * ((uint64_t)1 << (p.ks_radix_log - 1)) * 128 < ((uint64_t)1 << 31);
 }
 
 // (re)build the byte-plane image of the keyswitch key; called whenever the key becomes ready
@@ -335,8 +343,7 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
     a.in = d_in; a.ksk = c->d_ksk; a.out = d_out;
     a.n_in = c->prm.glwe_size * c->prm.polynomial_degree; a.n_out = c->prm.lwe_dimension;
     a.B = (uint32_t)B; a.radix_log = c->prm.ks_radix_log; a.count = c->prm.ks_radix_count;
-    static const bool force_valu = [] { const char* e = getenv("SPF_KEYSWITCH_VALU"); return e && e[0] == '1'; }();
-    const bool mfma = c->d_ksk_planes && !force_valu;
+    const bool mfma = c->d_ksk_planes != nullptr; // (null when the radix does not fit the int8 formulation: keyswitch_kernel)
     const size_t K = (size_t)a.n_in * a.count, mpad = (B + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
     if (mfma) {
         spf_status st = ensure(c, c->ks_dig, mpad * K);
@@ -344,11 +351,10 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
         st = ensure(c, c->ks_rowsum, mpad * sizeof(int));
         if (st != SPF_OK) return st;
     }
-    TimedLaunch tl{};
-    if (c->timing) {
-        spf_status st = get_events(c, &tl.start, &tl.stop);
+    TimedScope ts(c, s, T_KS);
+    {
+        spf_status st = ts.begin();
         if (st != SPF_OK) return st;
-        HIPCHK(c, hipEventRecord(tl.start, s));
     }
     if (mfma) {
         HIPCHK(c, hipMemsetAsync(c->ks_rowsum.p, 0, mpad * sizeof(int), s));
@@ -358,21 +364,13 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
         g.A = (const int8_t*)c->ks_dig.p; g.Bt = c->d_ksk_planes; g.rowsum = (const int*)c->ks_rowsum.p;
         g.in = d_in; g.out = d_out; g.B = a.B; g.n_in = a.n_in; g.n_out = a.n_out; g.K = (uint32_t)K;
         dim3 grid((unsigned)(c->ks_npad / KSG_TILE), (unsigned)(mpad / KSG_TILE));
-        // SPF_KS_GEMM=direct: operands straight from L2 into registers (r01 form, 64-byte pieces); default: tiles
-        // staged through LDS by LDS-DMA
-        static const bool direct = [] { const char* e = getenv("SPF_KS_GEMM"); return e && e[0] == 'd'; }();
-        if (direct) hipLaunchKernelGGL(ks_gemm_kernel, grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL(ks_gemm_lds_kernel, grid, dim3(256), kKsLdsBytes, s, g);
+        hipLaunchKernelGGL(ks_gemm_lds_kernel, grid, dim3(256), kKsLdsBytes, s, g); // operand tiles staged through LDS by LDS-DMA
     } else {
         dim3 grid((a.n_out + 1 + 255) / 256, (unsigned)((B + KS_CT - 1) / KS_CT)), block(256);
         hipLaunchKernelGGL(keyswitch_kernel, grid, block, 0, s, a);
     }
     HIPCHK(c, hipGetLastError());
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(tl.stop, s));
-        c->timed[T_KS].push_back(tl);
-    }
-    return SPF_OK;
+    return ts.end();
 }
 
 bool params_supported(const spf_params& p, std::string& why)
@@ -479,8 +477,6 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 4>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, cmux_lds_bytes(4)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            cmux_lds_bytes(2)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2>),
@@ -587,6 +583,51 @@ spf_status spf_load_keyswitch_key(spf_ctx* c, const uint64_t* ksk, size_t n_word
     spf_status st = build_ks_planes(c);
     if (st != SPF_OK) return st;
     c->ksk_ready = true;
+    return SPF_OK;
+}
+
+// ---------------------------------------------------------------- device buffers for callers without a HIP binding
+// (a Rust shim that chains the `_dev` entry points keeps its ciphertexts in HBM between calls; these four spare it a
+// HIP binding of its own.  Plain hipMalloc / hipMemcpy on the context's device.)
+
+spf_status spf_device_alloc(spf_ctx* c, size_t bytes, void** dev_ptr)
+{
+    if (!c || !dev_ptr) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return SPF_OK;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dev_ptr, bytes));
+    return SPF_OK;
+}
+
+spf_status spf_device_free(spf_ctx* c, void* dev_ptr)
+{
+    if (!c) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null context");
+    if (!dev_ptr) return SPF_OK;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(dev_ptr));
+    return SPF_OK;
+}
+
+spf_status spf_device_upload(spf_ctx* c, void* dev_dst, const void* host_src, size_t bytes)
+{
+    if (!c || (bytes && (!dev_dst || !host_src))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes == 0) return SPF_OK;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return SPF_OK;
+}
+
+spf_status spf_device_download(spf_ctx* c, void* stream, void* host_dst, const void* dev_src, size_t bytes)
+{
+    if (!c || (bytes && (!host_dst || !dev_src))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream)); // what was enqueued on `stream` has written dev_src
+    if (bytes) HIPCHK(c, hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
     return SPF_OK;
 }
 
@@ -805,11 +846,11 @@ spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_
 }
 
 // At most one gate per CU: the four-waves-per-gate latency shape (a level of a gate graph); beyond
-// that two (or four) gates per workgroup, the streaming shape.  SPF_CMUX4=0 keeps the streaming shape.
+// that two gates per workgroup, the streaming shape.
 static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 {
-    static const int quad_mode = [] { const char* e = getenv("SPF_CMUX4"); return e ? e[0] - '0' : 1; }();
-    if (quad_mode == 2 || (quad_mode == 1 && a.B <= (uint32_t)c->n_cu)) {
+    if (a.B <= (uint32_t)c->n_cu) {
+        c->last_cmux_kernel = "cmux4_kernel<4,4>";
 #ifdef SPF_STAMPS
         // diagnostic build: per-phase cycles of the first few cmux4 launches (median over waves)
         static int reported = 0;
@@ -844,12 +885,11 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
     } else {
         // two gates per workgroup, two workgroups per CU: the same eight waves as one workgroup of four gates, but
         // the two halves drift apart, so one half's selector requests fly while the other computes, and a barrier
-        // ties four waves instead of eight (0.329 -> 0.316 ms per 4096 gates; SPF_CMUX_GATES=4 for the old shape)
-        static const int gates = [] { const char* e = getenv("SPF_CMUX_GATES"); return e ? atoi(e) : 2; }();
+        // ties four waves instead of eight (0.329 -> 0.316 ms per 4096 gates against four gates per 512-thread workgroup)
 #ifdef SPF_STAMPS
         // diagnostic build: per-phase cycles of the first few streaming-shape launches (median over waves)
         static int reported_s = 0;
-        if (reported_s < 2 && gates == 2 && a.B >= 1024) {
+        if (reported_s < 2 && a.B >= 1024) {
             const size_t waves = (size_t)((a.B + 1) / 2) * 4;
             uint64_t* d_st = nullptr;
             (void)hipMalloc(&d_st, waves * 16 * 8);
@@ -879,15 +919,18 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
             return;
         }
 #endif
-        // selectors of the launch (one 256 KiB selector per per_ggsw units) that, with the operands, no longer fit the 256 MB
-        // Infinity Cache: streaming loads (measured cross-over between 768 and 1024 gates)
-        const bool stream = !a.ptrs && (size_t)(a.B / (a.per_ggsw ? a.per_ggsw : 1)) * (256u << 10) >= ((size_t)224 << 20);
-        if (gates == 2 && stream)
+        // selectors of the launch (one per `per_ggsw` units, (k+1) l (k+1) N/2 complex each) that, with the operands, no
+        // longer fit the Infinity Cache (256 MB on MI355X; measured cross-over between 768 and 1024 gates of 256 KiB):
+        // streaming loads.  Gate graphs (ptrs) share selectors between gates and keep plain loads.
+        const size_t sel_bytes = ggsw_fft_complex(c->prm, c->prm.cbs_radix_count) * sizeof(c64);
+        const bool stream = !a.ptrs && (size_t)(a.B / (a.per_ggsw ? a.per_ggsw : 1)) * sel_bytes >= ((size_t)224 << 20);
+        if (stream) {
+            c->last_cmux_kernel = "cmux_kernel<4,4,2,stream>";
             hipLaunchKernelGGL((cmux_kernel<4, 4, 2, true>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
-        else if (gates == 2)
+        } else {
+            c->last_cmux_kernel = "cmux_kernel<4,4,2>";
             hipLaunchKernelGGL((cmux_kernel<4, 4, 2>), dim3((a.B + 1) / 2), dim3(256), cmux_lds_bytes(2), s, a);
-        else
-            hipLaunchKernelGGL((cmux_kernel<4, 4, 4>), dim3((a.B + 3) / 4), dim3(512), cmux_lds_bytes(4), s, a);
+        }
     }
 }
 
@@ -1009,15 +1052,13 @@ spf_status spf_keyswitch_lwe_l1_lwe_l0_batch(spf_ctx* c, size_t B, const uint64_
 // k+1.. run.  The output is 32 KiB per ciphertext (134 MB per 4096): in one piece behind the kernel it
 // added 10-15 % to a call, sliced only the last slice's copy is exposed.  (A pageable destination makes
 // hipMemcpyAsync block the host until that copy is done — which is why every kernel is enqueued first.)
-// SPF_HOST_SLICES=0 restores the single copy (A/B).
 static spf_status bootstrap_sliced_to_host(spf_ctx* c, size_t B, const uint64_t* d_lwe, const uint64_t* d_lut,
                                            size_t lut_stride, uint32_t log_chi, uint32_t log_v, uint64_t rot, size_t ow,
                                            bool extract, uint64_t* host_out)
 {
-    static const bool sliced = [] { const char* e = getenv("SPF_HOST_SLICES"); return !(e && e[0] == '0'); }();
     const size_t lw = lwe0_words(c->prm);
     const size_t round = 4 * (size_t)c->n_cu;
-    const size_t slice = (sliced && B > round) ? round : B;
+    const size_t slice = B > round ? round : B;
     const size_t n_slices = (B + slice - 1) / slice;
     while (c->slice_ev.size() < n_slices) {
         hipEvent_t e;
@@ -1542,6 +1583,13 @@ const char* spf_last_blind_rotate_kernel(spf_ctx* c)
     if (!c) return "";
     std::lock_guard<std::recursive_mutex> g(c->mu);
     return c->last_pbs_kernel; // string literals: valid for the life of the library
+}
+
+const char* spf_last_cmux_kernel(spf_ctx* c)
+{
+    if (!c) return "";
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    return c->last_cmux_kernel;
 }
 
 // ---------------------------------------------------------------- call-coalescing pool

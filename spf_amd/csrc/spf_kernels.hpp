@@ -97,6 +97,26 @@ __device__ __forceinline__ void young_prio(uint32_t flag) {
         asm volatile("v_readfirstlane_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lprio%=\n\ts_setprio 0\n.Lprio%=:" : "=&s"(tmp) : "v"(flag) : "scc");
 }
 
+// Issue-priority schedule of blind_rotate2p_body: one character per point of a CMUX step, '-' = leave the priority alone,
+// '0' / '1' = the younger waves (4-7, the SIMD partners of waves 0-3) set that priority.  Points, in program order:
+//    0 top of the step (polynomial 0)      1 p0 staged, before hand-over 1       2 behind hand-over 1, before the gather
+//    3 p0 twisted, before hand-over 2      4 before p0's forward pair            5 behind p0's forward pair
+//    6 behind p0's key barrier             7 behind p0's MADs                    8 behind p0's ring barrier (p1 staging)
+//    9 behind p1's hand-over 1            10 before p1's forward pair           11 behind p1's cross write
+//   12 behind p1's key barrier            13 behind p1's ring barrier           14 behind the inverse cross exchange
+//   15 behind the inverse pair            16 behind the conversion of q = 0     17 / 18 / 19 half-way through p0's forward
+//   pair / p1's forward pair / the inverse pair
+// (hand-overs 1 and 2 exist in the mixing instantiation only).  r03c's schedule, tuned on the even-rotation instantiation:
+// the younger waves lead from 14 to 4 and from 10 to 11.
+#ifndef SPF_PRIO_SCHED_EVEN
+#define SPF_PRIO_SCHED_EVEN "----0-----10--1-----"
+#endif
+#ifndef SPF_PRIO_SCHED_MIX
+#define SPF_PRIO_SCHED_MIX "----0-----10--1-----"
+#endif
+template <int MIX> constexpr char prio_sched_at(int i) { return MIX ? SPF_PRIO_SCHED_MIX[i] : SPF_PRIO_SCHED_EVEN[i]; }
+static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) == 21, "20 schedule points");
+
 // OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
 // transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
@@ -190,6 +210,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             pair_barrier_w();
         } while (opaque_zero != 0);
     };
+#define SPF_PRIO_POINT(i) do { if constexpr (PRIO) { if constexpr (prio_sched_at<MIX>(i) == '1') young_prio<1>(is_young); \
+                                                      else if constexpr (prio_sched_at<MIX>(i) == '0') young_prio<0>(is_young); } } while (0)
     // MIX = 0: every rotation amount is even (log_v >= 1), an even rotation keeps the coefficient parity, a wave gathers
     // only what it staged itself and in-order LDS needs no hand-over for that; the block structure stays the same
     auto rendezvous_if_mixing = [&]() {
@@ -221,11 +243,14 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
         for (int p = 0; p < 2; p++, chunk++) {
             // my region is free: for p = 0 the partner's last reads of it (inverse cross data) were
             // followed by a rendezvous, for p = 1 by the workgroup barrier behind the MADs
+            if (p == 0) SPF_PRIO_POINT(0); else SPF_PRIO_POINT(8);
             stage(p);
+            if (p == 0) SPF_PRIO_POINT(1);
             // With log_v >= 1 (MIX = 0: the modulus switch clears the low log_v bits — the circuit bootstrap uses log_v = 2)
             // the two gather hand-overs of a polynomial are not needed: four of the ten barriers of a step go.
             rendezvous_if_mixing(); // both parities staged
             STAMP(0);
+            if (p == 0) SPF_PRIO_POINT(2); else SPF_PRIO_POINT(9);
             uint32_t dig[16];
             {
                 // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024
@@ -255,17 +280,17 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, tw);
             }
             STAMP(1);
+            if (p == 0) SPF_PRIO_POINT(3);
             rendezvous_if_mixing(); // partner is done gathering from my region
             STAMP(2);
             // the ring is free since the barrier behind the last MADs: bring in polynomial 1's rows (those
             // of polynomial 0 were requested ahead of the previous step's inverse transforms)
-            if constexpr (PRIO) { // (2) polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger
-                if (p == 0) young_prio<0>(is_young);
-                else young_prio<1>(is_young);
-            }
+            // (r03c: polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger)
+            if (p == 0) SPF_PRIO_POINT(4); else SPF_PRIO_POINT(10);
             if (p == 1) ring_dma(chunk);
-            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { if (p == 0) SPF_PRIO_POINT(17); else SPF_PRIO_POINT(18); });
             STAMP(3);
+            if (p == 0) SPF_PRIO_POINT(5);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
             // d < 4 and sends registers 4..7, wave 1 the other way round
             if constexpr (w == 0) {
@@ -279,7 +304,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
                     for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
             }
-            if constexpr (PRIO) { if (p == 1) young_prio<0>(is_young); } // (3)
+            if (p == 1) SPF_PRIO_POINT(11);
 #ifdef SPF_STAMPS
             STAMP(4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,6 +313,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
             __syncthreads();
             STAMP(4);
+            if (p == 0) SPF_PRIO_POINT(6); else SPF_PRIO_POINT(12);
             // X[i] = E[i] + W^k O[i], X[i+4] = E[i] - W^k O[i]: wave 0 holds E and receives O, wave 1 the reverse
             if constexpr (w == 0) {
 #pragma unroll
@@ -343,8 +369,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 }
             }
             STAMP(6);
+            if (p == 0) SPF_PRIO_POINT(7);
             __syncthreads(); // every wave is done with the ring and with its partner's cross data
             STAMP(7);
+            if (p == 1) SPF_PRIO_POINT(13);
         }
 
         // ---- back to the torus, both output polynomials together
@@ -390,7 +418,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's contents are in registers
             STAMP(8);
-            if constexpr (PRIO) young_prio<1>(is_young); // (1) the long stretch starts: the younger waves lead
+            SPF_PRIO_POINT(14); // (r03c: the long stretch starts: the younger waves lead)
             if (chunk < total_chunks) {
                 const char* src = reinterpret_cast<const char*>(a.bsk) +
                                   (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes);
@@ -430,16 +458,19 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
             rendezvous(); // both cross reads retired before either region is overwritten
             STAMP(8);
+            SPF_PRIO_POINT(14);
             if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
-        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
+        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
         STAMP(9);
+        SPF_PRIO_POINT(15);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             uint64_t t[16];
             untwist_to_torus_bits(WW[q], twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[q][e] += t[e];
+            if (q == 0) SPF_PRIO_POINT(16);
         }
         STAMP(10);
     }
@@ -450,6 +481,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
     }
 #endif
 #undef STAMP
+#undef SPF_PRIO_POINT
 
     if (!owns_output) return;
     uint64_t* out = a.out + (size_t)ct * a.out_stride;
@@ -591,7 +623,12 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
 #define SPF_KEY_PIECE(i) request_keys(std::integral_constant<int, i>{})
     SPF_KEY_PIECE(0); SPF_KEY_PIECE(1); SPF_KEY_PIECE(2); SPF_KEY_PIECE(3); SPF_KEY_PIECE(4);
     uint64_t a_next = lwe[0];
-    for (uint32_t step = 0; step < a.n; step++) {
+    // One CMUX step.  LAST = the final step, compiled as its own copy WITHOUT the requests for the next step's rows: until r03
+    // the last step re-requested its own rows (dead loads, drained behind the loop); a load nobody consumes is a write into a
+    // register the allocator considers free, and r03's persistent-CMUX experiment showed how such a kernel goes wrong one
+    // gate in a thousand — so no shipped kernel issues one any more.
+    auto cmux_step = [&](uint32_t step, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
         SPF_KEY_PIECE(5);
@@ -706,11 +743,10 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                     V[r].im = __builtin_fma(k.im, x.re, im);
                 }
         }
-        // the last step re-requests its own rows
-        key_next = key_base + (size_t)(step + 1 < a.n ? step + 1 : step) * (2 * L) * (2 * kHalf);
-        SPF_KEY_PIECE(0);
+        key_next = key_base + (size_t)(step + 1) * (2 * L) * (2 * kHalf);
+        if constexpr (!LAST) SPF_KEY_PIECE(0);
         STAMP4(7);
-        SPF_KEY_PIECE(1);
+        if constexpr (!LAST) SPF_KEY_PIECE(1);
 
         // ---- polynomial h back to the torus
         {
@@ -724,7 +760,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             for (int i = 0; i < 4; i++)
                 reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
             wg_barrier(); // 7
-            SPF_KEY_PIECE(2);
+            if constexpr (!LAST) SPF_KEY_PIECE(2);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
@@ -733,10 +769,10 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             }
         }
         STAMP4(8);
-        SPF_KEY_PIECE(3);
+        if constexpr (!LAST) SPF_KEY_PIECE(3);
         fft512_single<-1, 7>(V, mineB, tab, lane); // image B: the partner may still be reading the cross data in A
         STAMP4(9);
-        SPF_KEY_PIECE(4);
+        if constexpr (!LAST) SPF_KEY_PIECE(4);
         {
             uint64_t t[16];
             untwist_to_torus_bits(V, twist, t);
@@ -745,9 +781,9 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
         }
         STAMP4(10);
         // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
-    }
-    // the last step requested key rows nobody uses (its own again): they have landed before the registers are reused
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    for (uint32_t step = 0; step + 1 < a.n; step++) cmux_step(step, std::false_type{});
+    cmux_step(a.n - 1, std::true_type{});
 
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
@@ -925,11 +961,14 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 #pragma unroll
         for (int r = 0; r < 8; r++) k1[r] = key_load(row + kHalf + 64 * (r & 3) + 512 * (r >> 2));
     }
-#pragma unroll 1
-    for (int m = 0; m < 2 * L; m++) {
+    // One round = one digit transform and its two MAD rows.  The LAST round is compiled as its own copy without the requests
+    // for a next row pair (until r03 it re-requested its own rows — dead loads, waited for behind the loop with the registers
+    // held; a branch around the requests inside ONE copy of the round makes hipcc wait for every row right where it is
+    // requested, 0.31 -> 0.61 ms per 4096): no kernel of the library issues a load nobody consumes.
+    auto round = [&](int m, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const int p = m / L, j = m - p * L, sh = j * LOGB;
-        // the last round re-requests its own row (an L2 hit) rather than branching around the loads
-        const gc64_ptr next = key_row(m + 1 < 2 * L ? m + 1 : m);
+        const gc64_ptr next = key_row(LAST ? m : m + 1);
         c64 V[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) {
@@ -980,8 +1019,10 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             prod[0][r].re = __builtin_fma(-k0[r].im, X[r].im, re);
             prod[0][r].im = __builtin_fma(k0[r].im, X[r].re, im);
         }
+        if constexpr (!LAST) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) k0[r] = key_load(next + 64 * (r & 3) + 512 * (r >> 2));
+            for (int r = 0; r < 8; r++) k0[r] = key_load(next + 64 * (r & 3) + 512 * (r >> 2));
+        }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             double re = __builtin_fma(k1[r].re, X[r].re, prod[1][r].re);
@@ -989,17 +1030,22 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             prod[1][r].re = __builtin_fma(-k1[r].im, X[r].im, re);
             prod[1][r].im = __builtin_fma(k1[r].im, X[r].re, im);
         }
+        if constexpr (!LAST) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) k1[r] = key_load(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+            for (int r = 0; r < 8; r++) k1[r] = key_load(next + kHalf + 64 * (r & 3) + 512 * (r >> 2));
+        }
         STAMPS_(8);
+    };
+#pragma unroll 1
+    for (int m = 0; m < 2 * L - 1; m++) round(m, std::false_type{});
+    {
+        // (the round index goes through an opaque move: as a literal it lets hipcc extract the last round's digits in the
+        // prologue and carry them across the loop — 24 B of scratch, and a kernel of thousands of short workgroups pays
+        // for every byte of scratch it declares)
+        int m_last = 2 * L - 1;
+        asm volatile("" : "+s"(m_last));
+        round(m_last, std::true_type{});
     }
-    // The last round re-requested its own row pair (an L2 hit) rather than branching around the loads (a branch there
-    // makes hipcc wait for every row right where it is requested: 0.31 -> 0.61 ms per 4096).  Those sixteen loads are
-    // dead; they are waited for here with their registers still held, so that nothing the inverse transforms put into
-    // those registers can be overwritten by a row landing late.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 8; r++) asm volatile("" :: "v"(k0[r].re), "v"(k0[r].im), "v"(k1[r].re), "v"(k1[r].im));
 
     // ---- both output polynomials back to the torus as ONE transform pair (`fft512_pair1`: each exchange of one
     // transform travels under a butterfly pass of the other; one cross exchange, three hand-overs instead of five)
@@ -1467,7 +1513,7 @@ struct KsGemmArgs {
     uint32_t B, n_in, n_out, K;
 };
 
-// epilogue shared by the two GEMM kernels
+// epilogue of the GEMM kernel
 __device__ __forceinline__ void ks_gemm_epilogue(const KsGemmArgs& a, const v16i32& acc00, const v16i32& acc01, const v16i32& acc10,
                                                  const v16i32& acc11, uint32_t m0, uint32_t n0, int r, int h)
 {
@@ -1497,57 +1543,13 @@ __device__ __forceinline__ void ks_gemm_epilogue(const KsGemmArgs& a, const v16i
     finish(acc11, m0 + 32, n0 + 32);
 }
 
-__global__ __launch_bounds__(256, 2) void ks_gemm_kernel(KsGemmArgs a)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const size_t K = a.K;
-    const uint32_t m0 = blockIdx.y * KSG_TILE + wm * 64, n0 = blockIdx.x * KSG_TILE + wn * 64;
-    // v_mfma_i32_32x32x32_i8: lane (r, h) supplies 16 k values of A row r and of B column r per instruction; any
-    // assignment of k values to (h, position) that is the same for both operands leaves the dot products
-    // unchanged.  So a lane takes 64 CONTIGUOUS bytes of its row per round of 128 k (k0 + 64 h .. + 64): whole
-    // 128-byte lines per row instead of 32-byte pieces, and the four 16-byte quarters feed four MFMA k-steps.
-    // Rounds are double-buffered in registers: the loads of round i+1 are in flight under the 16 MFMAs of round i.
-    const int8_t* pa = a.A + (size_t)(m0 + r) * K + 64 * h;
-    const int8_t* pb = a.Bt + (size_t)(n0 + r) * K + 64 * h;
-    const size_t row32 = 32 * K;
-    struct Frag { v4i32 a[2][4], b[2][4]; };
-    auto load = [&](Frag& f, size_t k0) {
-#pragma unroll
-        for (int blk = 0; blk < 2; blk++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f.a[blk][q] = *reinterpret_cast<const v4i32*>(pa + blk * row32 + k0 + 16 * q);
-                f.b[blk][q] = *reinterpret_cast<const v4i32*>(pb + blk * row32 + k0 + 16 * q);
-            }
-    };
-    v16i32 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    auto mac = [&](const Frag& f) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0][q], f.b[0][q], acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0][q], f.b[1][q], acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1][q], f.b[0][q], acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1][q], f.b[1][q], acc11, 0, 0, 0);
-        }
-    };
-    Frag f0, f1;
-    load(f0, 0);
-    for (size_t k0 = 0; k0 < K; k0 += 256) { // K is a multiple of 256 (host check)
-        load(f1, k0 + 128);
-        mac(f0);
-        if (k0 + 256 < K) load(f0, k0 + 256);
-        mac(f1);
-    }
-    ks_gemm_epilogue(a, acc00, acc01, acc10, acc11, m0, n0, r, h);
-}
-
-// ks_gemm_lds_kernel: the same block-GEMM with the operand tiles staged through LDS.  A workgroup (4 waves, 128 x 128
+// ks_gemm_lds_kernel: the block-GEMM with the operand tiles staged through LDS.  v_mfma_i32_32x32x32_i8: lane (r, h) supplies
+// 16 k values of A row r and of B column r per instruction; any assignment of k values to (h, position) that is the same for
+// both operands leaves the dot products unchanged.  A workgroup (4 waves, 128 x 128
 // tile, 64 x 64 per wave) brings each 128-row x 128-byte slab of A and of Bt into LDS ONCE per round (LDS-DMA, 1 KiB
 // per wave-instruction, double-buffered: the slabs of round i+1 land under the 16 MFMAs per wave of round i) instead
-// of every wave fetching its own rows from L2: half the vector-memory traffic, which is what bounds the direct form
-// (64 B/clk/CU against 128 B/clk needed at full MFMA rate).  Image: 16-byte slot of (row, chunk) =
+// of every wave fetching its own rows from L2 (r01's direct form, 0.886 against 0.337 ms per 4096, removed in r04): half the
+// vector-memory traffic, which is what bounded that form (64 B/clk/CU against 128 B/clk needed at full MFMA rate).  Image: 16-byte slot of (row, chunk) =
 // 8 row + (chunk ^ ((row >> 1) & 7)) — the DMA writes slots linearly and chooses WHICH chunk each lane fetches, the
 // reads of a 16-lane ds_read_b128 group (16 rows, one chunk) hit 16 distinct slots mod 16: conflict-free.
 // Two workgroups per CU (64 KiB of LDS each).

@@ -55,8 +55,19 @@ def main():
     lwe128 = O.encrypt_bits_l0(0x5EED0200, k128, [0, 1, 1])
     lwe128[2] = rng.integers(0, 1 << 64, P128.lwe_n + 1, dtype=np.uint64)   # and one arbitrary word vector
     out128 = np.stack([O.cbs_pbs(x, k128.bsk_fft, P128) for x in lwe128])
+    #    plus the plain PBS (log_chi = 0, log_v = 0: the other instantiation of every blind-rotation kernel): the
+    #    negacyclic identity LUT of one plaintext bit + padding (generate_lut, programmable_bootstrapping.rs:129-185)
+    #    as GLWE out and through sample_extract(., 0) (programmable_bootstrap_univariate, :291-318)
+    plain_lut = O.trivial_lut_glwe(O.generate_lut(P128.N, [lambda x: x], 1), P128)
+    #    inputs: the bits 0, 1 with a padding bit (message at 2^62, as the reference's PBS tests encode them) and the
+    #    arbitrary word vector again
+    plain_lwe = np.stack([O.encrypt_lwe(O.Rng(0x5EED0300 + b), k128.lwe_sk, O.encode(b, 2), P128.lwe_std) for b in (0, 1)]
+                         + [lwe128[2]])
+    gen128 = np.stack([O.generalized_pbs(x, plain_lut, k128.bsk_fft, P128, 0, 0) for x in plain_lwe])
+    uni128 = np.stack([O.pbs_univariate(x, plain_lut, k128.bsk_fft, P128) for x in plain_lwe])
     np.savez_compressed(os.path.join(HERE, "pbs_default128.npz"), key_seed=np.uint64(0x5EED0001),
-                        lwe_n=np.uint32(P128.lwe_n), lwe=lwe128, cbs_out=out128,
+                        lwe_n=np.uint32(P128.lwe_n), lwe=lwe128, cbs_out=out128, plain_lut=plain_lut, plain_lwe=plain_lwe,
+                        gen_out_chi0_v0=gen128, univariate_out=uni128,
                         bsk_checksum=k128.bsk_fft.view(np.uint64).sum(dtype=np.uint64))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

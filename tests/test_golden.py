@@ -49,6 +49,13 @@ def test_oracle_reproduces_default128_fixture(golden_dir):
     assert int(ks.bsk_fft.view(np.uint64).sum(dtype=np.uint64)) == int(z["bsk_checksum"])
     for i, x in enumerate(z["lwe"]):
         assert np.array_equal(O.cbs_pbs(x, ks.bsk_fft, ks.params), z["cbs_out"][i])
+    for i, x in enumerate(z["plain_lwe"]):
+        assert np.array_equal(O.generalized_pbs(x, z["plain_lut"], ks.bsk_fft, ks.params, 0, 0), z["gen_out_chi0_v0"][i])
+        assert np.array_equal(O.pbs_univariate(x, z["plain_lut"], ks.bsk_fft, ks.params), z["univariate_out"][i])
+    # the identity LUT of one plaintext bit: the two valid encryptions (input with a padding bit, output decoded
+    # without, as programmable_bootstrapping.rs' bootstrap_helper does) bootstrap to their own bit
+    for i, bit in enumerate((0, 1)):
+        assert O.decode(O.decrypt_lwe_raw(z["univariate_out"][i], ks.glwe_sk), 1) == bit
 
 
 @pytest.mark.gpu

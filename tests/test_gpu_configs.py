@@ -18,7 +18,7 @@ import pytest
 
 import oracle as O
 import spf_amd
-from tests.util import M64, keyset, random_glwe, random_lwe_batch, to_engine_params
+from tests.util import M64, dev_bootstrap, keyset, random_glwe, random_lwe_batch, to_engine_params
 
 pytestmark = pytest.mark.gpu
 
@@ -46,14 +46,17 @@ def test_config2_batch_4096_pbs_default128_every_ciphertext(full):
 
 
 def test_config2_ragged_batch_1031_default128(full):
-    """Ragged last workgroup (1031 = 257 workgroups of four + 3) at n = 637: first / last ciphertext of
-    a workgroup and the tail against the oracle."""
+    """Ragged last workgroup (1031 = 257 workgroups of four + 3) at n = 637, as ONE launch through the device-pointer
+    entry point (the host-pointer form would cut it into 1024 + 7): first / last ciphertext of a workgroup and the tail
+    against the oracle."""
     ks, eng = full
     B = 1031
     lwe = random_lwe_batch(0xC0F3, B, 637)
-    got = eng.circuit_bootstrap_pbs(lwe)
+    got = dev_bootstrap(eng, lwe)
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,14,even>"
     for i in (0, 3, 4, 515, 1023, 1027, 1028, 1029, 1030):
         assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params)), i
+    assert np.array_equal(got, eng.circuit_bootstrap_pbs(lwe))   # the sliced host-pointer form: same words
 
 
 def test_config2_keyswitch_4096_default128(full):
@@ -105,6 +108,82 @@ def test_streaming_cmux_large_launch_uses_streaming_loads_and_same_words(full):
     assert np.array_equal(whole, halves)
     for i in (0, 511, 512, 1023):
         assert np.array_equal(whole[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+
+
+# ---- the plain / univariate PBS (log_v = 0) at config-2 size.  `programmable_bootstrap_univariate`
+# (programmable_bootstrapping.rs:291-318) is the unit of the reference's own bench (sunscreen_tfhe/benches/ops.rs:86-123);
+# with log_v = 0 the rotation amounts are odd as often as even, so the dispatch takes the OTHER instantiation of every
+# blind-rotation kernel (the one that keeps the hand-overs around the rotation gather): it gets the same evidence as the
+# circuit-bootstrap variant above.
+
+
+@pytest.fixture(scope="module")
+def plain_pbs_4096(full):
+    """4096 LWE words vectors, one shared random LUT, the oracle's GLWE outputs for (log_chi, log_v) = (0, 0)."""
+    ks, _ = full
+    lwe = random_lwe_batch(0xC0FA, 4096, 637)
+    lut = random_glwe(0xC0FB, 1, ks.params.glwe_len)[0]
+    _, exp = O.bench_generalized_pbs(lwe, lut, ks.bsk_fft, ks.params, HOST_THREADS, 0, 0)
+    return lwe, lut, exp
+
+
+def test_config2_batch_4096_generalized_pbs_log_v0_every_ciphertext(full, plain_pbs_4096):
+    """generalized_programmable_bootstrap(log_chi = 0, log_v = 0) at B = 4096, n = 637 through the throughput shape
+    (`blind_rotate2p_kernel<2,16,14>`, nine barriers a step): all 4096 GLWE outputs against the oracle."""
+    ks, eng = full
+    lwe, lut, exp = plain_pbs_4096
+    got = eng.generalized_pbs(lwe, lut, 0, 0, 0)
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,14>"
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} ciphertexts differ, first {bad[:8]}"
+
+
+def test_config2_batch_4096_pbs_univariate_every_ciphertext(full, plain_pbs_4096):
+    """programmable_bootstrap_univariate at B = 4096, n = 637 (fused sample_extract(., 0) epilogue): all 4096 LWE outputs
+    against sample_extract of the oracle's GLWE (glwe_ciphertext_ops.rs:31-76), and a sample against the oracle's own
+    univariate entry point."""
+    ks, eng = full
+    P = ks.params
+    lwe, lut, exp_glwe = plain_pbs_4096
+    got = eng.pbs_univariate(lwe, lut)
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,14>"
+    exp = np.stack([O.sample_extract(g, 0, P.N, P.k) for g in exp_glwe])
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} ciphertexts differ, first {bad[:8]}"
+    for i in (0, 4095):
+        assert np.array_equal(got[i], O.pbs_univariate(lwe[i], lut, ks.bsk_fft, P)), i
+
+
+def test_config2_plain_pbs_512_and_ragged_1031(full, plain_pbs_4096):
+    """The same ciphertexts through the two-ciphertexts-per-workgroup shape (B = 512: `blind_rotate2p2_kernel<2,16,14>`,
+    every output against the oracle), the four-wave latency shape (B = 200) and a ragged throughput launch (B = 1031 =
+    257 workgroups of four + 3)."""
+    ks, eng = full
+    lwe, lut, exp = plain_pbs_4096
+    got = eng.generalized_pbs(lwe[:512], lut, 0, 0, 0)
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p2_kernel<2,16,14>"
+    assert np.array_equal(got, exp[:512])
+    got = eng.generalized_pbs(lwe[3000:3200], lut, 0, 0, 0)
+    assert eng.last_blind_rotate_kernel() == "blind_rotate4_kernel<2,16>"
+    assert np.array_equal(got, exp[3000:3200])
+    got = dev_bootstrap(eng, lwe[1000:2031], lut, 0, 0, 0)        # one launch: 257 workgroups of four + 3
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,14>"
+    assert np.array_equal(got, exp[1000:2031])
+    u = dev_bootstrap(eng, lwe[1000:2031], lut, extract=True)
+    P = ks.params
+    assert np.array_equal(u, np.stack([O.sample_extract(g, 0, P.N, P.k) for g in exp[1000:2031]]))
+    got = dev_bootstrap(eng, lwe[:4096], lut, 0, 0, 0)            # and the whole batch as one 1024-workgroup launch
+    assert np.array_equal(got, exp)
+
+
+def test_golden_default128_fixture_plain_pbs(golden_dir):
+    """The log_v = 0 entries of the DEFAULT_128 fixture: generalized PBS (GLWE out) and univariate PBS (LWE out)."""
+    z = np.load(os.path.join(golden_dir, "pbs_default128.npz"))
+    ks = keyset(int(z["key_seed"]), int(z["lwe_n"]))
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    assert np.array_equal(eng.generalized_pbs(z["plain_lwe"], z["plain_lut"], 0, 0, 0), z["gen_out_chi0_v0"])
+    assert np.array_equal(eng.pbs_univariate(z["plain_lwe"], z["plain_lut"]), z["univariate_out"])
 
 
 def _torus_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:

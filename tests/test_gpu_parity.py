@@ -5,7 +5,7 @@ import pytest
 
 import oracle as O
 import spf_amd
-from tests.util import M64, keyset, random_glwe, random_lwe_batch, to_engine_params
+from tests.util import M64, dev_bootstrap, keyset, random_glwe, random_lwe_batch, to_engine_params
 
 pytestmark = pytest.mark.gpu
 
@@ -111,6 +111,103 @@ def test_saturating_cast_quirk_is_reproduced():
     eng.load_bootstrap_key(bsk)
     got = eng.generalized_pbs(lwe, lut)
     assert np.array_equal(got[0], exp)
+
+
+# ---- the same edge vectors through EVERY blind-rotation body.  The two tests above run B = 4 / B = 1, i.e. the four-wave
+# latency kernel only; the throughput bodies (`blind_rotate2p_body`, four or two ciphertexts per workgroup, each in an
+# even-rotation and a mixing instantiation) have their own conversion fast path / fallback (`torus_bits16`), their own
+# gather hand-overs and their own ragged tail.  One launch per batch (device-pointer entry points).
+
+EDGE_BATCHES = [1030, 600, 400, 100]   # 2p ragged, 2p, 2p2, four-wave
+EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,14", 600: "blind_rotate2p_kernel<2,16,14",
+               400: "blind_rotate2p2_kernel<2,16,14", 100: "blind_rotate4_kernel<2,16"}
+
+
+def _edge_lwe(B, n):
+    """random words with the special vectors of test_identity_steps_and_extreme_words spread through the batch (so every
+    workgroup slot, both SIMD partners and the ragged tail see them)"""
+    lwe = random_lwe_batch(0xED6E + B, B, n)
+    for i in range(0, B, 5):
+        kind = (i // 5) % 4
+        if kind == 0:
+            lwe[i, :] = 0                     # every a~_i = 0: 20 identity steps
+        elif kind == 1:
+            lwe[i, :] = M64
+        elif kind == 2:
+            lwe[i, :] = 0
+            lwe[i, ::2] = 1 << 63             # a~ = N: pure negations
+        else:
+            lwe[i, 3:9] = 0                   # identity steps between ordinary ones
+    return lwe
+
+
+@pytest.mark.parametrize("B", EDGE_BATCHES)
+def test_identity_steps_and_extreme_words_every_shape(small, B):
+    ks, eng = small
+    P = ks.params
+    lwe = _edge_lwe(B, SMALL_N)
+    # even rotations (log_v = 2, the circuit bootstrap) ...
+    got = dev_bootstrap(eng, lwe)
+    assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + ",even>"
+    rot = lwe.copy()
+    rot[:, -1] += np.uint64(1 << 62)
+    _, exp = O.bench_generalized_pbs(rot, O.fill_cbs_lut(P), ks.bsk_fft, P, 8, 0, 2)
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"even: {bad.size} ciphertexts differ, first {bad[:8]}"
+    # ... and mixing ones (log_v = 0, the plain PBS), with a LUT per ciphertext
+    luts = random_glwe(0xED6F, B, P.glwe_len)
+    got = dev_bootstrap(eng, lwe, luts, 0, 0, 0)
+    assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + ">"
+    _, exp = O.bench_generalized_pbs(lwe, luts, ks.bsk_fft, P, 8, 0, 0)
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"mixing: {bad.size} ciphertexts differ, first {bad[:8]}"
+    u = dev_bootstrap(eng, lwe, luts, extract=True)
+    assert np.array_equal(u, np.stack([O.sample_extract(g, 0, P.N, P.k) for g in exp]))
+
+
+def _const_key_engine(value):
+    """n = 1; the only non-zero key polynomial (row b, level 0 <-> top digit, output polynomial b) is the constant
+    `value`: the external product is then top_digit(diff_b) * value, coefficient by coefficient"""
+    P = O.DEFAULT_128.replace(lwe_n=1)
+    bsk = np.zeros((1, 2, 2, 2, P.N // 2), dtype=np.complex128)   # [i][row][level][poly][bin]
+    const = np.zeros(P.N, dtype=np.uint64)
+    const[0] = value
+    bsk[0, 1, 0, 1, :] = O.poly_fft(const)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(bsk)
+    return P, bsk, eng
+
+
+@pytest.mark.parametrize("B", EDGE_BATCHES)
+@pytest.mark.parametrize("key_const,label", [(1 << 48, "below 2^64: literal fallback"),
+                                             (3 << 48, "1.5 x 2^64: the quirk inside the fast path's range"),
+                                             (1 << 10, "below 2^52: real rounding in the fallback")])
+def test_saturating_cast_quirk_every_shape(B, key_const, label):
+    """`vector_mod_pow2_q_f64` + `as i64` turn an inverse-transform value v < 0 with v = 2^63 mod 2^64 into 0x7FFF...F
+    (simd/scalar.rs:85-118, math/torus.rs:177-192).  LUT body = 2^62 everywhere and a~ = N make diff = 0x8000..0, top
+    digit -2^15; times a constant key polynomial c the product is -2^15 c in every coefficient:
+      c = 2^48      -2^63: below 2^64, every wave leaves `torus_bits16`'s fast path through its exponent test;
+      c = 3 * 2^48  -3 * 2^63 = 2^63 mod 2^64 with |v| >= 2^64: inside the fast path's range, only its quirk test saves it;
+      c = 2^10      -2^25: far below 2^52, the literal sequence has to ROUND the transform's noise away.
+    Every third ciphertext is such a vector, the others are random words with their own random LUT (products of every
+    magnitude up to 2^15 c)."""
+    P, bsk, eng = _const_key_engine(key_const)
+    lwe = random_lwe_batch(0x5A7 + B, B, 1)
+    luts = random_glwe(0x5A8 + B, B, P.glwe_len)
+    lwe[::3] = np.array([1 << 63, 0], dtype=np.uint64)
+    luts[::3, :P.N] = 0
+    luts[::3, P.N:] = 1 << 62
+    _, exp = O.bench_generalized_pbs(lwe, luts, bsk, P, 8, 0, 0)
+    if key_const != 1 << 10:
+        delta = (exp[0, P.N:].astype(object) - (1 << 62)) % (1 << 64)
+        assert sum(1 for v in delta if v == (1 << 63) - 1) > 0, "test vector no longer hits the quirk"
+    for log_v in (0, 1):   # the mixing and the even-rotation instantiation (a~ = N is even)
+        if log_v:
+            _, exp = O.bench_generalized_pbs(lwe, luts, bsk, P, 8, 0, log_v)
+        got = dev_bootstrap(eng, lwe, luts, 0, log_v, 0)
+        assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + (",even>" if log_v else ">")
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, f"{label}, log_v {log_v}: {bad.size} ciphertexts differ, first {bad[:8]}"
 
 
 @pytest.mark.parametrize("B", [1, 5, 33])

@@ -38,3 +38,41 @@ def gpu_available() -> bool:
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def dev_bootstrap(eng, lwe, lut=None, log_chi=0, log_v=0, body_rotate=0, extract=False):
+    """ONE launch of the whole batch through the device-pointer entry points (the host-pointer forms cut a batch into
+    slices of one chip round, 4 x #CU ciphertexts, so a ragged last workgroup of the throughput shape never forms there).
+    lut None: spf_circuit_bootstrap_pbs_dev; extract: spf_pbs_univariate_dev; else spf_generalized_pbs_dev.
+    Device buffers through the library's own spf_device_* helpers, default stream."""
+    P = eng.params
+    lwe = np.ascontiguousarray(lwe, dtype=np.uint64)
+    B = lwe.shape[0]
+    out = np.empty((B, P.lwe1_words if extract else P.glwe_words), dtype=np.uint64)
+    bufs = []
+
+    def up(a):
+        p = eng.device_alloc(a.nbytes)
+        bufs.append(p)
+        eng.device_upload(p, a)
+        return p
+
+    try:
+        d_lwe = up(lwe)
+        d_out = eng.device_alloc(out.nbytes)
+        bufs.append(d_out)
+        if lut is None:
+            eng.circuit_bootstrap_pbs_dev(None, B, d_lwe, d_out)
+        else:
+            lut = np.ascontiguousarray(lut, dtype=np.uint64)
+            stride = 0 if lut.ndim == 1 else P.glwe_words
+            d_lut = up(lut)
+            if extract:
+                eng.pbs_univariate_dev(None, B, d_lwe, d_lut, stride, d_out)
+            else:
+                eng.generalized_pbs_dev(None, B, d_lwe, d_lut, stride, log_chi, log_v, body_rotate, d_out)
+        eng.device_download(None, out, d_out)
+    finally:
+        for p in bufs:
+            eng.device_free(p)
+    return out

@@ -6,16 +6,20 @@ TAG=$1; shift
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras --no-live-counters ${BENCH_EXTRA:-}"
 export KFILTER=${KFILTER:-blind_rotate}
+LOG=gpurun_out/cnt_$TAG.log
+: > $LOG
 for V in "$@"; do
   N=$(echo "$V" | tr -c 'A-Za-z0-9\n' '_')
   OUT=$PWD/gpurun_out/cnt_${TAG}_$N
   mkdir -p $OUT
-  export $V
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || exit 1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1 || exit 1
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || exit 1
-  unset ${V%%=*}
-  python3 - "$OUT" "$V" <<'PY'
+  # a variant may set several variables ("A=1 B=2"): all of them are exported for its passes and ALL are unset afterwards
+  # (rocprofv3 stays the launched program and python3 the program behind `--`: no env / shell hop under the profiler)
+  for KV in $V; do export "$KV"; done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "$V: rocprofv3 pass failed" >> $LOG; exit 1; }
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1 || { echo "$V: rocprofv3 pass failed" >> $LOG; exit 1; }
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || { echo "$V: rocprofv3 pass failed" >> $LOG; exit 1; }
+  for KV in $V; do unset "${KV%%=*}"; done
+  python3 - "$OUT" "$V" >> $LOG <<'PY'
 import csv, glob, os, sys, collections
 out, v = sys.argv[1], sys.argv[2]
 ms = None
@@ -34,4 +38,6 @@ print(f"{v} | {name} | {ms:.3f} ms | INSTS_VALU {c['SQ_INSTS_VALU']:.4g} | INSTS
       f"WAIT_INST_LDS {c['SQ_WAIT_INST_LDS']:.4g} | WAIT_ANY/WAVE_CYCLES {c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.3f} | WAIT_INST_ANY/WAVE_CYCLES {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f} | "
       f"BANK_CONFLICT {c['SQ_LDS_BANK_CONFLICT']:.3g}")
 PY
-done | tee gpurun_out/cnt_$TAG.log
+  [ $? -eq 0 ] || { echo "summary of $V failed" >> $LOG; exit 1; }
+done
+cat $LOG

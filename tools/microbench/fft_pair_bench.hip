@@ -1,0 +1,347 @@
+// fft_pair_bench.hip — what a transform pair costs on one CU, in isolation (r04).
+//
+// The blind rotation spends ~60 % of a step in `fft512_pair1` (three pairs per CMUX step), at about half the rate its
+// own VALU work would allow.  This microbenchmark runs the SAME device code (spf_device.hpp) in a loop, 8 waves per
+// 512-thread workgroup, one workgroup per CU, with the register pressure of the real kernel emulated by a live
+// accumulator / product set, and reports cycles per pair per wave for a list of variants:
+//   0  fft512_pair1<+1, 2>            the shipped schedule (exchange 2 of the second transform in registers)
+//   1  fft512_pair1<+1, 0>            every exchange through LDS
+//   2  fft512_pair1<+1, 1>            exchange 2 of both transforms in registers
+//   3  arithmetic only                the butterflies and twiddles, no exchange at all (wrong results: VALU floor)
+//   4  exchanges only                 the LDS traffic of variant 0, no butterflies (LDS floor)
+//   5  fft512_pair1s<+1, 2>           variant 0 with the stores of one transform spread through the other's butterflies
+// and the same with a workgroup barrier after every pair (SYNC = 1: the lockstep the ring imposes on the real kernel).
+// Build:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/microbench/bin/fft_pair_bench tools/microbench/fft_pair_bench.hip
+// Run:    tools/microbench/bin/fft_pair_bench [iters]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "../../spf_amd/csrc/spf_device.hpp"
+
+using namespace spf;
+
+#define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// the butterflies and twiddles of a pair without any exchange (registers keep stale data between passes)
+template <int DIR>
+__device__ __forceinline__ void pair_arith_only(c64 (&A)[8], c64 (&B)[8], const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3;
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    sched_fence();
+    radix8<DIR>(A);
+#pragma unroll
+    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+    radix8<DIR>(A);
+    radix8<DIR>(B);
+    sched_fence();
+}
+
+// the LDS traffic of fft512_pair1<., 2> without the butterflies
+__device__ __forceinline__ void pair_lds_only(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    c64 tw[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 7; k++) tw[k] = cadd(tw[k], tab[kT2Off + k * 8 + hi3]);
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+#pragma unroll
+    for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+    sched_fence();
+#pragma unroll
+    for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+    sched_fence();
+    A[0] = cadd(A[0], tw[0]); A[1] = cadd(A[1], tw[1]); A[2] = cadd(A[2], tw[2]); A[3] = cadd(A[3], tw[3]);
+    A[4] = cadd(A[4], tw[4]); A[5] = cadd(A[5], tw[5]); A[6] = cadd(A[6], tw[6]);
+}
+
+// variant 5: fft512_pair1<DIR, 2> with every burst of eight stores / eight reads of one transform spread through the
+// radix-8 of the other one (two LDS instructions per butterfly stage / twiddle group) instead of sitting between them
+template <int DIR> __device__ __forceinline__ void radix8_stage1(c64 (&v)[8], c64 (&s)[4], c64 (&t)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = cadd(v[i], v[i + 4]); t[i] = csub(v[i], v[i + 4]); }
+}
+template <int DIR> __device__ __forceinline__ void radix8_stage2(c64 (&v)[8], const c64 (&s)[4], const c64 (&t)[4], c64 (&u)[8])
+{
+    c64 t1w, t3w;
+    if (DIR > 0) {
+        double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;
+        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
+        double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
+        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
+    } else {
+        double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;
+        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
+        double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;
+        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
+    }
+    u[0] = cadd(s[0], s[2]); u[1] = cadd(s[1], s[3]); u[2] = csub(s[0], s[2]); u[3] = csub(s[1], s[3]);
+    if (DIR > 0) {
+        u[4] = {t[0].re + t[2].im, t[0].im - t[2].re};
+        u[5] = {t[0].re - t[2].im, t[0].im + t[2].re};
+    } else {
+        u[4] = {t[0].re - t[2].im, t[0].im + t[2].re};
+        u[5] = {t[0].re + t[2].im, t[0].im - t[2].re};
+    }
+    u[6] = cadd(t1w, t3w); u[7] = csub(t1w, t3w);
+}
+template <int DIR> __device__ __forceinline__ void radix8_stage3(c64 (&v)[8], const c64 (&u)[8])
+{
+    v[0] = cadd(u[0], u[1]);
+    v[4] = csub(u[0], u[1]);
+    if (DIR > 0) {
+        v[2] = {u[2].re + u[3].im, u[2].im - u[3].re};
+        v[6] = {u[2].re - u[3].im, u[2].im + u[3].re};
+    } else {
+        v[2] = {u[2].re - u[3].im, u[2].im + u[3].re};
+        v[6] = {u[2].re + u[3].im, u[2].im - u[3].re};
+    }
+    v[1] = cadd(u[4], u[6]);
+    v[5] = csub(u[4], u[6]);
+    if (DIR > 0) {
+        v[3] = {u[5].re + u[7].im, u[5].im - u[7].re};
+        v[7] = {u[5].re - u[7].im, u[5].im + u[7].re};
+    } else {
+        v[3] = {u[5].re - u[7].im, u[5].im + u[7].re};
+        v[7] = {u[5].re + u[7].im, u[5].im - u[7].re};
+    }
+}
+// radix-8 of X (+ its seven twiddles from `tw_base[stride * k]`) with the eight LDS operations `op(0..7)` spread through it
+template <int DIR, bool TW, class OP>
+__device__ __forceinline__ void radix8_spread(c64 (&X)[8], const c64* tw_base, int stride, OP op)
+{
+    c64 s[4], t[4], u[8];
+    radix8_stage1<DIR>(X, s, t);
+    sched_fence();
+    op(0); op(1);
+    sched_fence();
+    radix8_stage2<DIR>(X, s, t, u);
+    sched_fence();
+    op(2); op(3);
+    sched_fence();
+    radix8_stage3<DIR>(X, u);
+    sched_fence();
+    op(4); op(5);
+    sched_fence();
+    if constexpr (TW) {
+#pragma unroll
+        for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
+        sched_fence();
+        op(6); op(7);
+        sched_fence();
+#pragma unroll
+        for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
+    } else {
+        op(6); op(7);
+    }
+    sched_fence();
+}
+template <int DIR>
+__device__ __forceinline__ void fft512_pair1s(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    const c64* t1 = tab + kT1Off + lane;
+    const c64* t2 = tab + kT2Off + hi3;
+    // pass 1 of A
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], t1[64 * (k1 - 1)]);
+    sched_fence();
+    // pass 1 of B with A's exchange-1 stores spread through it
+    radix8_spread<DIR, true>(B, t1, 64, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
+    // A's exchange-1 reads, then B's exchange-1 stores spread through pass 2 of A ... but A's pass 2 needs the reads: so the
+    // reads go first (they travel under the stores' issue), the stores are spread through A's pass 2
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    radix8_spread<DIR, true>(A, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = B[k]; });
+    // B's exchange-1 reads; A's exchange-2 stores spread through pass 2 of B
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    radix8_spread<DIR, true>(B, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
+#pragma unroll
+    for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+    sched_fence();
+    lane_transpose_hi3(B);
+    radix8<DIR>(A);
+    radix8<DIR>(B);
+    sched_fence();
+}
+
+template <int V, int SYNC>
+__global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned long long* out, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64* tab = reinterpret_cast<c64*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* buf = smem + kTableBytes + wv * 8192;
+    for (int i = tid; i < kTableEntries; i += 512) tab[i] = tables[i];
+    c64 A[8], B[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        A[r] = {(double)((lane * 8 + r) * 2654435761u % 65536) - 32768.0, (double)((lane * 8 + r + 7) * 40503u % 65536) - 32768.0};
+        B[r] = {(double)((lane * 8 + r + wv) * 2246822519u % 65536) - 32768.0, (double)((lane * 8 + r + 3) * 3266489917u % 65536) - 32768.0};
+    }
+    // live state of the real kernel: 64 registers of accumulator, 64 of frequency-domain product
+    unsigned long long acc[32];
+    c64 prod[16];
+#pragma unroll
+    for (int e = 0; e < 32; e++) acc[e] = (unsigned long long)(tid * 32 + e);
+#pragma unroll
+    for (int e = 0; e < 16; e++) prod[e] = {1.0 + e, 2.0 + lane};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if constexpr (V == 0) fft512_pair1<+1, 2>(A, B, buf, tab, lane);
+        else if constexpr (V == 1) fft512_pair1<+1, 0>(A, B, buf, tab, lane);
+        else if constexpr (V == 2) fft512_pair1<+1, 1>(A, B, buf, tab, lane);
+        else if constexpr (V == 3) pair_arith_only<+1>(A, B, tab, lane);
+        else if constexpr (V == 4) pair_lds_only(A, B, buf, tab, lane);
+        else fft512_pair1s<+1>(A, B, buf, tab, lane);
+        // keep magnitudes bounded (exact power-of-two scaling) and the emulated state live
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            A[r] = {A[r].re * 0x1p-9, A[r].im * 0x1p-9};
+            B[r] = {B[r].re * 0x1p-9, B[r].im * 0x1p-9};
+        }
+        if ((it & 15) == 15) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                acc[e] += (unsigned long long)__double_as_longlong(A[e & 7].re);
+                acc[16 + e] ^= (unsigned long long)__double_as_longlong(B[e & 7].im);
+                prod[e].re = __builtin_fma(prod[e].re, 0.5, A[e & 7].im);
+                prod[e].im = __builtin_fma(prod[e].im, 0.5, B[e & 7].re);
+            }
+        }
+        if constexpr (SYNC) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long h = 0;
+#pragma unroll
+    for (int e = 0; e < 32; e++) h = h * 1099511628211ull + acc[e];
+#pragma unroll
+    for (int e = 0; e < 16; e++) h = h * 1099511628211ull + (unsigned long long)__double_as_longlong(prod[e].re) + (unsigned long long)__double_as_longlong(prod[e].im);
+#pragma unroll
+    for (int r = 0; r < 8; r++) h = h * 1099511628211ull + (unsigned long long)__double_as_longlong(A[r].re) + (unsigned long long)__double_as_longlong(B[r].im);
+    // wave-level xor of the lanes' hashes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
+    if (lane == 0) {
+        out[((size_t)blockIdx.x * 8 + wv) * 2] = t1 - t0;
+        out[((size_t)blockIdx.x * 8 + wv) * 2 + 1] = h;
+    }
+}
+
+static c64 root(unsigned long long num, unsigned long long den)
+{
+    const long double TWO_PI = 6.283185307179586476925286766559005768L;
+    long double th = TWO_PI * (long double)(num % den) / (long double)den;
+    return {(double)cosl(th), (double)sinl(th)};
+}
+
+template <int V, int SYNC> static void run(const char* name, const c64* d_tab, unsigned long long* d_out, int n_cu, int iters)
+{
+    const int lds = kTableBytes + 8 * 8192;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_loop<V, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((pair_loop<V, SYNC>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, 8); // warm-up
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((pair_loop<V, SYNC>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, iters);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h((size_t)n_cu * 16);
+    CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> old_w, young_w;
+    unsigned long long sum = 0;
+    for (int b = 0; b < n_cu; b++)
+        for (int w = 0; w < 8; w++) {
+            (w < 4 ? old_w : young_w).push_back((double)h[((size_t)b * 8 + w) * 2] / iters);
+            sum += h[((size_t)b * 8 + w) * 2 + 1];
+        }
+    std::sort(old_w.begin(), old_w.end());
+    std::sort(young_w.begin(), young_w.end());
+    printf("%-58s sync=%d  cycles/pair: waves 0-3 %7.0f  waves 4-7 %7.0f   %.3f ms  (%.0f cycles/pair at 2.4 GHz)  checksum %016llx\n", name, SYNC,
+           old_w[old_w.size() / 2], young_w[young_w.size() / 2], ms, ms * 1e-3 * 2.4e9 / iters, sum);
+}
+
+int main(int argc, char** argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 4000;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    std::vector<c64> t(kTableEntries);
+    for (int k1 = 1; k1 < 8; k1++)
+        for (int lane = 0; lane < 64; lane++) { c64 r = root((unsigned long long)(lane * k1), 512); t[kT1Off + (k1 - 1) * 64 + lane] = {r.re, -r.im}; }
+    for (int c = 1; c < 8; c++)
+        for (int b = 0; b < 8; b++) { c64 r = root((unsigned long long)(b * c), 64); t[kT2Off + (c - 1) * 8 + b] = {r.re, -r.im}; }
+    for (int k = 0; k < 512; k++) { c64 r = root((unsigned long long)k, 1024); t[kWCOff + k] = {r.re, -r.im}; }
+    for (int n = 0; n < 1024; n++) t[kTWOff + n] = root((unsigned long long)n, 4096);
+    c64* d_tab; unsigned long long* d_out;
+    CK(hipMalloc((void**)&d_tab, kTableBytes));
+    CK(hipMemcpy(d_tab, t.data(), kTableBytes, hipMemcpyHostToDevice));
+    CK(hipMalloc((void**)&d_out, (size_t)n_cu * 16 * 8));
+    printf("%d CUs, %d pairs per wave, 8 waves per workgroup, one workgroup per CU\n", n_cu, iters);
+    run<0, 0>("0 fft512_pair1<+1,2> (shipped)", d_tab, d_out, n_cu, iters);
+    run<0, 1>("0 fft512_pair1<+1,2> (shipped)", d_tab, d_out, n_cu, iters);
+    run<1, 0>("1 fft512_pair1<+1,0> all exchanges via LDS", d_tab, d_out, n_cu, iters);
+    run<1, 1>("1 fft512_pair1<+1,0> all exchanges via LDS", d_tab, d_out, n_cu, iters);
+    run<2, 0>("2 fft512_pair1<+1,1> exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
+    run<2, 1>("2 fft512_pair1<+1,1> exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
+    run<3, 0>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
+    run<3, 1>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
+    run<4, 0>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
+    run<4, 1>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
+    run<5, 0>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
+    run<5, 1>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
+    return 0;
+}

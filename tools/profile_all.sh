@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile bench.py on the GPU box: kernel trace + PMC passes (each its own run, no trace domains beside --pmc).
-# usage: bash scripts_profile.sh <tag> [batch] [extra bench args, e.g. "" to keep the extras legs]
+# usage: bash tools/profile_all.sh <tag> [batch] [extra bench args, e.g. "" to keep the extras legs]
 set -o pipefail
 TAG=${1:-r02}
 BATCH=${2:-4096}

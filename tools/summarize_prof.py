@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Condense a scripts_profile.sh output directory into profiles/<tag>_summary.md (every kernel of the run)
+"""Condense a tools/profile_all.sh output directory into profiles/<tag>_summary.md (every kernel of the run)
 and, for the dominant kernel, profiles/latest_counters.json (what bench.py attaches to its roofline block,
 labelled as a stored profile).
 
-usage: tools_summarize_prof.py <gpurun_out/prof_TAG> <TAG> [batch]
+usage: tools/summarize_prof.py <gpurun_out/prof_TAG> <TAG> [batch]
 HBM traffic is corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE (KB) under-counts wide coalesced reads
 by exactly 2x on gfx950 (128-B requests tallied at 64 B); WRITE_SIZE (KB) is exact.  SQ_* counters are summed
 over the chip; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (x4 = cycles)."""
