@@ -351,6 +351,7 @@ def main() -> int:
         mul8 = leg("mul8_gate_pool", lambda: _bench_mul8_pool(eng, P, rank, world))
         mul32 = leg("mul32_gate_pool", lambda: _bench_mul32_pool(eng, P, rank, world))
     cmux = leg("cmux", _cmux) if args.with_cmux else None
+    evpool = leg("evaluation_pool", lambda: _bench_evaluation_pool(eng, P, dev, torch)) if (extras and rank == 0) else None
     leg("restore", restore_headline_output)
 
     # one collective for all legs: MAX of the per-rank seconds (inf where a rank failed)
@@ -497,6 +498,8 @@ def main() -> int:
             line["cmux"] = cmux
         if cbs:
             line["circuit_bootstrap"] = cbs
+        if evpool:
+            line["evaluation_pool"] = evpool
         if add32:
             line["add32"] = add32
         if mul8:
@@ -592,6 +595,94 @@ def _live_counters(kernel_name, B, kernel_ms, n_cu, budget_s=150.0):
         out["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]
         out["SQ_LDS_BANK_CONFLICT"] = c["SQ_LDS_BANK_CONFLICT"]
     return out
+
+
+def _bench_evaluation_pool(eng, P, dev, torch, thread_counts=(64, 256, 1024), seconds=2.5):
+    """The drop-in scenario itself (VERDICT r3 task 5): T host threads, each calling `FheOp::KeyswitchL1toL0 ->
+    FheOp::CircuitBootstrap` on ONE ciphertext synchronously, again and again — what the rayon workers of
+    `CircuitProcessor::execute_task` do (parasol_runtime/src/circuit_processor/mod.rs:192-253) — through spf_pool_*.
+    The callers are native threads (tools/pool_driver.cpp: Python threads would serialise on the interpreter lock); they use
+    the public C ABI only; they are confined to the box's CPU share (the GPU box grants 16 CPUs through a CFS quota while
+    `nproc` shows 256: a thousand threads waking across 256 CPUs spend the whole quota in scheduler work — 19 s of kernel
+    time per 1.8 s of wall time, 12 of 17 periods throttled, tools/pool_probe.py — so the leg pins itself to the quota's
+    CPUs for its duration).  Reported per T: circuit bootstraps per second, the batch size the pool achieved
+    (spf_pool_stats), and the ratio to the device-resident rate of the same two kernels at a batch of T (inputs and
+    outputs in HBM, no host traffic): 16 KiB in and 256 KiB out per operation cross PCIe here."""
+    import ctypes as C
+    import subprocess
+    import spf_amd
+    drv_path = os.path.join(ROOT, "tools", "bin", "libpool_driver.so")
+    src = os.path.join(ROOT, "tools", "pool_driver.cpp")
+    if not os.path.exists(drv_path) or os.path.getmtime(drv_path) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(drv_path), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", os.path.join(ROOT, "include"),
+                        "-o", drv_path, src], check=True)
+    drv = C.CDLL(drv_path)
+    drv.spf_pool_drive.restype = C.c_long
+    drv.spf_pool_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_size_t,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    cpus_before = os.sched_getaffinity(0)
+    n_quota = len(cpus_before)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n_quota = max(1, min(n_quota, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    os.sched_setaffinity(0, set(sorted(cpus_before)[:n_quota]))   # the driver's threads inherit it
+    out_cpus = n_quota
+    lib = eng._lib
+    submit = C.cast(lib.spf_pool_submit_keyswitch_circuit_bootstrap, C.c_void_p)
+    wait = C.cast(lib.spf_pool_wait, C.c_void_p)
+    lwe1 = np.random.default_rng(0x9001).integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"op": "spf_pool_submit_keyswitch_circuit_bootstrap + spf_pool_wait, one ciphertext per call",
+           "host_cpus": out_cpus, "runs": []}
+    try:
+        _pool_runs(out, thread_counts, seconds, eng, P, dev, torch, drv, submit, wait, lwe1, stream, spf_amd, C)
+    finally:
+        os.sched_setaffinity(0, cpus_before)
+    return out
+
+
+def _pool_runs(out, thread_counts, seconds, eng, P, dev, torch, drv, submit, wait, lwe1, stream, spf_amd, C):
+    for T in thread_counts:
+        # device-resident reference at a batch of T: keyswitch + whole circuit bootstrap, everything in HBM
+        d_in = torch.randint(-(2 ** 63), 2 ** 63 - 1, (T, P.lwe1_words), device=dev, dtype=torch.int64)
+        d_mid = torch.empty((T, P.lwe0_words), device=dev, dtype=torch.int64)
+        d_out = torch.empty((T, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
+
+        def dev_step():
+            eng.keyswitch_dev(stream, T, d_in.data_ptr(), d_mid.data_ptr())
+            eng.circuit_bootstrap_dev(stream, T, d_mid.data_ptr(), d_out.data_ptr())
+
+        dev_step()
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dev_step()
+        torch.cuda.synchronize()
+        dev_rate = T * reps / (time.perf_counter() - t0)
+        del d_in, d_mid, d_out
+        pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=200)
+        try:
+            el, ck = C.c_double(), C.c_double()
+            drv.spf_pool_drive(pool._h, submit, wait, T, 0.5, lwe1.ctypes.data, P.lwe1_words, P.cbs_ggsw_complex * 2,
+                               C.byref(el), C.byref(ck))   # warm-up: staging buffers pinned, shapes settled
+            ops0, launches0 = pool.stats()
+            n = drv.spf_pool_drive(pool._h, submit, wait, T, seconds, lwe1.ctypes.data, P.lwe1_words, P.cbs_ggsw_complex * 2,
+                                   C.byref(el), C.byref(ck))
+            ops1, launches1 = pool.stats()
+        finally:
+            pool.close()
+        if n < 0:
+            raise RuntimeError(f"pool driver: an operation failed at T = {T}")
+        rate = n / el.value
+        out["runs"].append({"threads": T, "circuit_bootstraps_per_s": round(rate, 1), "operations": int(n),
+                            "achieved_batch": round((ops1 - ops0) / max(1, launches1 - launches0), 1),
+                            "device_resident_rate_at_batch_T": round(dev_rate, 1),
+                            "frac_of_device_resident": round(rate / dev_rate, 4)})
 
 
 def _bench_mul8_pool(eng, P, rank, world, per_gpu=8):

@@ -495,6 +495,213 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     sched_fence(); // the image's next writer stays behind these reads
 }
 
+// ---- fft512_pair1 with the LDS stores SPREAD through the arithmetic ------------------------------------------------------
+// tools/microbench/fft_pair_bench.hip (r04): eight waves per CU running transform pairs in lockstep need 7.9 k cycles per pair,
+// the butterflies alone 4.7 k and the LDS traffic alone 4.2 k — the two hardly overlap, because each exchange leaves the wave as
+// a burst of eight `ds_write_b128` (13 cycles of the CU's store path each, all eight waves bursting at once) and the other
+// transform's table reads queue behind it.  Here the eight stores of one transform are issued two at a time between the
+// three butterfly stages and the twiddle products of the OTHER transform (7.4 k cycles per pair in the same probe).  radix8 is
+// cut into its three stages for that; the operations and their order per value are those of `radix8`: same words.
+template <int DIR> __device__ __forceinline__ void radix8_stage1(const c64 (&v)[8], c64 (&s)[4], c64 (&t)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = cadd(v[i], v[i + 4]); t[i] = csub(v[i], v[i + 4]); }
+}
+template <int DIR> __device__ __forceinline__ void radix8_stage2(const c64 (&s)[4], const c64 (&t)[4], c64 (&u)[8])
+{
+    c64 t1w, t3w;
+    if (DIR > 0) {
+        double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;
+        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
+        double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
+        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
+    } else {
+        double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;
+        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
+        double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;
+        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
+    }
+    u[0] = cadd(s[0], s[2]); u[1] = cadd(s[1], s[3]); u[2] = csub(s[0], s[2]); u[3] = csub(s[1], s[3]);
+    if (DIR > 0) {
+        u[4] = {t[0].re + t[2].im, t[0].im - t[2].re};
+        u[5] = {t[0].re - t[2].im, t[0].im + t[2].re};
+    } else {
+        u[4] = {t[0].re - t[2].im, t[0].im + t[2].re};
+        u[5] = {t[0].re + t[2].im, t[0].im - t[2].re};
+    }
+    u[6] = cadd(t1w, t3w); u[7] = csub(t1w, t3w);
+}
+template <int DIR> __device__ __forceinline__ void radix8_stage3(c64 (&v)[8], const c64 (&u)[8])
+{
+    v[0] = cadd(u[0], u[1]);
+    v[4] = csub(u[0], u[1]);
+    if (DIR > 0) {
+        v[2] = {u[2].re + u[3].im, u[2].im - u[3].re};
+        v[6] = {u[2].re - u[3].im, u[2].im + u[3].re};
+    } else {
+        v[2] = {u[2].re - u[3].im, u[2].im + u[3].re};
+        v[6] = {u[2].re + u[3].im, u[2].im - u[3].re};
+    }
+    v[1] = cadd(u[4], u[6]);
+    v[5] = csub(u[4], u[6]);
+    if (DIR > 0) {
+        v[3] = {u[5].re + u[7].im, u[5].im - u[7].re};
+        v[7] = {u[5].re - u[7].im, u[5].im + u[7].re};
+    } else {
+        v[3] = {u[5].re - u[7].im, u[5].im + u[7].re};
+        v[7] = {u[5].re + u[7].im, u[5].im - u[7].re};
+    }
+}
+// radix-8 of X, then its seven twiddle products (table entries tw_base[stride * (k - 1)]), with the eight LDS operations
+// op(0) .. op(7) of the caller issued two at a time between the stages
+template <int DIR, class OP>
+__device__ __forceinline__ void radix8_tw_spread(c64 (&X)[8], const c64* tw_base, int stride, OP op)
+{
+    c64 s[4], t[4], u[8];
+    radix8_stage1<DIR>(X, s, t);
+    sched_fence();
+    op(0); op(1);
+    sched_fence();
+    radix8_stage2<DIR>(s, t, u);
+    sched_fence();
+    op(2); op(3);
+    sched_fence();
+    radix8_stage3<DIR>(X, u);
+    sched_fence();
+    op(4); op(5);
+    sched_fence();
+#pragma unroll
+    for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
+    sched_fence();
+    op(6); op(7);
+    sched_fence();
+#pragma unroll
+    for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
+    sched_fence();
+}
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1s(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    static_assert(XP == 1 || XP == 2, "exchange 2 of B (XP = 2) or of both transforms (XP = 1) in registers");
+    constexpr bool XA = XP == 1;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    const c64* t1 = tab + kT1Off + lane;
+    const c64* t2 = tab + kT2Off + hi3;
+    // pass 1 of A
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], t1[64 * (k1 - 1)]);
+    sched_fence();
+    // pass 1 of B, A's exchange-1 stores spread through it
+    radix8_tw_spread<DIR>(B, t1, 64, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
+    // A's exchange-1 reads (ahead of B's stores to the same image: a wave's DS instructions execute in issue order), then
+    // pass 2 of A with B's exchange-1 stores spread through it
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    radix8_tw_spread<DIR>(A, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = B[k]; });
+    mid();
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    if constexpr (XA) {
+        lane_transpose_hi3(A);
+        radix8<DIR>(A); // pass 3 of A
+        sched_fence();
+        radix8<DIR>(B);
+#pragma unroll
+        for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], t2[8 * (c - 1)]);
+        sched_fence();
+        lane_transpose_hi3(B);
+        radix8<DIR>(B);
+    } else {
+        // pass 2 of B, A's exchange-2 stores spread through it
+        radix8_tw_spread<DIR>(B, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
+#pragma unroll
+        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        sched_fence();
+        lane_transpose_hi3(B);
+        radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
+        radix8<DIR>(B);
+    }
+    sched_fence(); // the image's next writer stays behind these reads
+}
+
+// ---- fft512_pair1 with EARLY reads ---------------------------------------------------------------------------------------
+// fft512_pair1 issues the reads of an exchange one butterfly block behind its stores (the registers of the transform that is
+// in LDS are free for the other one's temporaries meanwhile), so the reads have only the next store burst to complete under.
+// Where registers allow (polynomial 0's forward pair: the frequency-domain product is not live yet; the inverse pair: it has
+// just been consumed), the reads go out right behind their own stores — a wave's DS instructions execute in issue order, the
+// image is free again for the other transform's stores as soon as the reads are ISSUED — and have a whole butterfly block of
+// the other transform to land under.  Same butterflies on the same values: same words.
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1e(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    static_assert(XP == 1 || XP == 2, "exchange 2 of B (XP = 2) or of both transforms (XP = 1) in registers");
+    constexpr bool XA = XP == 1;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    // pass 1 of A, exchange 1 of A out and straight back
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    // pass 1 of B (A's reads land under it), exchange 1 of B
+    radix8<DIR>(B);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
+    sched_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    // pass 2 of A (B's reads land under it)
+    radix8<DIR>(A);
+#pragma unroll
+    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+    mid();
+    if constexpr (XA) {
+        lane_transpose_hi3(A);
+        radix8<DIR>(A); // pass 3 of A
+        sched_fence();
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+        sched_fence();
+#pragma unroll
+        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        sched_fence();
+    }
+    // pass 2 of B (A's exchange-2 reads land under it), exchange 2 of B in registers
+    radix8<DIR>(B);
+#pragma unroll
+    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    sched_fence();
+    lane_transpose_hi3(B);
+    if constexpr (!XA) radix8<DIR>(A); // pass 3 of A
+    radix8<DIR>(B);
+    sched_fence(); // the image's next writer stays behind these reads
+}
+
 // round half away from zero, then reduce mod 2^64 into the torus exactly as
 // PolynomialFftRef::ifft does (entities/polynomial_fft.rs:82-99 -> simd/scalar.rs:26-35,
 // 75-119 -> `x as i64` saturating, math/torus.rs:177-192).

@@ -1602,11 +1602,30 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     p->ctx = c; p->prm = c->prm; p->max_batch = max_batch;
     p->max_inflight = 4 * max_batch; // flow control: cf. the reference's bounded token channel (circuit_processor/mod.rs:139)
     p->max_wait = std::chrono::microseconds(max_wait_us);
-    try {
-        p->worker = std::thread([p] { p->loop(); });
-    } catch (const std::exception& e) { // std::system_error: no thread to be had — must not cross extern "C"
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) != hipSuccess) {
         delete p;
-        return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the worker thread: ") + e.what());
+        return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the copy stream");
+    }
+    try {
+        p->launcher = std::thread([p] {
+            p->launch_loop();
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->launcher_gone = true;
+            p->cv_flight.notify_all();
+        });
+        p->completer = std::thread([p] { p->complete_loop(); });
+    } catch (const std::exception& e) { // std::system_error: no thread to be had — must not cross extern "C"
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->stop = true;
+            p->launcher_gone = !p->launcher.joinable();
+        }
+        p->cv_work.notify_all();
+        p->cv_flight.notify_all();
+        if (p->launcher.joinable()) p->launcher.join();
+        (void)hipStreamDestroy(p->s_in);
+        delete p;
+        return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the pool threads: ") + e.what());
     }
     *out = p;
     return SPF_OK;
@@ -1628,18 +1647,26 @@ void spf_pool_destroy(spf_pool* p)
         std::lock_guard<std::mutex> lk(p->mu);
         p->stop = true;
     }
-    // wake everything that can be parked on this pool: the worker, producers blocked on back-pressure (they
-    // return an error), and waiters (the worker drains the queues before it exits, so their tickets complete)
+    // wake everything that can be parked on this pool: the launcher (it closes and enqueues what is pending, then
+    // leaves), producers blocked on back-pressure or on a staging set (they return an error), and waiters (their
+    // batches complete: the completion thread outlives the launcher)
     p->cv_work.notify_all();
     p->cv_space.notify_all();
-    p->cv_done.notify_all();
-    if (p->worker.joinable()) p->worker.join();
+    p->cv_set.notify_all();
+    if (p->launcher.joinable()) p->launcher.join();
+    p->cv_flight.notify_all();
+    if (p->completer.joinable()) p->completer.join();
     {
         // nobody may still be inside submit() / spf_pool_wait() on the mutex and condition variables freed below
         std::unique_lock<std::mutex> lk(p->mu);
-        p->cv_done.notify_all();
+        p->cv_set.notify_all();
         p->cv_idle.wait(lk, [&] { return p->blocked == 0; });
+        for (auto& b : p->collecting) // batches with tickets nobody collected
+            for (hipEvent_t e : {b->ev_in, b->ev_k, b->ev_out})
+                if (e) (void)hipEventDestroy(e);
     }
+    p->free_sets();
+    (void)hipStreamDestroy(p->s_in);
     delete p;
 }
 
@@ -1664,21 +1691,7 @@ spf_status spf_pool_submit_cmux(spf_pool* p, const double* sel, const uint64_t* 
 
 spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)
 {
-    if (!p) return SPF_ERR_INVALID_ARGUMENT;
-    std::unique_lock<std::mutex> lk(p->mu);
-    // a ticket can be waited for exactly once: unknown, already collected, or already being waited for by
-    // another thread is an error (not a hang) — the claim is taken under the same lock as the check
-    if (p->open.count(ticket) == 0 || !p->claimed.insert(ticket).second) return SPF_ERR_INVALID_ARGUMENT;
-    p->blocked++;
-    p->cv_done.wait(lk, [&] { return p->done.count(ticket) != 0; });
-    p->blocked--;
-    spf_status st = p->done[ticket];
-    p->done.erase(ticket);
-    p->open.erase(ticket);
-    p->claimed.erase(ticket);
-    p->cv_space.notify_all();
-    if (p->stop) p->cv_idle.notify_all();
-    return st;
+    return p ? p->wait(ticket) : SPF_ERR_INVALID_ARGUMENT;
 }
 
 spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)

@@ -107,12 +107,16 @@ __device__ __forceinline__ void young_prio(uint32_t flag) {
 //   15 behind the inverse pair            16 behind the conversion of q = 0     17 / 18 / 19 half-way through p0's forward
 //   pair / p1's forward pair / the inverse pair
 // (hand-overs 1 and 2 exist in the mixing instantiation only).  r03c's schedule, tuned on the even-rotation instantiation:
-// the younger waves lead from 14 to 4 and from 10 to 11.
+// the younger waves lead from 14 to 4 and from 10 to 11 (r04 re-checked it with the half-way points 17-19: four more
+// schedules, 42.35-44.07 ms against 42.29).  The mixing instantiation (the plain PBS, log_v = 0) has two more barriers per
+// polynomial, right where r03c's long stretch runs, so its younger waves arrived 4 600 cycles early at hand-over 1; its own
+// schedule (r04, twelve timed: profiles/r04_experiments_blind_rotate.md) lets them lead through the FIRST HALF of each of
+// the three transform pairs and nowhere else: 46.4 -> 44.9 ms per 4096.
 #ifndef SPF_PRIO_SCHED_EVEN
 #define SPF_PRIO_SCHED_EVEN "----0-----10--1-----"
 #endif
 #ifndef SPF_PRIO_SCHED_MIX
-#define SPF_PRIO_SCHED_MIX "----0-----10--1-----"
+#define SPF_PRIO_SCHED_MIX "----1-----1---10-00-"
 #endif
 template <int MIX> constexpr char prio_sched_at(int i) { return MIX ? SPF_PRIO_SCHED_MIX[i] : SPF_PRIO_SCHED_EVEN[i]; }
 static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) == 21, "20 schedule points");
@@ -122,6 +126,18 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
 // two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
+#ifndef SPF_FFT_PAIR
+#define SPF_FFT_PAIR fft512_pair1
+#endif
+#ifndef SPF_FFT_PAIR_P0   // polynomial 0's forward pair (the frequency-domain product is not live yet)
+#define SPF_FFT_PAIR_P0 SPF_FFT_PAIR
+#endif
+#ifndef SPF_FFT_PAIR_INV  // the inverse pair (the product has just been consumed)
+#define SPF_FFT_PAIR_INV SPF_FFT_PAIR
+#endif
+#ifndef SPF_BR_OPT
+#define SPF_BR_OPT 14
+#endif
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
@@ -288,7 +304,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             // (r03c: polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger)
             if (p == 0) SPF_PRIO_POINT(4); else SPF_PRIO_POINT(10);
             if (p == 1) ring_dma(chunk);
-            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { if (p == 0) SPF_PRIO_POINT(17); else SPF_PRIO_POINT(18); });
+            if (p == 0) SPF_FFT_PAIR_P0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
+            else SPF_FFT_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
             STAMP(3);
             if (p == 0) SPF_PRIO_POINT(5);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
@@ -461,7 +478,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             SPF_PRIO_POINT(14);
             if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
-        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+        SPF_FFT_PAIR_INV<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
         STAMP(9);
         SPF_PRIO_POINT(15);
 #pragma unroll
@@ -512,8 +529,8 @@ template <int L, int LOGB, int OPT, int MIX = 1>
 __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 4, MIX>(a, smem);
-    else blind_rotate2p_body<L, LOGB, OPT, 0, 4, MIX>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, SPF_BR_OPT, 1, 4, MIX>(a, smem);
+    else blind_rotate2p_body<L, LOGB, SPF_BR_OPT, 0, 4, MIX>(a, smem);
 }
 
 // The same schedule with TWO ciphertexts per workgroup (four waves, one per SIMD, one workgroup per CU): for batches

@@ -5,19 +5,43 @@
 // `execute_task` -> `rayon::spawn` -> `exec_op`; flow control by a bounded token channel, :130-190).
 // A GPU wants thousands of ciphertexts per launch.  The pool bridges the two without touching the
 // scheduler: every caller *submits* its single-ciphertext operation and blocks in *wait*, exactly
-// like the synchronous call it replaces; a worker thread gathers whatever operations of one kind are
-// pending (up to max_batch, or after max_wait_us since the oldest arrived), runs them as ONE batch
-// through the ordinary entry points, scatters the outputs and wakes the callers.  Errors follow the
-// reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters.
+// like the synchronous call it replaces.
+//
+// r04: a pipeline instead of one worker that gathered, ran and scattered a batch at a time through pageable vectors
+// (r03: the drop-in scenario — T threads, one ciphertext per call — moved 256 KiB of GGSW per gate through ONE thread's
+// memcpy, twice, with the GPU idle meanwhile):
+//   * the CALLERS move the bytes: `submit` takes a slot of the batch that is filling and copies its input straight into
+//     that batch's PINNED staging buffer (outside the lock, all submitting threads in parallel); `wait` copies the
+//     caller's own output out of the pinned buffer once the batch is done — T threads scatter T outputs at once;
+//   * a launcher thread closes a batch when it is full, or — the pool's kernels off the GPU — at once when it holds one and
+//     a half ciphertexts per CU, else when no member has arrived for max_wait_us or an eighth of the last batch's GPU time
+//     (everything that arrives during kernel k, and the callers of batch k coming straight back, is batch k + 1), and enqueues
+//     host-to-device copy, kernels and device-to-host copy on three streams tied by events: the copies of batch k + 1
+//     and k - 1 run under the kernels of batch k;
+//   * a completion thread waits for each batch's last event and wakes its waiters — through ONE futex word per batch, not
+//     a condition variable of the pool: a thousand sleeping callers on one condition variable + mutex cost 24 s of kernel
+//     time per 1.9 s of wall time (a wake storm per batch, then a convoy on the mutex) and ran the process into its CPU
+//     quota (tools/pool_probe.py: 15 of 18 scheduler periods throttled); the pool's mutex is held for a few hundred
+//     nanoseconds at a time (slot bookkeeping), never across a copy, a sleep or a HIP call;
+//   * three staging sets (pinned host + device buffers, grown on demand): one filling, one in flight, one being
+//     collected.  A set returns to the pool when every ticket of its batch has been collected; tickets nobody waits for
+//     are delivered by the launcher after a grace period, so that abandoned tickets cannot wedge the pipeline.
+// Errors follow the reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters.
 #pragma once
 #include "../../include/spf_hip.h"
 
+#include <atomic>
 #include <chrono>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
-#include <mutex>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -26,38 +50,68 @@
 namespace spf_pool_impl {
 
 enum Op { OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3, N_OPS = 4 };
+constexpr int kSets = 3;
+constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
 
-struct Request {
-    const void* in0;
-    const void* in1;
-    const void* in2;
+struct Slot {
     void* out;
     uint64_t ticket;
-    std::chrono::steady_clock::time_point t;
+    bool delivered; // output already copied to `out` (by the launcher, for a ticket nobody collected in time)
+};
+
+struct Staging {
+    void* h_in[3] = {nullptr, nullptr, nullptr};
+    void* h_out = nullptr;
+    void* d_in[3] = {nullptr, nullptr, nullptr};
+    void* d_out = nullptr;
+    void* d_mid = nullptr;
+    size_t cap_in[3] = {0, 0, 0}, cap_out = 0, cap_mid = 0;
+    bool busy = false;
+};
+
+struct Batch {
+    int op = 0, set = 0;
+    size_t cap = 0;               // slots of this batch
+    size_t n = 0, n_ready = 0;    // slots taken / inputs copied in
+    size_t n_collected = 0;
+    bool closed = false, done = false;
+    bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
+    std::atomic<uint32_t> done_word{0}; // 0 -> 1 when the batch is done: what its waiters sleep on (futex)
+    spf_status st = SPF_OK;
+    std::chrono::steady_clock::time_point t0, t_last, t_done, t_close, t_enq, t_ready, t_sync;
+    std::vector<Slot> slots;
+    hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
 };
 
 } // namespace spf_pool_impl
 
 struct spf_pool {
+    using Batch = spf_pool_impl::Batch;
     spf_ctx* ctx = nullptr;
     spf_params prm{};
     size_t max_batch = 4096;
     std::chrono::microseconds max_wait{200};
     std::mutex mu;
-    std::condition_variable cv_work, cv_done, cv_space;
-    std::deque<spf_pool_impl::Request> q[spf_pool_impl::N_OPS];
-    std::unordered_map<uint64_t, spf_status> done;
-    std::unordered_set<uint64_t> open;  // submitted and not yet collected by spf_pool_wait
+    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_flight;
+    std::shared_ptr<Batch> filling[spf_pool_impl::N_OPS];
+    std::deque<std::shared_ptr<Batch>> closing;                                     // closed, waiting for their members' input copies
+    std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, waited for by the completer
+    std::deque<std::shared_ptr<Batch>> collecting;                                  // done, not yet fully collected
+    std::unordered_map<uint64_t, std::pair<std::shared_ptr<Batch>, size_t>> tickets; // open tickets -> (batch, slot)
     std::unordered_set<uint64_t> claimed; // tickets some thread is already waiting for (a ticket has ONE waiter)
-    size_t blocked = 0;                 // callers inside submit() / spf_pool_wait(): destroy waits until they have left
-    std::condition_variable cv_idle;
-    size_t max_inflight = 16384;        // submit blocks while this many tickets are open (back-pressure)
+    size_t blocked = 0;                   // callers inside submit() / wait(): destroy waits until they have left
+    size_t space_waiters = 0, set_waiters = 0; // submitters parked on back-pressure / on a staging set
+    size_t max_inflight = 16384;          // submit blocks while this many tickets are open (back-pressure)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
     bool stop = false;
-    std::thread worker;
-    // gather / scatter staging (host)
-    std::vector<uint8_t> h_in0, h_in1, h_in2, h_out;
+    std::thread launcher, completer;
+    spf_pool_impl::Staging sets[spf_pool_impl::kSets];
+    hipStream_t s_in = nullptr;           // host-to-device copies; kernels run on ctx->stream, device-to-host on ctx->copy_stream
+    std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
+    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
+                                                              // (pinned staging is sized by what the callers actually produce:
+                                                              // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
 
     size_t lwe0_bytes() const { return ((size_t)prm.lwe_dimension + 1) * 8; }
     size_t lwe1_bytes() const { return ((size_t)prm.glwe_size * prm.polynomial_degree + 1) * 8; }
@@ -78,109 +132,413 @@ struct spf_pool {
         default: in[0] = ggsw_bytes(); in[1] = glwe_bytes(); in[2] = glwe_bytes(); out = glwe_bytes(); break;
         }
     }
-
-    spf_status run_batch(int op, std::vector<spf_pool_impl::Request>& batch)
+    size_t batch_cap(int op) const
     {
-        using namespace spf_pool_impl;
-        const size_t B = batch.size();
         size_t in[3], out;
         in_out_sizes(op, in, out);
-        std::vector<uint8_t>* hin[3] = {&h_in0, &h_in1, &h_in2};
+        const size_t big = std::max(std::max(in[0], in[1]), std::max(in[2], out));
+        return std::max<size_t>(1, std::min(max_batch, spf_pool_impl::kMaxStagingBytes / big));
+    }
+
+    // ---- staging sets (called with `mu` held; growing a buffer is rare: first use of an operation kind)
+    static bool grow_host(void*& p, size_t& cap, size_t bytes)
+    {
+        if (cap >= bytes) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return false;
+        cap = bytes;
+        return true;
+    }
+    static bool grow_dev(void*& p, size_t have, size_t bytes)
+    {
+        if (have >= bytes) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        return hipMalloc(&p, bytes) == hipSuccess;
+    }
+    bool prepare_set(spf_pool_impl::Staging& s, int op, size_t cap)
+    {
+        size_t in[3], out;
+        in_out_sizes(op, in, out);
+        if (hipSetDevice(ctx->device) != hipSuccess) return false;
         for (int k = 0; k < 3; k++) {
             if (!in[k]) continue;
-            hin[k]->resize(B * in[k]);
-            for (size_t i = 0; i < B; i++) {
-                const void* src = k == 0 ? batch[i].in0 : (k == 1 ? batch[i].in1 : batch[i].in2);
-                std::memcpy(hin[k]->data() + i * in[k], src, in[k]);
+            const size_t had = s.cap_in[k];
+            if (!grow_dev(s.d_in[k], had, cap * in[k])) return false; // (device first: cap_in is updated by grow_host)
+            if (!grow_host(s.h_in[k], s.cap_in[k], cap * in[k])) return false;
+        }
+        const size_t had_out = s.cap_out;
+        if (!grow_dev(s.d_out, had_out, cap * out)) return false;
+        if (!grow_host(s.h_out, s.cap_out, cap * out)) return false;
+        if (op == spf_pool_impl::OP_GATE_CBS && s.cap_mid < cap * lwe0_bytes()) {
+            if (!grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
+            s.cap_mid = cap * lwe0_bytes();
+        }
+        return true;
+    }
+    void free_sets()
+    {
+        (void)hipSetDevice(ctx->device);
+        for (auto& s : sets) {
+            for (int k = 0; k < 3; k++) {
+                if (s.h_in[k]) (void)hipHostFree(s.h_in[k]);
+                if (s.d_in[k]) (void)hipFree(s.d_in[k]);
+            }
+            if (s.h_out) (void)hipHostFree(s.h_out);
+            if (s.d_out) (void)hipFree(s.d_out);
+            if (s.d_mid) (void)hipFree(s.d_mid);
+            s = spf_pool_impl::Staging{};
+        }
+    }
+
+    static void futex_wait(std::atomic<uint32_t>* w, uint32_t expected)
+    {
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+    }
+    static void futex_wake_all(std::atomic<uint32_t>* w)
+    {
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    }
+
+    // output of one slot to its caller's buffer (any thread; the pinned buffer is stable while the batch is collecting)
+    void deliver(const Batch& b, size_t slot) const
+    {
+        size_t in[3], out;
+        in_out_sizes(b.op, in, out);
+        std::memcpy(b.slots[slot].out, static_cast<const uint8_t*>(sets[b.set].h_out) + slot * out, out);
+    }
+    // called with `mu` held when a ticket of `b` has been collected (or delivered on its owner's behalf)
+    void collected_one(const std::shared_ptr<Batch>& b)
+    {
+        if (++b->n_collected == b->n) {
+            sets[b->set].busy = false;
+            for (auto it = collecting.begin(); it != collecting.end(); ++it)
+                if (it->get() == b.get()) { collecting.erase(it); break; }
+            for (hipEvent_t e : {b->ev_in, b->ev_k, b->ev_out})
+                if (e) (void)hipEventDestroy(e);
+            b->ev_in = b->ev_k = b->ev_out = nullptr;
+            if (set_waiters) cv_set.notify_all();
+        }
+    }
+
+    spf_status submit(int op, const void* a, const void* b_in, const void* c, void* out, uint64_t* ticket)
+    {
+        using namespace spf_pool_impl;
+        if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
+        std::unique_lock<std::mutex> lk(mu);
+        blocked++;
+        struct Leave { spf_pool* p; ~Leave() { p->blocked--; if (p->stop) p->cv_idle.notify_all(); } } leave{this};
+        // back-pressure: a producer that runs ahead of its own waits blocks here instead of growing the queues
+        space_waiters++;
+        cv_space.wait(lk, [&] { return stop || tickets.size() < max_inflight; });
+        space_waiters--;
+        if (stop) return SPF_ERR_INVALID_ARGUMENT;
+        std::shared_ptr<Batch> b;
+        for (;;) {
+            b = filling[op];
+            if (b) break; // (a batch leaves `filling` the moment it is closed: what is there has room)
+            // open a batch on a free staging set
+            int set = -1;
+            for (int i = 0; i < kSets; i++) if (!sets[i].busy) { set = i; break; }
+            if (set < 0) {
+                // all sets held: wait for collectors; past the grace period deliver the oldest done batch's leftovers here
+                set_waiters++;
+                const bool timed_out = cv_set.wait_for(lk, std::chrono::milliseconds(20)) == std::cv_status::timeout;
+                set_waiters--;
+                if (timed_out) reclaim(lk);
+                if (stop) return SPF_ERR_INVALID_ARGUMENT;
+                continue;
+            }
+            const size_t cap = std::min(batch_cap(op), cap_hint[op]);
+            sets[set].busy = true;
+            if (!prepare_set(sets[set], op, cap)) {
+                sets[set].busy = false;
+                cv_set.notify_all();
+                return SPF_ERR_HIP;
+            }
+            try {
+                b = std::make_shared<Batch>();
+                b->slots.reserve(cap);
+            } catch (const std::exception&) {
+                sets[set].busy = false;
+                cv_set.notify_all();
+                return SPF_ERR_HIP;
+            }
+            b->op = op; b->set = set; b->cap = cap;
+            filling[op] = b;
+            break;
+        }
+        size_t slot;
+        try {
+            slot = b->n;
+            b->slots.push_back(Slot{out, next_ticket, false});
+            tickets.emplace(next_ticket, std::make_pair(b, slot));
+        } catch (const std::exception&) {
+            if (b->slots.size() > b->n) b->slots.pop_back();
+            return SPF_ERR_HIP;
+        }
+        b->t_last = std::chrono::steady_clock::now();
+        if (b->n == 0) b->t0 = b->t_last;
+        b->n++;
+        *ticket = next_ticket++;
+        if (b->n == b->cap) {
+            cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
+            close_batch(op);
+        }
+        size_t in[3], outsz;
+        in_out_sizes(op, in, outsz);
+        const Staging& s = sets[b->set];
+        lk.unlock();
+        // the caller's own bytes, by the caller's own thread, straight into pinned memory
+        const void* src[3] = {a, b_in, c};
+        for (int k = 0; k < 3; k++)
+            if (in[k]) std::memcpy(static_cast<uint8_t*>(s.h_in[k]) + slot * in[k], src[k], in[k]);
+        lk.lock();
+        b->n_ready++;
+        // the launcher sleeps until something changes for it: a batch got its first member (its deadline starts), or a
+        // closed batch just got its last input
+        if (slot == 0 || (b->closed && b->n_ready == b->n)) cv_work.notify_all();
+        return SPF_OK;
+    }
+
+    // `mu` held: the batch of `op` takes no more members; the launcher enqueues it once every member's input is in
+    void close_batch(int op)
+    {
+        std::shared_ptr<Batch> b = filling[op];
+        if (!b) return;
+        b->closed = true;
+        b->t_close = std::chrono::steady_clock::now();
+        filling[op].reset();
+        closing.push_back(b);
+        cv_work.notify_all();
+    }
+
+    // `mu` held.  Deliver the uncollected outputs of done batches that have waited longer than the grace period.
+    void reclaim(std::unique_lock<std::mutex>& lk)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t bi = 0; bi < collecting.size(); bi++) {
+            std::shared_ptr<Batch> b = collecting[bi];
+            if (now - b->t_done < grace) continue;
+            for (size_t i = 0; i < b->n; i++) {
+                spf_pool_impl::Slot& sl = b->slots[i];
+                if (sl.delivered || claimed.count(sl.ticket)) continue; // (a claimed ticket's waiter is copying right now)
+                auto it = tickets.find(sl.ticket);
+                if (it == tickets.end()) continue;                      // collected already
+                sl.delivered = true;
+                if (b->st == SPF_OK) {
+                    lk.unlock();
+                    deliver(*b, i);
+                    lk.lock();
+                }
+                collected_one(b); // the ticket stays open (its status is still to be fetched), its bytes are out
+                if (!sets[b->set].busy) return;
             }
         }
-        h_out.resize(B * out);
-        spf_status st;
-        switch (op) {
-        case OP_KEYSWITCH:
-            st = spf_keyswitch_lwe_l1_lwe_l0_batch(ctx, B, (const uint64_t*)h_in0.data(), (uint64_t*)h_out.data());
-            break;
-        case OP_CBS:
-            st = spf_circuit_bootstrap_batch(ctx, B, (const uint64_t*)h_in0.data(), (double*)h_out.data());
-            break;
-        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
-            st = spf_keyswitch_circuit_bootstrap_batch(ctx, B, (const uint64_t*)h_in0.data(), (double*)h_out.data());
-            break;
-        default:
-            st = spf_cmux_batch(ctx, B, (const double*)h_in0.data(), (const uint64_t*)h_in1.data(),
-                                (const uint64_t*)h_in2.data(), (uint64_t*)h_out.data());
-            break;
+    }
+
+    spf_status wait(uint64_t ticket)
+    {
+        std::shared_ptr<Batch> b;
+        size_t slot;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            // a ticket can be waited for exactly once: unknown, already collected, or already being waited for by
+            // another thread is an error (not a hang) — the claim is taken under the same lock as the check
+            auto it = tickets.find(ticket);
+            if (it == tickets.end() || !claimed.insert(ticket).second) return SPF_ERR_INVALID_ARGUMENT;
+            b = it->second.first;
+            slot = it->second.second;
+            blocked++;
         }
-        if (st == SPF_OK)
-            for (size_t i = 0; i < B; i++) std::memcpy(batch[i].out, h_out.data() + i * out, out);
+        // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
+        while (b->done_word.load(std::memory_order_acquire) == 0) futex_wait(&b->done_word, 0);
+        const spf_status st = b->st;
+        // (`delivered` is only ever set for an unclaimed ticket, under the mutex this thread's claim went through)
+        if (st == SPF_OK && !b->slots[slot].delivered) deliver(*b, slot); // this caller's output, by this caller's thread
+        std::lock_guard<std::mutex> lk(mu);
+        if (!b->slots[slot].delivered) {
+            b->slots[slot].delivered = true;
+            collected_one(b);
+        }
+        tickets.erase(ticket);
+        claimed.erase(ticket);
+        blocked--;
+        if (space_waiters) cv_space.notify_all();
+        if (stop) cv_idle.notify_all();
         return st;
     }
 
-    void loop()
+    // ---- launcher: closes batches and enqueues them
+    spf_status enqueue(Batch& b)
+    {
+        using namespace spf_pool_impl;
+        size_t in[3], out;
+        in_out_sizes(b.op, in, out);
+        const Staging& s = sets[b.set];
+        const size_t B = b.n;
+        if (hipSetDevice(ctx->device) != hipSuccess) return SPF_ERR_HIP;
+#ifdef SPF_POOL_TRACE
+        constexpr unsigned kEvFlags = hipEventDefault;
+#else
+        constexpr unsigned kEvFlags = hipEventDisableTiming;
+#endif
+        if (hipEventCreateWithFlags(&b.ev_in, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&b.ev_k, kEvFlags) != hipSuccess ||
+            hipEventCreateWithFlags(&b.ev_out, kEvFlags) != hipSuccess)
+            return SPF_ERR_HIP;
+        for (int k = 0; k < 3; k++)
+            if (in[k] && hipMemcpyAsync(s.d_in[k], s.h_in[k], B * in[k], hipMemcpyHostToDevice, s_in) != hipSuccess) return SPF_ERR_HIP;
+        if (hipEventRecord(b.ev_in, s_in) != hipSuccess) return SPF_ERR_HIP;
+        hipStream_t sk = ctx->stream;
+        if (hipStreamWaitEvent(sk, b.ev_in, 0) != hipSuccess) return SPF_ERR_HIP;
+        spf_status st;
+        switch (b.op) {
+        case OP_KEYSWITCH:
+            st = spf_keyswitch_lwe_l1_lwe_l0_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out);
+            break;
+        case OP_CBS:
+            st = spf_circuit_bootstrap_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out);
+            break;
+        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
+            st = spf_keyswitch_lwe_l1_lwe_l0_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_mid);
+            if (st == SPF_OK) st = spf_circuit_bootstrap_dev(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)s.d_out);
+            break;
+        default:
+            st = spf_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],
+                              (uint64_t*)s.d_out);
+            break;
+        }
+        if (st != SPF_OK) return st;
+        if (hipEventRecord(b.ev_k, sk) != hipSuccess) return SPF_ERR_HIP;
+        hipStream_t so = ctx->copy_stream;
+        if (hipStreamWaitEvent(so, b.ev_k, 0) != hipSuccess) return SPF_ERR_HIP;
+        if (hipMemcpyAsync(s.h_out, s.d_out, B * out, hipMemcpyDeviceToHost, so) != hipSuccess) return SPF_ERR_HIP;
+        if (hipEventRecord(b.ev_out, so) != hipSuccess) return SPF_ERR_HIP;
+        return SPF_OK;
+    }
+
+    void launch_loop()
     {
         using namespace spf_pool_impl;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_work.wait(lk, [&] {
-                if (stop) return true;
-                for (auto& d : q) if (!d.empty()) return true;
-                return false;
-            });
-            if (stop) {
-                bool any = false;
-                for (auto& d : q) any = any || !d.empty();
-                if (!any) return;
+            // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in
+            if (!closing.empty()) {
+                std::shared_ptr<Batch> b = closing.front();
+                if (b->n_ready < b->n) { cv_work.wait(lk); continue; }
+                closing.pop_front();
+                b->t_ready = std::chrono::steady_clock::now();
+                lk.unlock();
+                spf_status st;
+                try {
+                    st = enqueue(*b);
+                } catch (const std::exception&) {
+                    st = SPF_ERR_HIP;
+                }
+                lk.lock();
+                b->st = st;
+                b->t_enq = std::chrono::steady_clock::now();
+                in_flight.push_back(b);
+                cv_flight.notify_all();
+                continue;
             }
-            // the kind whose oldest request has waited longest
+            // 2. the filling batch with the oldest first member: close it when the GPU has no kernels of the pool in flight and that
+            // member has waited max_wait, or — the GPU busy — the moment the kernels of the batch in flight have completed
+            // (everything that arrived during kernel k is batch k + 1; its copy in and kernels overlap batch k's copy out);
+            // a full batch was closed by the submit that filled it
             int op = -1;
             for (int k = 0; k < N_OPS; k++)
-                if (!q[k].empty() && (op < 0 || q[k].front().t < q[op].front().t)) op = k;
-            // let the batch fill: until max_batch, or max_wait after its oldest member arrived
-            auto deadline = q[op].front().t + max_wait;
-            while (!stop && q[op].size() < max_batch && std::chrono::steady_clock::now() < deadline)
-                cv_work.wait_until(lk, deadline);
-            std::vector<Request> batch;
-            while (!q[op].empty() && batch.size() < max_batch) {
-                batch.push_back(q[op].front());
-                q[op].pop_front();
+                if (filling[k] && filling[k]->n > 0 && (op < 0 || filling[k]->t0 < filling[op]->t0)) op = k;
+            if (op < 0) {
+                if (stop) return;
+                cv_work.wait(lk);
+                continue;
             }
-            lk.unlock();
-            spf_status st;
-            try {
-                st = run_batch(op, batch);
-            } catch (const std::exception&) { // bad_alloc while staging a batch: its waiters get an error, the pool lives on
-                st = SPF_ERR_HIP;
+            if (!stop) {
+                bool gpu_busy = false;
+                for (auto& f : in_flight) gpu_busy = gpu_busy || !f->kernels_done;
+                if (gpu_busy) { idle_since_valid = false; cv_work.wait_for(lk, std::chrono::milliseconds(50)); continue; }
+                // The GPU is free.  The callers of the batch that just finished are copying their outputs out and will be
+                // back within a few hundred microseconds: launching what has gathered so far would split the callers into
+                // two groups that take turns on a half-empty GPU (T = 64: two groups of 32, each paying the full latency of
+                // a launch).  So the batch closes when no member has arrived for max_wait — bounded by 20 x max_wait of
+                // idle GPU, so that a trickle of arrivals cannot hold it open.
+                // With one and a half ciphertexts per CU gathered the GPU is worth starting at once (the callers then settle into two
+                // groups whose kernels run back to back).  The quiet time is max_wait, stretched to an eighth of the last batch's
+                // time on the GPU (a caller needs that long to copy 256 KiB out and come back when its CPU is shared).
+                const auto now = std::chrono::steady_clock::now();
+                if (!idle_since_valid) { idle_since = now; idle_since_valid = true; }
+                if (filling[op]->n < 3 * (size_t)ctx->n_cu / 2) {
+                    // (a small batch also waits for the copy out of the batch before it: those callers are the ones to come back)
+                    if (!in_flight.empty() && now < idle_since + std::chrono::milliseconds(20)) {
+                        cv_work.wait_for(lk, std::chrono::milliseconds(1));
+                        continue;
+                    }
+                    const auto quiet = std::max(std::chrono::duration_cast<std::chrono::steady_clock::duration>(max_wait),
+                                                std::min<std::chrono::steady_clock::duration>(last_gpu_span / 8, std::chrono::milliseconds(2)));
+                    const auto deadline = std::min(std::max(filling[op]->t_last, last_done) + quiet, idle_since + 20 * quiet);
+                    if (now < deadline) { cv_work.wait_until(lk, deadline); continue; }
+                }
             }
-            lk.lock();
-            n_launches++;
-            n_ops += batch.size();
-            for (auto& r : batch) done[r.ticket] = st;
-            cv_done.notify_all();
+            idle_since_valid = false;
+            close_batch(op);
         }
     }
 
-    spf_status submit(int op, const void* a, const void* b, const void* c, void* out, uint64_t* ticket)
+    void complete_loop()
     {
-        if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
         std::unique_lock<std::mutex> lk(mu);
-        // back-pressure: a producer that runs ahead of its own waits blocks here instead of growing the queues
-        blocked++;
-        cv_space.wait(lk, [&] { return stop || open.size() < max_inflight; });
-        blocked--;
-        if (stop) {
-            cv_idle.notify_all(); // spf_pool_destroy waits for blocked callers to leave before it frees the pool
-            return SPF_ERR_INVALID_ARGUMENT;
+        for (;;) {
+            cv_flight.wait(lk, [&] { return !in_flight.empty() || (stop && launcher_gone); });
+            if (in_flight.empty()) return;
+            std::shared_ptr<Batch> b = in_flight.front();
+            lk.unlock();
+            if (b->st == SPF_OK) {
+                (void)hipSetDevice(ctx->device);
+                // first the kernels: the launcher closes and enqueues the batch that filled meanwhile, so that its copy in and
+                // its kernels run under this batch's copy out
+                const bool k_ok = hipEventSynchronize(b->ev_k) == hipSuccess;
+                lk.lock();
+                b->kernels_done = true;
+                last_gpu_span = std::chrono::steady_clock::now() - b->t_enq;
+                cv_work.notify_all();
+                lk.unlock();
+                if (!k_ok || hipEventSynchronize(b->ev_out) != hipSuccess) b->st = SPF_ERR_HIP;
+                b->t_sync = std::chrono::steady_clock::now();
+            } else {
+                // something was enqueued before the failure: let it drain before the staging set is reused
+                (void)hipSetDevice(ctx->device);
+                (void)hipStreamSynchronize(s_in);
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipStreamSynchronize(ctx->copy_stream);
+            }
+            lk.lock();
+            b->kernels_done = true;
+            in_flight.pop_front();
+            b->done = true;
+            b->t_done = std::chrono::steady_clock::now();
+            last_done = b->t_done;
+#ifdef SPF_POOL_TRACE
+            {
+                auto us = [](auto d) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(d).count(); };
+                float gpu_ms = -1.f;
+                if (b->ev_in && b->ev_out) (void)hipEventElapsedTime(&gpu_ms, b->ev_in, b->ev_out);
+                fprintf(stderr, "[pool] batch op %d n %zu: filled %ld us, closed->inputs in %ld us, enqueue %ld us, enqueued->event %ld us (gpu h2d..d2h %.0f us), event->marked %ld us\n", b->op, b->n,
+                        us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), gpu_ms * 1e3f, us(b->t_done - b->t_sync));
+            }
+#endif
+            collecting.push_back(b);
+            n_launches++;
+            n_ops += b->n;
+            b->done_word.store(1, std::memory_order_release);
+            futex_wake_all(&b->done_word);
+            cv_work.notify_all(); // the launcher closes the batch that filled meanwhile
         }
-        try {
-            spf_pool_impl::Request r{a, b, c, out, next_ticket, std::chrono::steady_clock::now()};
-            q[op].push_back(r);
-            open.insert(r.ticket);
-            *ticket = r.ticket;
-            next_ticket++;
-        } catch (const std::exception&) {
-            return SPF_ERR_HIP;
-        }
-        cv_work.notify_one();
-        return SPF_OK;
     }
+    bool launcher_gone = false;
+    std::chrono::steady_clock::time_point idle_since; // since when the launcher has seen the GPU free with members waiting
+    bool idle_since_valid = false;
+    std::chrono::steady_clock::duration last_gpu_span{0}; // enqueue -> kernels done of the most recent batch
+    std::chrono::steady_clock::time_point last_done;      // when the most recent batch was handed to its waiters
 };

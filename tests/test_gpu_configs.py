@@ -290,3 +290,71 @@ def test_big_batches_are_bit_stable_run_to_run(full):
     for i in (0, B - 1):
         exp = O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P)
         assert np.array_equal(first[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), i
+
+
+_SOAK = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SPF_ROOT"])
+import torch
+import oracle as O
+import spf_amd
+
+P = spf_amd.DEFAULT_128
+OP = O.DEFAULT_128
+dev = torch.device("cuda", 0)
+eng = spf_amd.Engine(P, device=0)
+g = torch.Generator(device=dev).manual_seed(0x50A4)
+LAUNCH, LAUNCHES = 4096, 256           # 256 launches x 4096 gates = 1 048 576 gates per pass
+POOL = LAUNCH + LAUNCHES               # launch l takes gates l .. l + 4095 of the pool: every launch pairs the gates with
+                                       # other workgroup slots, neighbours and addresses
+sel = torch.randn((POOL, P.cbs_ggsw_complex * 2), generator=g, device=dev, dtype=torch.float64) * (2.0 ** 60)
+da = torch.randint(-(2 ** 63), 2 ** 63 - 1, (POOL, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
+db = torch.randint(-(2 ** 63), 2 ** 63 - 1, (POOL, P.glwe_words), generator=g, device=dev, dtype=torch.int64)
+out = torch.empty((LAUNCH, P.glwe_words), device=dev, dtype=torch.int64)
+stream = torch.cuda.current_stream().cuda_stream
+w = torch.arange(LAUNCH * P.glwe_words, device=dev, dtype=torch.int64).reshape(LAUNCH, -1) * 2654435761 + 12345
+
+
+def one_pass(keep):
+    sums = []
+    for l in range(LAUNCHES):
+        eng.cmux_dev(stream, LAUNCH, sel[l].data_ptr(), da[l].data_ptr(), db[l].data_ptr(), out.data_ptr())
+        sums.append(torch.stack([out.sum(), (out * w).sum(), out[0].sum(), out[-1].sum()]))
+        if l in keep:
+            keep[l] = (out[0].cpu().numpy().view(np.uint64).copy(), out[-1].cpu().numpy().view(np.uint64).copy())
+    return torch.stack(sums).cpu().numpy()
+
+
+keep = {l: None for l in (0, 1, 7, 100, 255)}
+first = one_pass(keep)
+second = one_pass({})
+bad = np.nonzero((first != second).any(axis=1))[0]
+assert bad.size == 0, f"launches {bad[:8]} differ between two passes over the same 1 048 576 gates"
+# a gate's result does not depend on the launch it is in: gate l + 4095 is the last gate of launch l and gate 4095 - ... of
+# later ones; first / last gate of sampled launches against the oracle
+sel_h = lambda i: sel[i].cpu().numpy().view(np.complex128)
+u = lambda t, i: t[i].cpu().numpy().view(np.uint64)
+for l, (o_first, o_last) in keep.items():
+    for i, got in ((l, o_first), (l + LAUNCH - 1, o_last)):
+        exp = O.cmux(u(da, i), u(db, i), sel_h(i), OP.N, OP.k, OP.cbs_radix_log, OP.cbs_count)
+        assert np.array_equal(got, exp), (l, i)
+assert eng.last_cmux_kernel() == "cmux_kernel<4,4,2,stream>", eng.last_cmux_kernel()
+print("CMUX_SOAK_OK", LAUNCHES * LAUNCH * 2)
+'''
+
+
+@pytest.mark.timeout(900)
+def test_cmux_soak_one_million_gates_two_passes():
+    """VERDICT r3 task 4: >= 1 M gates through spf_cmux_dev in launches of 4096, two passes, every launch's output
+    checksums equal between the passes (a register hit by a load landing late shows as a launch that differs from run to
+    run), plus the first and last gate of sampled launches against the oracle.  The kernels no longer issue a load nobody
+    consumes (the last round / last step is its own copy without requests).  In a child process: torch holds the 1.5 GB
+    gate pool on the device and must be imported before the library's HIP runtime."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPF_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _SOAK], capture_output=True, text=True, timeout=840, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "CMUX_SOAK_OK 2097152" in r.stdout, r.stdout[-1500:]

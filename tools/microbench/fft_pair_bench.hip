@@ -88,128 +88,13 @@ __device__ __forceinline__ void pair_lds_only(c64 (&A)[8], c64 (&B)[8], char* bu
     A[4] = cadd(A[4], tw[4]); A[5] = cadd(A[5], tw[5]); A[6] = cadd(A[6], tw[6]);
 }
 
-// variant 5: fft512_pair1<DIR, 2> with every burst of eight stores / eight reads of one transform spread through the
-// radix-8 of the other one (two LDS instructions per butterfly stage / twiddle group) instead of sitting between them
-template <int DIR> __device__ __forceinline__ void radix8_stage1(c64 (&v)[8], c64 (&s)[4], c64 (&t)[4])
-{
-#pragma unroll
-    for (int i = 0; i < 4; i++) { s[i] = cadd(v[i], v[i + 4]); t[i] = csub(v[i], v[i + 4]); }
-}
-template <int DIR> __device__ __forceinline__ void radix8_stage2(c64 (&v)[8], const c64 (&s)[4], const c64 (&t)[4], c64 (&u)[8])
-{
-    c64 t1w, t3w;
-    if (DIR > 0) {
-        double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;
-        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
-        double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
-        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
-    } else {
-        double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;
-        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
-        double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;
-        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
-    }
-    u[0] = cadd(s[0], s[2]); u[1] = cadd(s[1], s[3]); u[2] = csub(s[0], s[2]); u[3] = csub(s[1], s[3]);
-    if (DIR > 0) {
-        u[4] = {t[0].re + t[2].im, t[0].im - t[2].re};
-        u[5] = {t[0].re - t[2].im, t[0].im + t[2].re};
-    } else {
-        u[4] = {t[0].re - t[2].im, t[0].im + t[2].re};
-        u[5] = {t[0].re + t[2].im, t[0].im - t[2].re};
-    }
-    u[6] = cadd(t1w, t3w); u[7] = csub(t1w, t3w);
-}
-template <int DIR> __device__ __forceinline__ void radix8_stage3(c64 (&v)[8], const c64 (&u)[8])
-{
-    v[0] = cadd(u[0], u[1]);
-    v[4] = csub(u[0], u[1]);
-    if (DIR > 0) {
-        v[2] = {u[2].re + u[3].im, u[2].im - u[3].re};
-        v[6] = {u[2].re - u[3].im, u[2].im + u[3].re};
-    } else {
-        v[2] = {u[2].re - u[3].im, u[2].im + u[3].re};
-        v[6] = {u[2].re + u[3].im, u[2].im - u[3].re};
-    }
-    v[1] = cadd(u[4], u[6]);
-    v[5] = csub(u[4], u[6]);
-    if (DIR > 0) {
-        v[3] = {u[5].re + u[7].im, u[5].im - u[7].re};
-        v[7] = {u[5].re - u[7].im, u[5].im + u[7].re};
-    } else {
-        v[3] = {u[5].re - u[7].im, u[5].im + u[7].re};
-        v[7] = {u[5].re + u[7].im, u[5].im - u[7].re};
-    }
-}
-// radix-8 of X (+ its seven twiddles from `tw_base[stride * k]`) with the eight LDS operations `op(0..7)` spread through it
-template <int DIR, bool TW, class OP>
-__device__ __forceinline__ void radix8_spread(c64 (&X)[8], const c64* tw_base, int stride, OP op)
-{
-    c64 s[4], t[4], u[8];
-    radix8_stage1<DIR>(X, s, t);
-    sched_fence();
-    op(0); op(1);
-    sched_fence();
-    radix8_stage2<DIR>(X, s, t, u);
-    sched_fence();
-    op(2); op(3);
-    sched_fence();
-    radix8_stage3<DIR>(X, u);
-    sched_fence();
-    op(4); op(5);
-    sched_fence();
-    if constexpr (TW) {
-#pragma unroll
-        for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
-        sched_fence();
-        op(6); op(7);
-        sched_fence();
-#pragma unroll
-        for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
-    } else {
-        op(6); op(7);
-    }
-    sched_fence();
-}
-template <int DIR>
-__device__ __forceinline__ void fft512_pair1s(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
-{
-    const int hi3 = lane >> 3, lo3 = lane & 7;
-    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
-    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
-    const uint32_t wbase = 16 * (64 * hi3 + lo3);
-    char* wr[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
-    const c64* t1 = tab + kT1Off + lane;
-    const c64* t2 = tab + kT2Off + hi3;
-    // pass 1 of A
-    radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], t1[64 * (k1 - 1)]);
-    sched_fence();
-    // pass 1 of B with A's exchange-1 stores spread through it
-    radix8_spread<DIR, true>(B, t1, 64, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
-    // A's exchange-1 reads, then B's exchange-1 stores spread through pass 2 of A ... but A's pass 2 needs the reads: so the
-    // reads go first (they travel under the stores' issue), the stores are spread through A's pass 2
-#pragma unroll
-    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    radix8_spread<DIR, true>(A, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = B[k]; });
-    // B's exchange-1 reads; A's exchange-2 stores spread through pass 2 of B
-#pragma unroll
-    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    radix8_spread<DIR, true>(B, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
-#pragma unroll
-    for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
-    sched_fence();
-    lane_transpose_hi3(B);
-    radix8<DIR>(A);
-    radix8<DIR>(B);
-    sched_fence();
-}
+// variant 5 is spf_device.hpp's fft512_pair1s: the stores of one transform spread through the other's butterflies
 
-template <int V, int SYNC>
+// STG: waves 4-7 (the SIMD partners of waves 0-3) sleep STG x 64 cycles at the start of every pair (a small phase offset, so
+// that one wave's exchanges fall under the other's butterflies); PRI: 1 = waves 4-7 at s_setprio 1 for the whole pair,
+// 2 = for the first half of the pair (the r03c schedule of the real kernel), 3 = waves 0-3 at priority 1 for the second half
+// PRESS: registers of emulated live state besides the pair: 2 = accumulator + product (128), 1 = accumulator only (64)
+template <int V, int SYNC, int STG = 0, int PRI = 0, int PRESS = 2>
 __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned long long* out, int iters)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,13 +118,25 @@ __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned 
     for (int e = 0; e < 16; e++) prod[e] = {1.0 + e, 2.0 + lane};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const bool young = wv >= 4;
     for (int it = 0; it < iters; it++) {
+        if constexpr (STG > 0) { if (young) __builtin_amdgcn_s_sleep(STG); }
+        if constexpr (PRI == 1 || PRI == 2) { if (young) __builtin_amdgcn_s_setprio(1); }
+        if constexpr (V == 0 && PRI >= 2) {
+            fft512_pair1<+1, 2>(A, B, buf, tab, lane, [&]() {
+                if constexpr (PRI == 2) { if (young) __builtin_amdgcn_s_setprio(0); }
+                if constexpr (PRI == 3) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+            });
+            if constexpr (PRI == 3) { if (!young) __builtin_amdgcn_s_setprio(0); }
+        } else
         if constexpr (V == 0) fft512_pair1<+1, 2>(A, B, buf, tab, lane);
         else if constexpr (V == 1) fft512_pair1<+1, 0>(A, B, buf, tab, lane);
         else if constexpr (V == 2) fft512_pair1<+1, 1>(A, B, buf, tab, lane);
         else if constexpr (V == 3) pair_arith_only<+1>(A, B, tab, lane);
         else if constexpr (V == 4) pair_lds_only(A, B, buf, tab, lane);
-        else fft512_pair1s<+1>(A, B, buf, tab, lane);
+        else if constexpr (V == 5) fft512_pair1s<+1>(A, B, buf, tab, lane);
+        else if constexpr (V == 6) fft512_pair1e<+1, 2>(A, B, buf, tab, lane);
+        else fft512_pair1e<+1, 1>(A, B, buf, tab, lane);
         // keep magnitudes bounded (exact power-of-two scaling) and the emulated state live
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -251,10 +148,13 @@ __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned 
             for (int e = 0; e < 16; e++) {
                 acc[e] += (unsigned long long)__double_as_longlong(A[e & 7].re);
                 acc[16 + e] ^= (unsigned long long)__double_as_longlong(B[e & 7].im);
-                prod[e].re = __builtin_fma(prod[e].re, 0.5, A[e & 7].im);
-                prod[e].im = __builtin_fma(prod[e].im, 0.5, B[e & 7].re);
+                if constexpr (PRESS >= 2) {
+                    prod[e].re = __builtin_fma(prod[e].re, 0.5, A[e & 7].im);
+                    prod[e].im = __builtin_fma(prod[e].im, 0.5, B[e & 7].re);
+                }
             }
         }
+        if constexpr (PRI == 1) { if (young) __builtin_amdgcn_s_setprio(0); }
         if constexpr (SYNC) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -284,16 +184,16 @@ static c64 root(unsigned long long num, unsigned long long den)
     return {(double)cosl(th), (double)sinl(th)};
 }
 
-template <int V, int SYNC> static void run(const char* name, const c64* d_tab, unsigned long long* d_out, int n_cu, int iters)
+template <int V, int SYNC, int STG = 0, int PRI = 0, int PRESS = 2> static void run(const char* name, const c64* d_tab, unsigned long long* d_out, int n_cu, int iters)
 {
     const int lds = kTableBytes + 8 * 8192;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_loop<V, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((pair_loop<V, SYNC>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, 8); // warm-up
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_loop<V, SYNC, STG, PRI, PRESS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((pair_loop<V, SYNC, STG, PRI, PRESS>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, 8); // warm-up
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((pair_loop<V, SYNC>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, iters);
+    hipLaunchKernelGGL((pair_loop<V, SYNC, STG, PRI, PRESS>), dim3(n_cu), dim3(512), lds, 0, d_tab, d_out, iters);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -309,6 +209,8 @@ template <int V, int SYNC> static void run(const char* name, const c64* d_tab, u
         }
     std::sort(old_w.begin(), old_w.end());
     std::sort(young_w.begin(), young_w.end());
+    if (STG || PRI) printf("[stagger %d x 64 cycles, priority mode %d] ", STG, PRI);
+    if (PRESS != 2) printf("[live state %d] ", PRESS);
     printf("%-58s sync=%d  cycles/pair: waves 0-3 %7.0f  waves 4-7 %7.0f   %.3f ms  (%.0f cycles/pair at 2.4 GHz)  checksum %016llx\n", name, SYNC,
            old_w[old_w.size() / 2], young_w[young_w.size() / 2], ms, ms * 1e-3 * 2.4e9 / iters, sum);
 }
@@ -343,5 +245,13 @@ int main(int argc, char** argv)
     run<4, 1>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
     run<5, 0>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
     run<5, 1>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
+    run<6, 0>("6 fft512_pair1e<+1,2> early reads", d_tab, d_out, n_cu, iters);
+    run<6, 1>("6 fft512_pair1e<+1,2> early reads", d_tab, d_out, n_cu, iters);
+    run<7, 1>("7 fft512_pair1e<+1,1> early reads, exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
+    run<0, 1, 0, 0, 1>("0 shipped", d_tab, d_out, n_cu, iters);
+    run<5, 1, 0, 0, 1>("5 spread", d_tab, d_out, n_cu, iters);
+    run<6, 1, 0, 0, 1>("6 early reads", d_tab, d_out, n_cu, iters);
+    run<7, 1, 0, 0, 1>("7 early reads, XP = 1", d_tab, d_out, n_cu, iters);
+    run<6, 1, 0, 2, 1>("6 early reads", d_tab, d_out, n_cu, iters);
     return 0;
 }
