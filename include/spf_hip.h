@@ -194,7 +194,15 @@ spf_status spf_gate_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1
 spf_status spf_keyswitch_circuit_bootstrap_batch(spf_ctx *ctx, size_t B, const uint64_t *lwe1_in,
                                                  double *ggsw_fft_out);
 
-/* ---- device-pointer forms (inputs/outputs resident in HBM, asynchronous on `stream`) ----- */
+/* ---- device-pointer forms (inputs/outputs resident in HBM, asynchronous on `stream`) -----
+ * Contract of every `_dev` entry point: the call only ENQUEUES on `stream`; inputs and outputs must stay valid and
+ * unchanged until that work has completed; an output must not overlap any input of the same call.  The entry points that
+ * need intermediates (`spf_circuit_bootstrap_dev`, the keyswitch) keep them in buffers of the CONTEXT: enqueue them on ONE
+ * stream per context (or order the streams with events) — two such calls running concurrently on different streams would
+ * share those buffers.  `spf_mod_switch_trace_and_rotate_dev` additionally uses its OUTPUT as working memory while it runs
+ * (the kernel parks half of its accumulator in each unit's 32 KiB of `d_glev_out` between automorphism rounds):
+ * `d_glev_out` holds intermediate data until the kernel has completed and must not be read, or alias anything read, by
+ * work that may run concurrently with it. */
 
 spf_status spf_keyswitch_lwe_l1_lwe_l0_dev(spf_ctx *ctx, void *stream, size_t B,
                                            const uint64_t *d_lwe1_in, uint64_t *d_lwe0_out);

@@ -430,6 +430,12 @@ class Engine:
     def circuit_bootstrap_dev(self, stream, B, d_lwe, d_ggsw_out):
         self._ck(self._lib.spf_circuit_bootstrap_dev(self._h, stream, B, d_lwe, d_ggsw_out))
 
+    def mod_switch_trace_and_rotate_dev(self, stream, B, d_glwe, d_glev_out):
+        self._ck(self._lib.spf_mod_switch_trace_and_rotate_dev(self._h, stream, B, d_glwe, d_glev_out))
+
+    def scheme_switch_dev(self, stream, B, d_glev, d_ggsw_out):
+        self._ck(self._lib.spf_scheme_switch_dev(self._h, stream, B, d_glev, d_ggsw_out))
+
     def cmux_dev(self, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out):
         self._ck(self._lib.spf_cmux_dev(self._h, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out))
 

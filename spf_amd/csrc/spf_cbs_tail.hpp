@@ -362,8 +362,10 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
         }
         // the parked accumulator half has landed BEFORE the next key rows are requested: vmcnt counts in order, a wait for
         // it behind the request would wait for the rows as well
+#ifndef SPF_TRACE_LATE_PARK
 #pragma unroll
         for (int e = 0; e < 16; e++) asm volatile("" : "+v"(accb[e]));
+#endif
         if (chunk < total_chunks) { // rows of the next round's first digit pair, this wave's share = the slot it just read
             const uint32_t rnd = chunk / 3;
             const char* src = reinterpret_cast<const char*>(a.ak) +

@@ -42,6 +42,8 @@ def test_size_guards():
         parse_compute_key(buf[: len(buf) // 2], P)           # truncated
     with pytest.raises(KeyFormatError):
         parse_compute_key(b"\x01\x00", P)
+    with pytest.raises(KeyFormatError):   # the reference's malformed-length vector (rejects_malformed_keys, safe_bincode.rs:98-117)
+        parse_compute_key(bytes([253, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x1, 0x2, 0x3, 0x4]), P)
 
 
 @pytest.mark.gpu
@@ -71,7 +73,10 @@ def test_bincode_loader_behind_the_c_abi_equals_field_by_field_loading():
     bad = bytearray(blob)
     bad[0:8] = struct.pack("<Q", ks.bsk_fft.size + 1)
     fresh = spf_amd.Engine(to_engine_params(P))
-    for broken in (bytes(bad), blob[:-9], blob[:4]):
+    # ... and the reference's own key-shaped negative vector (rejects_malformed_keys, safe_bincode.rs:98-117: a length
+    # prefix of 0xFF..FF introduced by 253, then four stray bytes)
+    ref_bad = bytes(_kats()["bytes"])
+    for broken in (bytes(bad), blob[:-9], blob[:4], ref_bad):
         with pytest.raises(spf_amd.SpfError):
             fresh.load_compute_key_bincode(broken)
     with pytest.raises(spf_amd.SpfError):           # nothing was loaded by the failed attempts

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Launch ONE entry point of the library `reps` times at a FIXED batch, device-resident, for rocprofv3: every dispatch of a
 kernel in the trace then has the same grid, so per-kernel averages are roofline-grade numbers.
-usage: python tools/kernel_bench.py <cmux|keyswitch|cbs|pbs|pbsu> <B> [reps]
+usage: python tools/kernel_bench.py <cmux|keyswitch|cbs|pbs|pbsu|trace|ss> <B> [reps]
   cmux       spf_cmux_dev                 (cmux_kernel; cmux4_kernel for B <= #CU)
   keyswitch  spf_keyswitch_lwe_l1_lwe_l0_dev (ks_digits_kernel + ks_gemm_lds_kernel)
   cbs        spf_circuit_bootstrap_dev    (blind rotation + cbs_trace_kernel + scheme_switch_kernel)
   pbs        spf_circuit_bootstrap_pbs_dev (blind rotation only: blind_rotate4 / 2p2 / 2p by batch size; even rotations)
   pbsu       spf_pbs_univariate_dev       (the plain PBS, log_v = 0: the mixing instantiation of the same kernels)
+  trace      spf_mod_switch_trace_and_rotate_dev (cbs_trace_kernel alone, B ciphertexts = 4 B units)
+  ss         spf_scheme_switch_dev        (scheme_switch_kernel alone)
 Prints one JSON line with the hipEvent time per call."""
 import json
 import os
@@ -51,6 +53,16 @@ elif what == "keyswitch":
     lwe1 = rnd_i64(B, P.lwe1_words)
     out = torch.empty((B, P.lwe0_words), device=dev, dtype=torch.int64)
     call = lambda: eng.keyswitch_dev(stream, B, lwe1.data_ptr(), out.data_ptr())
+elif what in ("trace", "ss"):
+    key(2 if what == "trace" else 3, 2.0 ** 67)
+    if what == "trace":
+        src = rnd_i64(B, P.glwe_words)
+        out = torch.empty((B, 4 * P.glwe_words), device=dev, dtype=torch.int64)
+        call = lambda: eng.mod_switch_trace_and_rotate_dev(stream, B, src.data_ptr(), out.data_ptr())
+    else:
+        src = rnd_i64(B, 4 * P.glwe_words)
+        out = torch.empty((B, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
+        call = lambda: eng.scheme_switch_dev(stream, B, src.data_ptr(), out.data_ptr())
 elif what in ("cbs", "pbs", "pbsu"):
     for which in ((0, 2, 3) if what == "cbs" else (0,)):
         key(which, 2.0 ** 67)
@@ -77,11 +89,11 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 rec = {"what": what, "B": B, "reps": reps, "ms_per_call": round(e0.elapsed_time(e1) / reps, 4)}
-if what in ("pbs", "pbsu", "cmux"):
+if what in ("pbs", "pbsu", "cmux", "trace", "ss"):
     # checksum of the output words (seeded inputs): bit-equal builds print the same two numbers, so an A/B of library
     # builds (SPF_HIP_LIBRARY) is also a parity check against the build the test-suite verified
     res = (out if what != "cmux" else dc).view(torch.int64).reshape(-1)
     w = torch.arange(res.numel(), device=dev, dtype=torch.int64) * 2654435761 + 12345
     rec["checksum"] = [int(res.sum().item()), int((res * w).sum().item())]
-    rec["kernel"] = eng.last_blind_rotate_kernel() if what != "cmux" else eng.last_cmux_kernel()
+    rec["kernel"] = {"cmux": eng.last_cmux_kernel(), "trace": "cbs_trace_kernel", "ss": "scheme_switch_kernel"}.get(what) or eng.last_blind_rotate_kernel()
 print(json.dumps(rec))
