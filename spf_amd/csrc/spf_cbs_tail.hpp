@@ -12,6 +12,10 @@
 #pragma once
 #include "spf_kernels.hpp"
 
+#ifndef SPF_TAIL_PAIR
+#define SPF_TAIL_PAIR fft512_pair1t // pass twiddles requested early, shared by the pair (r04: scheme switch 1.16 -> 1.12 ms, trace unchanged)
+#endif
+
 namespace spf {
 
 // this wave's 8 bins of a 1024-bin row: index r -> bin lane + 64(4w + (r&3)) + 512(r>>2)
@@ -237,7 +241,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             if (m == 0) young_prio<0>(is_young);
             if (m == 2) young_prio<1>(is_young);
             if (m > 0) ring_dma(chunk);
-            fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+            SPF_TAIL_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
             STAMPT(2);
             // radix-2 stage across the two waves, both digits in one exchange
             if constexpr (w == 0) {
@@ -376,7 +380,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             for (int k = 0; k < 8; k++) lds_dma_piece(src + k * 1024, lane16, dst + k * 1024);
         }
         STAMPT(7);
-        fft512_pair1<-1, XP>(WW[0], WW[1], mine, tab, lane);
+        SPF_TAIL_PAIR<-1, XP>(WW[0], WW[1], mine, tab, lane);
         STAMPT(8);
         {
             uint64_t t[16];
@@ -483,7 +487,7 @@ __device__ __forceinline__ void scheme_switch_body(const SchemeSwitchArgs& a, ch
     const c64* wc = tab + kWCOff + 256 * w + lane;
     // forward transform pair with the radix-2 stage across the two waves; leaves this wave's bins in VV
     auto forward_pair = [&](c64 (&VV)[2][8]) {
-        fft512_pair1<+1, XP>(VV[0], VV[1], mine, tab, lane);
+        SPF_TAIL_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
         if constexpr (w == 0) {
 #pragma unroll
             for (int j = 0; j < 2; j++)

@@ -702,6 +702,200 @@ __device__ __forceinline__ void fft512_pair1e(c64 (&A)[8], c64 (&B)[8], char* bu
     sched_fence(); // the image's next writer stays behind these reads
 }
 
+// ---- fft512_pair1 with the pass twiddles requested EARLY and SHARED by the two transforms ---------------------------------
+// The ISA of fft512_pair1 (r04, `tools/isa_build.sh`) shows what hipcc makes of `X[k] = cmul_tw(X[k], tab[...])` when registers
+// are tight: the seven twiddles of a pass are fetched just in time, one or two at a time, each `ds_read_b128` followed by an
+// `s_waitcnt lgkmcnt(1)` four instructions later — about twenty exposed LDS round trips per pair that only the partner wave
+// can cover — and each transform fetches its own copy of the same seven entries (lane-indexed T1, hi3-indexed T2: the same
+// for A and B).  Here the seven entries of a pass are requested once, ahead of the butterflies they follow (they land under
+// ~50 f64 instructions), and multiply both transforms.  28 registers, live from the request to the second transform's
+// products: there is room for them wherever the frequency-domain product is not live (polynomial 0's forward pair, the
+// inverse pair), because one of the two transforms is always parked in LDS while the other is in its butterflies.
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1t(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    static_assert(XP == 1 || XP == 2, "exchange 2 of B (XP = 2) or of both transforms (XP = 1) in registers");
+    constexpr bool XA = XP == 1;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    c64 tw[7];
+    // pass 1: T1 for both transforms, requested ahead of A's butterflies
+#pragma unroll
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+    compiler_fence();
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tw[k1 - 1]);
+    sched_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
+    sched_fence();
+    // pass 2: T2 for both transforms, requested ahead of A's butterflies (behind B's stores in the queue)
+#pragma unroll
+    for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
+    compiler_fence();
+    radix8<DIR>(A);
+#pragma unroll
+    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tw[c - 1]);
+    sched_fence();
+    mid();
+#pragma unroll
+    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
+    sched_fence();
+    if constexpr (XA) {
+        lane_transpose_hi3(A);
+        radix8<DIR>(A); // pass 3 of A
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+    }
+    sched_fence();
+    radix8<DIR>(B);
+#pragma unroll
+    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tw[c - 1]);
+    sched_fence();
+    if constexpr (!XA) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        sched_fence();
+    }
+    lane_transpose_hi3(B);
+    if constexpr (!XA) radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
+    radix8<DIR>(B);
+    sched_fence(); // the image's next writer stays behind these reads
+}
+
+// fft512_pair1t with (EARLY) the reads of an exchange issued right behind its own stores and / or (SPREAD) the stores of one
+// transform issued two at a time between the butterfly stages of the other — the combinations r04 measured after the
+// shared twiddles had removed the exposed table reads (profiles/r04_experiments_blind_rotate.md).
+template <int DIR, class OP>
+__device__ __forceinline__ void radix8_twr_spread(c64 (&X)[8], const c64 (&tw)[7], OP op)
+{
+    c64 s[4], t[4], u[8];
+    radix8_stage1<DIR>(X, s, t);
+    sched_fence();
+    op(0); op(1);
+    sched_fence();
+    radix8_stage2<DIR>(s, t, u);
+    sched_fence();
+    op(2); op(3);
+    sched_fence();
+    radix8_stage3<DIR>(X, u);
+    sched_fence();
+    op(4); op(5);
+    sched_fence();
+#pragma unroll
+    for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
+    sched_fence();
+    op(6); op(7);
+    sched_fence();
+#pragma unroll
+    for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
+    sched_fence();
+}
+template <int DIR, int XP, bool EARLY, bool SPREAD, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    static_assert(XP == 2, "exchange 2 of B in registers");
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    auto store = [&](c64 (&X)[8], int k) { *reinterpret_cast<c64*>(wr[k]) = X[k]; };
+    auto load = [&](c64 (&X)[8], uint32_t rd) {
+#pragma unroll
+        for (int a = 0; a < 8; a++) X[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
+    };
+    c64 tw[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+    compiler_fence();
+    // pass 1 of A
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
+    if constexpr (!SPREAD) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) store(A, k);
+        sched_fence();
+        if constexpr (EARLY) { load(A, rd1); sched_fence(); }
+        radix8<DIR>(B);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tw[k1 - 1]);
+        sched_fence();
+    } else {
+        sched_fence();
+        radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
+    }
+    if constexpr (!EARLY || SPREAD) { load(A, rd1); sched_fence(); }
+    // exchange 1 of B, T2 for both transforms, pass 2 of A
+    if constexpr (!SPREAD) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) store(B, k);
+        sched_fence();
+        if constexpr (EARLY) { load(B, rd1); sched_fence(); }
+#pragma unroll
+        for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
+        compiler_fence();
+        radix8<DIR>(A);
+#pragma unroll
+        for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tw[c - 1]);
+        sched_fence();
+    } else {
+#pragma unroll
+        for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
+        compiler_fence();
+        radix8_twr_spread<DIR>(A, tw, [&](int k) { store(B, k); });
+    }
+    mid();
+    if constexpr (!EARLY || SPREAD) { load(B, rd1); sched_fence(); }
+    // exchange 2 of A, pass 2 of B
+    if constexpr (!SPREAD) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) store(A, k);
+        sched_fence();
+        if constexpr (EARLY) { load(A, rd2); sched_fence(); }
+        radix8<DIR>(B);
+#pragma unroll
+        for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tw[c - 1]);
+        sched_fence();
+    } else {
+        radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
+    }
+    if constexpr (!EARLY || SPREAD) { load(A, rd2); sched_fence(); }
+    lane_transpose_hi3(B);
+    radix8<DIR>(A);
+    radix8<DIR>(B);
+    sched_fence();
+}
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1te(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    fft512_pair1x<DIR, XP, true, false>(A, B, buf, tab, lane, mid);
+}
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1ts(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    fft512_pair1x<DIR, XP, false, true>(A, B, buf, tab, lane, mid);
+}
+
 // round half away from zero, then reduce mod 2^64 into the torus exactly as
 // PolynomialFftRef::ifft does (entities/polynomial_fft.rs:82-99 -> simd/scalar.rs:26-35,
 // 75-119 -> `x as i64` saturating, math/torus.rs:177-192).
@@ -804,14 +998,27 @@ __device__ __forceinline__ void torus_bits16(const double (&tv)[16], uint64_t (&
         for (int e = 0; e < 16; e++) t[e] = f64_round_to_torus(tv[e]);
     }
 }
+#ifndef SPF_UNTWIST_PRE
+#define SPF_UNTWIST_PRE 0
+#endif
 template <bool MANTISSA_FORM = false>
 __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64* twist_lds, uint64_t (&t)[16])
 {
     double tv[16];
+#if SPF_UNTWIST_PRE
+    c64 twf[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) twf[n1] = twist_lds[64 * n1];
+    compiler_fence();
+#endif
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) {
         c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+#if SPF_UNTWIST_PRE
+        c64 u = cmul_nf_conj(xs, twf[n1]);
+#else
         c64 u = cmul_nf_conj(xs, twist_lds[64 * n1]);
+#endif
         tv[n1] = u.re;
         tv[8 + n1] = u.im;
     }

@@ -127,7 +127,7 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 // two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
 #ifndef SPF_FFT_PAIR
-#define SPF_FFT_PAIR fft512_pair1
+#define SPF_FFT_PAIR fft512_pair1ts  // twiddles requested early and shared by the two transforms, stores spread (r04: 42.6 -> 39.9 ms per 4096)
 #endif
 #ifndef SPF_FFT_PAIR_P0   // polynomial 0's forward pair (the frequency-domain product is not live yet)
 #define SPF_FFT_PAIR_P0 SPF_FFT_PAIR
@@ -137,6 +137,12 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #endif
 #ifndef SPF_BR_OPT
 #define SPF_BR_OPT 14
+#endif
+#ifndef SPF_TWIST_PRE
+#define SPF_TWIST_PRE 0
+#endif
+#ifndef SPF_COMBINE_PRE
+#define SPF_COMBINE_PRE 0
 #endif
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
@@ -289,12 +295,27 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 }
             }
             c64 VV[2][8];
+#if SPF_TWIST_PRE
+            {
+                // the eight twist factors in one go (hipcc fetches them two at a time, each pair waited for on the spot)
+                c64 twf[8];
+#pragma unroll
+                for (int n1 = 0; n1 < 8; n1++) twf[n1] = twist[64 * n1];
+                compiler_fence();
+#pragma unroll
+                for (int n1 = 0; n1 < 8; n1++) {
+                    VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, twf[n1]);
+                    VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, twf[n1]);
+                }
+            }
+#else
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) {
                 const c64 tw = twist[64 * n1];
                 VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, tw);
                 VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, tw);
             }
+#endif
             STAMP(1);
             if (p == 0) SPF_PRIO_POINT(3);
             rendezvous_if_mixing(); // partner is done gathering from my region
@@ -332,6 +353,28 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             STAMP(4);
             if (p == 0) SPF_PRIO_POINT(6); else SPF_PRIO_POINT(12);
             // X[i] = E[i] + W^k O[i], X[i+4] = E[i] - W^k O[i]: wave 0 holds E and receives O, wave 1 the reverse
+#if SPF_COMBINE_PRE
+            {
+                // all eight cross values and the four cross twiddles requested at once behind the barrier
+                c64 xin[2][4], wcf[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) wcf[i] = wc[64 * i];
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
+                compiler_fence();
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const c64 Ei = w == 0 ? VV[j][i] : xin[j][i];
+                        const c64 t = cmul_tw<+1>(w == 0 ? xin[j][i] : VV[j][4 + i], wcf[i]);
+                        VV[j][i] = cadd(Ei, t);
+                        VV[j][i + 4] = csub(Ei, t);
+                    }
+            }
+#else
             if constexpr (w == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; j++)
@@ -354,11 +397,16 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                         VV[j][i + 4] = csub(Ei, t);
                     }
             }
+#endif
             STAMP(5);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const c64* row = reinterpret_cast<const c64*>(bskring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
+#ifdef SPF_MAD_KD
+                constexpr int KD = SPF_MAD_KD;
+#else
                 constexpr int KD = (OPT & 4) ? 2 : 3; // key pairs in flight (bit 2: two — 8 registers fewer across the MAD)
+#endif
                 c64 kb[KD][2];
                 auto key2 = [&](int grp, c64 (&dst)[2]) {
 #pragma unroll
@@ -368,7 +416,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     }
                 };
                 key2(0, kb[0]);
-                if constexpr (KD == 3) key2(1, kb[1]);
+                if constexpr (KD >= 3) key2(1, kb[1]);
+                if constexpr (KD >= 4) key2(2, kb[2]);
 #pragma unroll
                 for (int grp = 0; grp < 8; grp++) {
                     if (grp + KD - 1 < 8) key2(grp + KD - 1, kb[(grp + KD - 1) % KD]);
@@ -863,6 +912,12 @@ struct CmuxArgs {
 };
 constexpr int cmux_lds_bytes(int gates) { return kTableBytes + gates * kWaveBufBytes + 64; }
 
+#ifndef SPF_CMUX_INV_PAIR
+#define SPF_CMUX_INV_PAIR fft512_pair1
+#endif
+#ifndef SPF_CMUX_FWD_PRE
+#define SPF_CMUX_FWD_PRE 0
+#endif
 template <int L, int LOGB, int G, int W, bool STREAM>
 __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 {
@@ -998,7 +1053,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
         STAMPS_(2);
         if (m > 0) cmux_sync(); // partner is done with my last cross data
         STAMPS_(3);
-        fft512_single<+1>(V, mine, tab, lane);
+        fft512_single<+1, SPF_CMUX_FWD_PRE>(V, mine, tab, lane);
         STAMPS_(4);
         c64 Ei[4], Oi[4];
         if (w == 0) {
@@ -1110,7 +1165,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     }
     cmux_sync(); // both cross reads retired before either image is overwritten
     STAMPS_(9);
-    fft512_pair1<-1, 2>(WW[0], WW[1], mine, tab, lane);
+    SPF_CMUX_INV_PAIR<-1, 2>(WW[0], WW[1], mine, tab, lane);
     STAMPS_(10);
     // (the second polynomial's words only now: all 32 across the transform pair do not fit the registers, and a
     // spilled load waits for everything in flight; they land under the first polynomial's conversion)
