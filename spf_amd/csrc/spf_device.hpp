@@ -782,6 +782,33 @@ __device__ __forceinline__ void fft512_pair1t(c64 (&A)[8], c64 (&B)[8], char* bu
 // fft512_pair1t with (EARLY) the reads of an exchange issued right behind its own stores and / or (SPREAD) the stores of one
 // transform issued two at a time between the butterfly stages of the other — the combinations r04 measured after the
 // shared twiddles had removed the exposed table reads (profiles/r04_experiments_blind_rotate.md).
+// radix8_twr_spread with the stores packed into the three butterfly stages (3 + 3 + 2) and `after()` — the reads of the
+// transform just stored — issued behind the last store, ahead of the seven twiddle products: the butterfly temporaries are
+// dead there and the stored transform's registers are free, so the reads cost no registers and have the products to land under
+template <int DIR, class OP, class AFTER>
+__device__ __forceinline__ void radix8_twr_spread2(c64 (&X)[8], const c64 (&tw)[7], OP op, AFTER after)
+{
+    {
+        c64 s[4], t[4], u[8];
+        radix8_stage1<DIR>(X, s, t);
+        sched_fence();
+        op(0); op(1); op(2);
+        sched_fence();
+        radix8_stage2<DIR>(s, t, u);
+        sched_fence();
+        op(3); op(4); op(5);
+        sched_fence();
+        radix8_stage3<DIR>(X, u);
+    }
+    sched_fence();
+    op(6); op(7);
+    sched_fence();
+    after();
+    sched_fence();
+#pragma unroll
+    for (int k = 1; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
+    sched_fence();
+}
 template <int DIR, class OP>
 __device__ __forceinline__ void radix8_twr_spread(c64 (&X)[8], const c64 (&tw)[7], OP op)
 {
@@ -880,6 +907,47 @@ __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* bu
         radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
     }
     if constexpr (!EARLY || SPREAD) { load(A, rd2); sched_fence(); }
+    lane_transpose_hi3(B);
+    radix8<DIR>(A);
+    radix8<DIR>(B);
+    sched_fence();
+}
+// fft512_pair1ts with each exchange's reads issued inside the other transform's pass, right behind the last spread store
+template <int DIR, int XP = 2, class MID = no_hook>
+__device__ __forceinline__ void fft512_pair1ts2(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
+{
+    static_assert(XP == 2, "exchange 2 of B in registers");
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
+    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
+    const uint32_t wbase = 16 * (64 * hi3 + lo3);
+    char* wr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    auto store = [&](c64 (&X)[8], int k) { *reinterpret_cast<c64*>(wr[k]) = X[k]; };
+    auto load = [&](c64 (&X)[8], uint32_t rd) {
+#pragma unroll
+        for (int a = 0; a < 8; a++) X[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
+    };
+    c64 tw[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+    compiler_fence();
+    radix8<DIR>(A);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
+    sched_fence();
+    // pass 1 of B: A's exchange-1 stores in its butterflies, A's exchange-1 reads under its twiddle products
+    radix8_twr_spread2<DIR>(B, tw, [&](int k) { store(A, k); }, [&]() { load(A, rd1); });
+    // pass 2 of A: B's exchange-1 stores, then B's exchange-1 reads; T2 requested first
+    c64 tw2[7];
+#pragma unroll
+    for (int c = 0; c < 7; c++) tw2[c] = tab[kT2Off + c * 8 + hi3];
+    compiler_fence();
+    radix8_twr_spread2<DIR>(A, tw2, [&](int k) { store(B, k); }, [&]() { load(B, rd1); });
+    mid();
+    // pass 2 of B: A's exchange-2 stores, then A's exchange-2 reads
+    radix8_twr_spread2<DIR>(B, tw2, [&](int k) { store(A, k); }, [&]() { load(A, rd2); });
     lane_transpose_hi3(B);
     radix8<DIR>(A);
     radix8<DIR>(B);

@@ -126,14 +126,28 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
 // two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
 // everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
-#ifndef SPF_FFT_PAIR
-#define SPF_FFT_PAIR fft512_pair1ts  // twiddles requested early and shared by the two transforms, stores spread (r04: 42.6 -> 39.9 ms per 4096)
+// Which transform pair each of the three pairs of a step uses (spf_device.hpp; all give the same words), per instantiation:
+// E = even rotations (circuit bootstrap), M = mixing (plain PBS); 0 / 1 = polynomial 0's / 1's forward pair, I = the inverse pair.
+// All share the pass twiddles between the two transforms and spread the stores through the butterflies (r04: 42.6 -> 39.9 ms
+// per 4096); `…ts2` also issues an exchange's reads under the other transform's twiddle products — it pays where registers are
+// slack (39.8 -> 39.4 ms in the even instantiation with polynomial 1's pair left on `…ts`; the mixing one loses 0.2-0.5 ms with it).
+#ifndef SPF_PAIR_E0
+#define SPF_PAIR_E0 fft512_pair1ts2
 #endif
-#ifndef SPF_FFT_PAIR_P0   // polynomial 0's forward pair (the frequency-domain product is not live yet)
-#define SPF_FFT_PAIR_P0 SPF_FFT_PAIR
+#ifndef SPF_PAIR_E1
+#define SPF_PAIR_E1 fft512_pair1ts
 #endif
-#ifndef SPF_FFT_PAIR_INV  // the inverse pair (the product has just been consumed)
-#define SPF_FFT_PAIR_INV SPF_FFT_PAIR
+#ifndef SPF_PAIR_EI
+#define SPF_PAIR_EI fft512_pair1ts2
+#endif
+#ifndef SPF_PAIR_M0
+#define SPF_PAIR_M0 fft512_pair1ts
+#endif
+#ifndef SPF_PAIR_M1
+#define SPF_PAIR_M1 fft512_pair1ts
+#endif
+#ifndef SPF_PAIR_MI
+#define SPF_PAIR_MI fft512_pair1ts
 #endif
 #ifndef SPF_BR_OPT
 #define SPF_BR_OPT 14
@@ -325,8 +339,13 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             // (r03c: polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger)
             if (p == 0) SPF_PRIO_POINT(4); else SPF_PRIO_POINT(10);
             if (p == 1) ring_dma(chunk);
-            if (p == 0) SPF_FFT_PAIR_P0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
-            else SPF_FFT_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
+            if constexpr (MIX) {
+                if (p == 0) SPF_PAIR_M0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
+                else SPF_PAIR_M1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
+            } else {
+                if (p == 0) SPF_PAIR_E0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
+                else SPF_PAIR_E1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
+            }
             STAMP(3);
             if (p == 0) SPF_PRIO_POINT(5);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
@@ -527,7 +546,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             SPF_PRIO_POINT(14);
             if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
-        SPF_FFT_PAIR_INV<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+        if constexpr (MIX) SPF_PAIR_MI<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+        else SPF_PAIR_EI<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
         STAMP(9);
         SPF_PRIO_POINT(15);
 #pragma unroll

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned 
         else if constexpr (V == 8) fft512_pair1t<+1, 2>(A, B, buf, tab, lane);
         else if constexpr (V == 9) fft512_pair1t<+1, 1>(A, B, buf, tab, lane);
         else if constexpr (V == 10) fft512_pair1te<+1, 2>(A, B, buf, tab, lane);
-        else fft512_pair1ts<+1, 2>(A, B, buf, tab, lane);
+        else if constexpr (V == 11) fft512_pair1ts<+1, 2>(A, B, buf, tab, lane);
+        else fft512_pair1ts2<+1, 2>(A, B, buf, tab, lane);
         // keep magnitudes bounded (exact power-of-two scaling) and the emulated state live
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -249,11 +250,9 @@ int main(int argc, char** argv)
     run<4, 1>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
     run<5, 0>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
     run<5, 1>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
-    run<8, 1>("8 fft512_pair1t<+1,2> twiddles early + shared", d_tab, d_out, n_cu, iters);
-    run<10, 1>("10 fft512_pair1te: shared twiddles + early reads", d_tab, d_out, n_cu, iters);
     run<11, 1>("11 fft512_pair1ts: shared twiddles + spread stores", d_tab, d_out, n_cu, iters);
-    run<8, 1, 0, 0, 1>("8 twiddles early + shared", d_tab, d_out, n_cu, iters);
-    run<10, 1, 0, 0, 1>("10 shared twiddles + early reads", d_tab, d_out, n_cu, iters);
+    run<12, 1>("12 fft512_pair1ts2: + reads under the twiddle products", d_tab, d_out, n_cu, iters);
     run<11, 1, 0, 0, 1>("11 shared twiddles + spread stores", d_tab, d_out, n_cu, iters);
+    run<12, 1, 0, 0, 1>("12 + reads under the twiddle products", d_tab, d_out, n_cu, iters);
     return 0;
 }

@@ -6,7 +6,7 @@ set -o pipefail
 TAG=${1:-r03}
 export TMPDIR=/tmp
 ROOT=$PWD/gpurun_out/kprof_$TAG
-for CASE in "cmux 4096" "cmux 16384" "cmux 256" "keyswitch 4096" "cbs 4096" "pbs 64" "pbs 256" "pbs 512"; do
+for CASE in ${CASES:-"cmux 4096" "cmux 16384" "cmux 256" "keyswitch 4096" "cbs 4096" "pbsu 4096" "pbs 64" "pbs 256" "pbs 512" "pbsu 512" "pbsu 256"}; do
   set -- $CASE
   OUT=$ROOT/$1_$2
   mkdir -p $OUT
@@ -14,7 +14,7 @@ for CASE in "cmux 4096" "cmux 16384" "cmux 256" "keyswitch 4096" "cbs 4096" "pbs
   echo "$CMD" > $OUT/command.txt
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace failed: $CASE"; exit 1; }
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1 || exit 1
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || exit 1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || exit 1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1 || exit 1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1 || exit 1
   if [ "$1" = keyswitch ]; then

@@ -11,12 +11,19 @@ import glob
 import os
 import sys
 
-CLOCK_HZ = 2.39e9
+CLOCK_HZ = 2.39e9          # only where a case has no GRBM_GUI_ACTIVE pass (the cycles of the profiled dispatch = that counter / 8 XCDs)
 N_SIMD, N_CU = 1024, 256
 FP64_PEAK, HBM_PEAK, I8_PEAK = 78.6e12, 8.0e12, 5.0e15
 
 # algorithmic work per unit: what `achieved` is computed from
 GLWE, GGSW = 4096 * 8, 16384 * 16
+BSK, AK, SSK = 83492864, 2162688, 491520
+# algorithmic HBM bytes of the fp64-bound kernels per launch of B units: key read once + every unit's input and output
+ALG_BYTES = {
+    "blind_rotate": lambda B: BSK + B * (638 * 8 + GLWE),
+    "cbs_trace_kernel": lambda B: AK + B * (GLWE + 4 * GLWE),
+    "scheme_switch_kernel": lambda B: SSK + B * (4 * GLWE + GGSW),
+}
 WORK = {
     # kernel prefix: (bound, unit, work per unit, how many units a workgroup holds)
     "cmux_kernel": ("hbm", "CMUX", GGSW + 3 * GLWE, None),
@@ -76,7 +83,7 @@ def main():
                 for (k2, _), cc in cnt.items():
                     if k2 == k:
                         c = {n: sum(x) / len(x) for n, x in cc.items()}
-            cyc = ms * 1e-3 * CLOCK_HZ
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0 if c.get("GRBM_GUI_ACTIVE") else ms * 1e-3 * CLOCK_HZ
             f = lambda x: "—" if x is None else f"{x:.3f}"
             valu = c["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / cyc if "SQ_ACTIVE_INST_VALU" in c else None
             lds = c["SQ_LDS_IDX_ACTIVE"] / N_CU / cyc if "SQ_LDS_IDX_ACTIVE" in c else None
@@ -97,7 +104,10 @@ def main():
                     frac = f"{rate / peak:.3f}"
                     if bnd == "hbm":
                         alg = f"{work * units / 1e6:.1f} MB"
-            hb = "—" if hbm is None else (f"{hbm / 1e6:.1f} MB" + ("" if alg == "—" else f" vs {alg}"))
+                    elif pre in ALG_BYTES:
+                        alg = f"{ALG_BYTES[pre](units) / 1e6:.1f} MB"
+            hb = "—" if hbm is None else (f"{hbm / 1e6:.1f} MB (fetch x2 {c['FETCH_SIZE'] * 2048 / 1e6:.0f} + write {c.get('WRITE_SIZE', 0) * 1024 / 1e6:.0f})"
+                                          + ("" if alg == "—" else f" vs {alg}"))
             lines.append(f"| `{k[:56]}` | {grid} | {len(v)} | {ms:.4f} | {bound} | {ach} | {frac} | {hb} | {f(valu)} | {f(lds)} | {f(mfma)} | {f(wait)} | {f(stall)} |")
         lines.append("")
     os.makedirs("profiles", exist_ok=True)
