@@ -153,7 +153,10 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #define SPF_BR_OPT 14
 #endif
 #ifndef SPF_TWIST_PRE
-#define SPF_TWIST_PRE 0
+#define SPF_TWIST_PRE 1     // the eight twist factors of a polynomial requested at once ...
+#endif
+#ifndef SPF_GATHER_FENCE
+#define SPF_GATHER_FENCE 1  // ... and all sixteen rotation-gather reads out before the first is consumed (together −0.2 / −0.4 %)
 #endif
 #ifndef SPF_COMBINE_PRE
 #define SPF_COMBINE_PRE 0
@@ -299,7 +302,11 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
                     gin[e] = *reinterpret_cast<const uint64_t*>(region + ((t << 2) & 0x1FF8u));
                 }
+#if SPF_GATHER_FENCE
+                sched_fence(); // all sixteen reads out before the first is consumed (hipcc otherwise issues them four at a time)
+#else
                 compiler_fence();
+#endif
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;

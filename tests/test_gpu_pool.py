@@ -161,3 +161,28 @@ def test_mismatched_batches_raise(rig):
         eng.cmux(g, a, a)
     with pytest.raises(spf_amd.SpfError):
         eng.multiply_glwe_ggsw(a, g)
+
+
+def test_pool_survives_tickets_nobody_collects_in_time(rig):
+    """r04 pipeline: a batch's pinned staging set returns to the pool when all its tickets are collected.  Tickets nobody
+    waits for must not wedge it: with every set held by uncollected batches a further submit delivers the oldest batch's
+    outputs itself after the grace period and goes on; the late waits still return the right status, the outputs are in the
+    callers' buffers, and a pool destroyed with uncollected tickets cleans up."""
+    ks, eng = rig
+    P = ks.params
+    pool = spf_amd.Pool(eng, max_batch=2, max_wait_us=100)   # batches of two: three staging sets hold six tickets
+    pool.set_max_inflight(64)
+    n = 10
+    lwe1 = random_lwe_batch(31, n, P.N * P.k)
+    outs = [np.zeros(P.lwe_n + 1, dtype=np.uint64) for _ in range(n)]
+    tickets = [pool.submit_keyswitch(outs[i], lwe1[i]) for i in range(n)]   # nobody waits in between
+    exp = [O.keyswitch_lwe(lwe1[i], ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count) for i in range(n)]
+    for i in (0, 1, 2, 3):                                   # delivered on the submitters' behalf, or by these waits
+        pool.wait(tickets[i])
+    for i in range(n - 2):
+        if i >= 4:
+            pool.wait(tickets[i])
+        assert np.array_equal(outs[i], exp[i]), i
+    ops, launches = pool.stats()
+    assert ops >= n - 2 and launches >= (n - 2) // 2
+    pool.close()                                             # tickets n-2, n-1 never collected
