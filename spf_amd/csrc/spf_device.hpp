@@ -353,6 +353,8 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     for (int k1 = 1; k1 < 8; k1++) tw1[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
 #pragma unroll
     for (int c = 1; c < 8; c++) tw2[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
+    compiler_fence(); // all fourteen requested HERE (r04: without the fence hipcc sank them to their uses, two at a time, each
+                      // waited for on the spot — at one wave per SIMD every such round trip is lost time)
     // E pass 1 -> exchange-1 image
     radix8<DIR>(E);
 #pragma unroll

@@ -749,7 +749,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                 const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
                 gin[e] = *reinterpret_cast<const uint64_t*>(src + ((t << 2) & 0x1FF8u));
             }
-            compiler_fence();
+            sched_fence(); // all sixteen reads out before the first is consumed
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
@@ -783,7 +783,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(partner)[(j * 4 + i) * 64 + lane];
-            compiler_fence();
+            sched_fence();
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 c64 X[8];
@@ -824,6 +824,7 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int r = 0; r < 8; r++) X[j][r] = sx[(j * 8 + r) * 64];
+            sched_fence(); // the sixteen spectrum values of a row polynomial in one go (they were fetched two at a time)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -854,9 +855,13 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                 reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
             wg_barrier(); // 7
             if constexpr (!LAST) SPF_KEY_PIECE(2);
+            c64 in4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) in4[i] = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+            sched_fence();
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+                const c64 in = in4[i];
                 V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
                 V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
             }
@@ -1366,7 +1371,7 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(partner)[(j * 4 + i) * 64 + lane];
-        compiler_fence();
+        sched_fence();
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             c64 Y[8];
@@ -1400,26 +1405,34 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
     c64 V[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) V[r] = {0.0, 0.0};
+    {
+        // row polynomial p: my own transforms when p == h, the sibling's otherwise — both read back from LDS, so that the 128
+        // registers of X are free for the selector rows.  The eight spectrum values of row m + 1 are requested before the
+        // FMAs of row m (r04: hipcc fetched them two at a time, each pair waited for on the spot — at one wave per SIMD
+        // every such round trip is lost time).
+        auto row_src = [&](int m) { return reinterpret_cast<const c64*>(smem + kTableBytes + (((m / L) * 2 + w) * 32768)) + ((m % L) * 8) * 64 + lane; };
+        c64 sx[2][8];
 #pragma unroll
-    for (int p = 0; p < 2; p++)
+        for (int r = 0; r < 8; r++) sx[0][r] = row_src(0)[r * 64];
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-            // row polynomial p: my own transforms when p == h, the sibling's otherwise — both read back
-            // from LDS, so that the 128 registers of X are free for the selector rows
-            const char* src = smem + kTableBytes + ((p * 2 + w) * 32768);
-            c64 sx[8];
+        for (int m = 0; m < 2 * L; m++) {
+            const int p = m / L, j = m % L;
+            if (m + 1 < 2 * L) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) sx[r] = reinterpret_cast<const c64*>(src)[(j * 8 + r) * 64 + lane];
+                for (int r = 0; r < 8; r++) sx[(m + 1) & 1][r] = row_src(m + 1)[r * 64];
+            }
+            sched_fence();
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const c64 k = {p == 0 ? key0[j][r].re : key1[j][r].re, p == 0 ? key0[j][r].im : key1[j][r].im};
-                const c64 x = sx[r];
+                const c64 x = sx[m & 1][r];
                 double re = __builtin_fma(k.re, x.re, V[r].re);
                 double im = __builtin_fma(k.re, x.im, V[r].im);
                 V[r].re = __builtin_fma(-k.im, x.im, re);
                 V[r].im = __builtin_fma(k.im, x.re, im);
             }
         }
+    }
     STAMPC(5);
     wg_barrier(); // sibling reads retired; regions free again
 
@@ -1435,9 +1448,13 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
         for (int i = 0; i < 4; i++)
             reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
         wg_barrier();
+        c64 in4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) in4[i] = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+        sched_fence();
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const c64 in = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
+            const c64 in = in4[i];
             V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
             V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
         }
