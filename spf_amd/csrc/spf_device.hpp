@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c
     torus_bits16(tv, t);
 }
 
-// ---- pieces shared by the latency-shape kernels (blind_rotate2w / blind_rotate4 / cmux4) ----------
+// ---- pieces shared by the latency-shape kernels (blind_rotate8 / cmux4) ----------
 
 // RadixDecomposition of one torus word (math/radix.rs:81-113,157-162; simd/scalar.rs:52-71): round to
 // the top L*LOGB bits (add the bit below), then L digits, least significant first, each reduced to

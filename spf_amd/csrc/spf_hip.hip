@@ -233,14 +233,14 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
-    // Shape by batch size: at most one ciphertext per CU -> four waves per ciphertext (blind_rotate4_kernel, latency);
+    // Shape by batch size: at most one ciphertext per CU -> eight waves per ciphertext (blind_rotate8_kernel, latency);
     // up to two per CU -> the paired schedule with two ciphertexts per workgroup (blind_rotate2p2_kernel);
     // beyond -> four ciphertexts per workgroup, one workgroup per CU, two waves per SIMD (blind_rotate2p_kernel).
     const size_t n_cu = (size_t)c->n_cu;
     const bool quad = B <= n_cu;
     const bool pair2 = !quad && B <= 2 * n_cu;
     const size_t per_wg = quad ? 1 : (pair2 ? 2 : 4);
-    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block((quad || pair2) ? 256 : 512);
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(pair2 ? 256 : 512);
     TimedScope ts(c, s, T_PBS);
     {
         spf_status st = ts.begin();
@@ -248,7 +248,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     }
 #ifdef SPF_STAMPS
     static uint64_t* d_stamps = nullptr;
-    const size_t stamp_waves = quad ? 4 : 8;
+    const size_t stamp_waves = 8;
     const size_t n_stamp = (size_t)grid.x * stamp_waves * 16;
     if (!pair2) {
         if (d_stamps) (void)hipFree(d_stamps);
@@ -259,8 +259,8 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
 #endif
 #define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
     // log_v >= 1 makes every rotation amount even: the kernels then skip the hand-overs around the rotation gather (",even")
-    if (quad && log_v == 0) SPF_LAUNCH("blind_rotate4_kernel<2,16>", (blind_rotate4_kernel<2, 16, 1>), kBlindRotate4Lds);
-    else if (quad) SPF_LAUNCH("blind_rotate4_kernel<2,16,even>", (blind_rotate4_kernel<2, 16, 0>), kBlindRotate4Lds);
+    if (quad && log_v == 0) SPF_LAUNCH("blind_rotate8_kernel<2,16>", (blind_rotate8_kernel<2, 16, 1>), kBlindRotate8Lds);
+    else if (quad) SPF_LAUNCH("blind_rotate8_kernel<2,16,even>", (blind_rotate8_kernel<2, 16, 0>), kBlindRotate8Lds);
     else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14>", (blind_rotate2p2_kernel<2, 16, 14, 1>), kBlindRotate2p2Lds);
     else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14,even>", (blind_rotate2p2_kernel<2, 16, 14, 0>), kBlindRotate2p2Lds);
     else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16,14>", (blind_rotate2p_kernel<2, 16, 14, 1>), kBlindRotate2pLds);
@@ -279,9 +279,8 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         static const char* names[12] = {"stage+rendezvous", "gather+decomp+twist", "rendezvous(gathered) + key-row wait", "fwd transform pair",
             "cross write+key barrier", "cross read+combine", "MAD x2", "ring barrier", "inverse cross exchange",
             "inv transform pair", "untwist+convert+acc", "step head"};
-        static const char* names4[12] = {"key issue+stage+barrier1", "gather+decomp+twist", "barrier2", "fwd transform pair",
-            "cross write+barrier3", "cross read+combine", "barrier4+swap write+barrier5", "sibling read+MAD", "barriers6-8+inverse cross",
-            "inv transform", "untwist+convert+acc", "-"};
+        static const char* names8[12] = {"step head+stage", "barrier A (j=1: A+F)", "gather+decomp+post+F+twist", "fwd transform", "cross write+barrier B",
+            "cross read+combine+publish", "barrier C", "MAD+inverse split+post", "barrier D", "inbox read", "inv transform", "untwist+convert+acc"};
         double total = 0;
         std::vector<double> med(12), med_old(12), med_young(12);
         for (int i = 0; i < 12; i++) {
@@ -300,7 +299,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         }
         fprintf(stderr, "[stamps] per CMUX step, median over %zu waves (cycles, share | waves 0-3 | waves 4-7)\n", (size_t)grid.x * stamp_waves);
         for (int i = 0; i < 12; i++)
-            fprintf(stderr, "[stamps] %-30s %8.0f %5.1f%% | %8.0f | %8.0f\n", (quad ? names4 : names)[i], med[i], 100.0 * med[i] / total, med_old[i], med_young[i]);
+            fprintf(stderr, "[stamps] %-30s %8.0f %5.1f%% | %8.0f | %8.0f\n", (quad ? names8 : names)[i], med[i], 100.0 * med[i] / total, med_old[i], med_young[i]);
         fprintf(stderr, "[stamps] %-26s %8.0f\n", "total", total);
     }
 #endif
@@ -473,10 +472,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16, 1>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate4_kernel<2, 16, 0>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate4Lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate8_kernel<2, 16, 1>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate8Lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate8_kernel<2, 16, 0>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate8Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            cmux_lds_bytes(2)));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cmux_kernel<4, 4, 2>),

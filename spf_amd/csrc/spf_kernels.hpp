@@ -5,7 +5,7 @@
 // of DAG-I; the forward transform ends with, and the inverse starts with, an exchange between the two waves):
 //   blind_rotate2p_kernel   throughput shape: four ciphertexts per 512-thread workgroup, two waves per SIMD, key ring
 //   blind_rotate2p2_kernel  the same body with two ciphertexts per workgroup (one to two ciphertexts per CU)
-//   blind_rotate4_kernel    latency shape: four waves per ciphertext (parity x polynomial), at most one ciphertext per CU
+//   blind_rotate8_kernel    latency shape: eight waves per ciphertext (parity x polynomial x digit), at most one ciphertext per CU
 // and the CMUX-tree gates (cmux_kernel, cmux4_kernel), the int8-MFMA keyswitch, and the small streaming kernels.
 // Each wave keeps its share of the GLWE accumulator and of the frequency-domain product in registers for all n steps.
 // The bootstrapping key is read in the reference's own layout (natural DFT bin order): lane l touches bins l + 64 r,
@@ -622,42 +622,46 @@ __global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs
 }
 
 // ------------------------------------------------------------------------------------------
-// blind_rotate4_kernel: FOUR waves per ciphertext, one ciphertext per workgroup, one wave per SIMD —
-// the shape for batches of at most one ciphertext per CU (B <= #CU), where latency is all that
-// counts.  Wave (w, h): sample parity w (as in the two-wave kernels) and polynomial h.  The two
-// polynomials of a CMUX step are independent until the multiply-accumulate, so the pair h = 0 and
-// the pair h = 1 each rotate, decompose and transform ONE polynomial (both digits together,
-// `fft512_pair_pipelined`) at the same time, and each transforms ONE output polynomial back.  The accumulation
-//   prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q          (in this order, each term 4 FMAs)
-// stays the sequential chain the reference's `glwe_ggsw_mad` defines: the two pairs swap their
-// transforms through LDS and wave (w, h) then runs the whole chain of OUTPUT polynomial q = h (its
-// own transforms for the rows of polynomial h, the sibling's for the others).  Same operations in
-// the same order on every value: same words.  All hand-overs are s_barrier among the four waves
-// (four per step: staged, cross data out, spectra out, inverse cross data out — each LDS region has one
-// use per step, so nothing waits for "reads retired"); keys go straight from L2 into registers, requested
-// a step ahead.  The whole 160 KiB of LDS: twiddles, 4 x 2 exchange images, 4 staging / spectra regions.
-constexpr int kBlindRotate4Lds = kTableBytes + 4 * 2 * 8192 + 4 * 16384; // exchange images + staging / spectra regions
+// blind_rotate8_kernel: EIGHT waves per ciphertext, one ciphertext per workgroup — the latency shape, for batches of at
+// most one ciphertext per CU (B <= #CU).  Wave (w, h, j): sample parity w (as in the two-wave kernels), polynomial h,
+// gadget digit j; waves (w, h, 0) and (w, h, 1) are SIMD siblings.
+//
+// Until r04 the shape was four waves (parity x polynomial, `blind_rotate4_kernel`, now under
+// profiles/r04_experimental_sources/), each running BOTH digits' forward transforms: one wave per SIMD, and its stamps
+// said the step (15.1 k cycles) was latency.  Here the two polynomials of a CMUX step are still independent until the
+// multiply-accumulate, and in addition
+//   * the j = 0 wave, which owns the accumulator of (w, h), stages, gathers the rotation, subtracts and decomposes ONCE
+//     and hands digit 1 to its sibling as sixteen 16-bit fields (a version in which both waves decomposed was 1 % slower:
+//     between the staging barrier and the cross exchange the SIMD of a pair is busy, so duplicated work costs its time);
+//   * each wave twists and transforms ONE digit, the sibling the other at the same time;
+//   * the multiply-accumulate of output polynomial q = h is split by BINS between the two waves (registers {2j, 2j+1,
+//     2j+4, 2j+5}: the pairs the inverse split needs are in one wave); per bin it is the sequential chain the
+//     reference's `glwe_ggsw_mad` defines (p = 0: digits 0, 1; p = 1: digits 0, 1), and each wave fetches only its
+//     quarter of a key row (16 KiB per wave and step), requested a step ahead in four pieces;
+//   * the four waves of polynomial h post their E' / O' halves into the inboxes of the two j = 0 waves, which transform
+//     back, untwist, convert and accumulate; the j = 1 wave meanwhile requests its next key rows.
+// Same operations in the same order on every value as the other shapes: same words.  Hand-overs are s_barrier among the
+// eight waves, five per step (four when every rotation is even: staged [mixing only], digits out, cross data out, spectra
+// out, inverse halves out); each LDS region has one use per phase.  LDS: tables + eight 8 KiB exchange images + four
+// 16 KiB staging / spectra regions = 160 KiB.  Tried and not kept, both bit-equal: converting the real and the imaginary
+// halves in different waves (one more barrier: +3 %), raising the sibling's issue priority (the lag just changes sides).
+constexpr int kBlindRotate8Lds = kTableBytes + 8 * 8192 + 4 * 16384;
 
-template <int L, int LOGB, int W, int MIX = 1>
-__device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, char* smem)
+template <int L, int LOGB, int W, int J, int MIX>
+__device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, char* smem)
 {
-    static_assert(L == 2 && L * LOGB <= 32, "two digits, processed as a pair");
+    static_assert(L == 2 && L * LOGB <= 32, "two digits, one per wave of a pair");
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int w = W; // sample parity: compile-time (one copy of the body per parity), so that which half of a
-                         // cross exchange a wave keeps is static instead of ~160 v_cndmask per step
-    const int h = wv >> 1;
-    // region of wave (w, h): two 8 KiB images
-    auto region = [&](int ww, int hh) -> char* { return smem + kTableBytes + (hh * 2 + ww) * 16384; };
-    char* mine = region(w, h);
-    char* mineB = mine + 8192;
-    char* partner = region(w ^ 1, h); // same polynomial, other parity
-    // second region of wave (w, h), 16 KiB: its staged accumulator (rotation source) at the top of a step, its two
-    // transforms for the MADs later.  Having it apart from the exchange images is what lets a step do with four
-    // barriers instead of eight: no image is reused while someone may still read it.
-    auto spectra = [&](int ww, int hh) -> char* { return smem + kTableBytes + 4 * 16384 + (hh * 2 + ww) * 16384; };
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // = 4 j + 2 h + w
+    constexpr int w = W, j = J;
+    const int h = (wv >> 1) & 1;
+    auto image = [&](int ww, int hh, int jj) -> char* { return smem + kTableBytes + ((jj * 2 + hh) * 2 + ww) * 8192; };
+    char* mine = image(w, h, j);
+    char* partner = image(w ^ 1, h, j); // same polynomial and digit, other parity
+    // 16 KiB region of (w, h): the staged accumulator (rotation source) at the top of a step, the two digits' transforms later
+    auto spectra = [&](int ww, int hh) -> char* { return smem + kTableBytes + 8 * 8192 + (hh * 2 + ww) * 16384; };
     auto wg_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // not __syncthreads(): keep the key loads in flight
         __builtin_amdgcn_s_barrier();
@@ -666,15 +670,15 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
     {
         const double2* src = reinterpret_cast<const double2*>(a.tables);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 256) dst[i] = src[i];
+        for (int i = tid; i < kTableEntries; i += 512) dst[i] = src[i];
     }
     const uint32_t ct = blockIdx.x; // grid = B
     const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
     const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
 
-    uint64_t acc[16]; // polynomial h, parity w
-    {
+    uint64_t acc[16]; // polynomial h, parity w: lives in the j = 0 wave only
+    if constexpr (J == 0) {
         uint32_t bt = mod_switch_2n(lwe[a.n] + a.body_rotate, a.log_chi, a.log_v);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
@@ -685,62 +689,52 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
     }
     __syncthreads(); // twiddle image in place
 
-    c64 twist[8], wc[4];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) twist[n1] = tab[kTWOff + w * 512 + lane + 64 * n1];
-#pragma unroll
-    for (int i = 0; i < 4; i++) wc[i] = tab[kWCOff + 256 * w + lane + 64 * i];
+    // twist and cross-stage factors are read from the LDS tables where they are used: 256 registers per wave here
+    const c64* twist_lds = tab + kTWOff + w * 512 + lane;
+    const c64* wc_lds = tab + kWCOff + 256 * w + lane;
 
+    // this wave's bins (registers 2j, 2j+1, 2j+4, 2j+5) of OUTPUT polynomial h in the four key rows of a step:
+    // [row polynomial p][digit jj][q], q -> register 2j + (q & 1) + 4 (q >> 1).  Requested one row at a time, spread over the step.
+    c64 key[2][2][4];
+    const c64* key_base = a.bsk + h * kHalf + 256 * w + lane + 128 * j;
+    const c64* key_next = key_base;
+    auto request_keys = [&](auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        constexpr int p = piece >> 1, jj = piece & 1;
+        const c64* row = key_next + (size_t)(p * L + (L - 1 - jj)) * (2 * kHalf);
+#pragma unroll
+        for (int q = 0; q < 4; q++) key[p][jj][q] = row[64 * (q & 1) + 512 * (q >> 1)];
+    };
+#define SPF_KEY_PIECE(i) request_keys(std::integral_constant<int, i>{})
+    SPF_KEY_PIECE(0); SPF_KEY_PIECE(1); SPF_KEY_PIECE(2); SPF_KEY_PIECE(3);
+    uint64_t a_next = lwe[0];
 #ifdef SPF_STAMPS
     uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t st_prev = __builtin_amdgcn_s_memtime();
-#define STAMP4(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP8(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
 #else
-#define STAMP4(i) do { } while (0)
+#define STAMP8(i) do { } while (0)
 #endif
-    // this wave's bins of OUTPUT polynomial h in all four key rows of a step (levels consumed in reverse):
-    // [row polynomial p][digit j][r].  32 KiB per wave and step, 128 KiB per CU: about 4 500 cycles of the CU's
-    // L2 path (~30 B/clk), and a wave that asks for all of it in one place spends 2 000-3 000 cycles waiting to
-    // issue.  So the rows of step s+1 are requested in eight pieces of four loads, spread from behind the MADs
-    // of step s (which free the registers) to the transform of step s+1.
-    c64 key[2][2][8];
-    const c64* key_base = a.bsk + h * kHalf + 256 * w + lane;
-    const c64* key_next = key_base; // rows of the step whose pieces are being requested
-    auto request_keys = [&](auto piece_c) {
-        constexpr int piece = decltype(piece_c)::value;
-        constexpr int p = piece >> 2, j = (piece >> 1) & 1, r0 = 4 * (piece & 1);
-        const c64* row = key_next + (size_t)(p * L + (L - 1 - j)) * (2 * kHalf);
-#pragma unroll
-        for (int r = r0; r < r0 + 4; r++) key[p][j][r] = row[64 * (r & 3) + 512 * (r >> 2)];
-    };
-#define SPF_KEY_PIECE(i) request_keys(std::integral_constant<int, i>{})
-    SPF_KEY_PIECE(0); SPF_KEY_PIECE(1); SPF_KEY_PIECE(2); SPF_KEY_PIECE(3); SPF_KEY_PIECE(4);
-    uint64_t a_next = lwe[0];
-    // One CMUX step.  LAST = the final step, compiled as its own copy WITHOUT the requests for the next step's rows: until r03
-    // the last step re-requested its own rows (dead loads, drained behind the loop); a load nobody consumes is a write into a
-    // register the allocator considers free, and r03's persistent-CMUX experiment showed how such a kernel goes wrong one
-    // gate in a thousand — so no shipped kernel issues one any more.
+    // One CMUX step; LAST = the final one, compiled without the requests for a next step's rows (no dead loads)
     auto cmux_step = [&](uint32_t step, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
         const uint32_t at = mod_switch_2n(a_next, a.log_chi, a.log_v);
         a_next = lwe[step + 1];
-        SPF_KEY_PIECE(5);
-
-
-        // ---- rotate, subtract, decompose polynomial h
-        uint64_t* stage = reinterpret_cast<uint64_t*>(spectra(w, h));
+        // ---- rotate, subtract, decompose polynomial h: ONCE, in the j = 0 wave (the two waves of a pair share a SIMD, and between
+        // barriers A and B that SIMD has no issue slot to spare: a decomposition done twice costs its full time twice).  The j = 1
+        // wave gets its digits as 16-bit fields through its own (idle) exchange image.
+        c64 V[8];
+        uint4* digits1 = reinterpret_cast<uint4*>(image(w, h, 1));
+        if constexpr (J == 0) {
+            uint64_t* stage = reinterpret_cast<uint64_t*>(spectra(w, h));
 #pragma unroll
-        for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
-        // 1: both parities of both polynomials staged.  Not needed when every rotation amount is even (MIX = 0, log_v >= 1:
-        // an even rotation keeps the coefficient parity, the wave gathers only from the region it staged itself)
-        if constexpr (MIX) wg_barrier();
-        else compiler_fence();
-        STAMP4(0);
-        SPF_KEY_PIECE(6);
-        uint32_t dig[16];
-        {
-            // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024 for
-            // e >= 8): region (parity) and the low address bits do not depend on e
+            for (int e = 0; e < 16; e++) stage[(e >> 3) * 512 + (e & 7) * 64 + lane] = acc[e];
+            STAMP8(0);
+            // A: both parities staged.  Not needed when every rotation amount is even (MIX = 0): the wave then gathers only from
+            // the region it staged itself
+            if constexpr (MIX) wg_barrier();
+            else compiler_fence();
+            STAMP8(1);
             const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
             const char* src = spectra((int)(t0 & 1), h);
             uint64_t gin[16];
@@ -749,7 +743,11 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                 const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
                 gin[e] = *reinterpret_cast<const uint64_t*>(src + ((t << 2) & 0x1FF8u));
             }
-            sched_fence(); // all sixteen reads out before the first is consumed
+            c64 twist[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) twist[n1] = twist_lds[64 * n1];
+            sched_fence(); // all reads out before the first is consumed
+            uint32_t dig[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
@@ -757,164 +755,165 @@ __device__ __forceinline__ void blind_rotate4_body(const BlindRotateArgs& a, cha
                 const uint64_t rot = (gin[e] ^ sgn) - sgn;
                 dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[e]);
             }
+            static_assert(LOGB == 16, "digit 1 of the real and of the imaginary element share a 32-bit word");
+            uint32_t pk[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) pk[n1] = (dig[n1] >> 16) | (dig[8 + n1] & 0xFFFF0000u);
+            digits1[lane] = uint4{pk[0], pk[1], pk[2], pk[3]};
+            digits1[64 + lane] = uint4{pk[4], pk[5], pk[6], pk[7]};
+            wg_barrier(); // F: digits handed over
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) V[n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], 0, twist[n1]);
+        } else {
+            STAMP8(0);
+            if constexpr (MIX) wg_barrier(); // A
+            c64 twist[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) twist[n1] = twist_lds[64 * n1];
+            wg_barrier(); // F
+            STAMP8(1);
+            const uint4 lo = digits1[lane], hi = digits1[64 + lane];
+            const uint32_t pk[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++)
+                V[n1] = cmul_nf({(double)(((int)(pk[n1] << 16)) >> 16), (double)(((int)pk[n1]) >> 16)}, twist[n1]);
         }
-        c64 VV[2][8];
+        STAMP8(2);
+        fft512_single<+1, 7>(V, mine, tab, lane);
+        STAMP8(3);
+        // radix-2 stage across the parities
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) VV[j][n1] = twisted_digit<LOGB>(dig[n1], dig[8 + n1], j, twist[n1]);
-        SPF_KEY_PIECE(7);
-        STAMP4(1);
-        STAMP4(2);
-        fft512_pair_pipelined<+1>(VV[0], VV[1], mine, mineB, tab, lane);
-        STAMP4(3);
-        // radix-2 stage across the parities, both digits in one exchange
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = {w == 0 ? VV[j][4 + i].re : VV[j][i].re,
-                                                                         w == 0 ? VV[j][4 + i].im : VV[j][i].im};
-        wg_barrier(); // 3
-        STAMP4(4);
+        for (int i = 0; i < 4; i++)
+            reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? V[4 + i].re : V[i].re, w == 0 ? V[4 + i].im : V[i].im};
+        wg_barrier(); // B
+        STAMP8(4);
         {
-            c64 xin[2][4];
+            c64 xin[4], wc[4];
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 4; i++) xin[i] = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < 4; i++) xin[j][i] = reinterpret_cast<const c64*>(partner)[(j * 4 + i) * 64 + lane];
+            for (int i = 0; i < 4; i++) wc[i] = wc_lds[64 * i];
+            sched_fence();
+            c64 X[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c64 in = xin[i];
+                const c64 Ei = {w == 0 ? V[i].re : in.re, w == 0 ? V[i].im : in.im};
+                const c64 Oi = {w == 0 ? in.re : V[4 + i].re, w == 0 ? in.im : V[4 + i].im};
+                c64 t = cmul_tw<+1>(Oi, wc[i]);
+                X[i] = cadd(Ei, t);
+                X[i + 4] = csub(Ei, t);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(spectra(w, h))[(j * 8 + r) * 64 + lane] = X[r];
+        }
+        STAMP8(5);
+        wg_barrier(); // C: all four transforms of parity w are in the regions (the gathers from them ended before B)
+
+        STAMP8(6);
+        // ---- multiply-accumulate, this wave's four bins of output polynomial h, chain order of glwe_ggsw_mad
+        c64 P[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) P[q] = {0.0, 0.0};
+        {
+            c64 X[2][2][4];
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        X[p][jj][q] = reinterpret_cast<const c64*>(spectra(w, p))[(jj * 8 + 2 * j + (q & 1) + 4 * (q >> 1)) * 64 + lane];
             sched_fence();
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                c64 X[8];
+            for (int p = 0; p < 2; p++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const c64 in = xin[j][i];
-                    const c64 Ei = {w == 0 ? VV[j][i].re : in.re, w == 0 ? VV[j][i].im : in.im};
-                    const c64 Oi = {w == 0 ? in.re : VV[j][4 + i].re, w == 0 ? in.im : VV[j][4 + i].im};
-                    c64 t = cmul_tw<+1>(Oi, wc[i]);
-                    X[i] = cadd(Ei, t);
-                    X[i + 4] = csub(Ei, t);
-                }
+                for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-                for (int r = 0; r < 8; r++) VV[j][r] = X[r];
-            }
-        }
-        STAMP4(5);
-
-        // ---- multiply-accumulate.  prod[q] = X00 K00q + X01 K01q + X10 K10q + X11 K11q, in this
-        // order (glwe_ggsw_mad): the two pairs swap their transforms through LDS, then wave (w, h)
-        // runs the whole chain of output polynomial q = h.
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) reinterpret_cast<c64*>(spectra(w, h))[(j * 8 + r) * 64 + lane] = VV[j][r];
-        wg_barrier(); // 5: every wave's two transforms are in its region (the gathers from it ended before barrier 3)
-        STAMP4(6);
-        c64 V[8]; // prod[h]
-#pragma unroll
-        for (int r = 0; r < 8; r++) V[r] = {0.0, 0.0};
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            // row polynomial p: this wave's own transforms when p == h, the sibling's otherwise — both read back
-            // from LDS (16 more ds_read_b128 instead of 128 v_cndmask per step)
-            const c64* sx = reinterpret_cast<const c64*>(spectra(w, p)) + lane;
-            c64 X[2][8];
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) X[j][r] = sx[(j * 8 + r) * 64];
-            sched_fence(); // the sixteen spectrum values of a row polynomial in one go (they were fetched two at a time)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const c64 k = key[p][j][r];
-                    const c64 x = X[j][r];
-                    double re = __builtin_fma(k.re, x.re, V[r].re);
-                    double im = __builtin_fma(k.re, x.im, V[r].im);
-                    V[r].re = __builtin_fma(-k.im, x.im, re);
-                    V[r].im = __builtin_fma(k.im, x.re, im);
-                }
+                    for (int q = 0; q < 4; q++) {
+                        const c64 k = key[p][jj][q];
+                        const c64 x = X[p][jj][q];
+                        double re = __builtin_fma(k.re, x.re, P[q].re);
+                        double im = __builtin_fma(k.re, x.im, P[q].im);
+                        P[q].re = __builtin_fma(-k.im, x.im, re);
+                        P[q].im = __builtin_fma(k.im, x.re, im);
+                    }
         }
         key_next = key_base + (size_t)(step + 1) * (2 * L) * (2 * kHalf);
         if constexpr (!LAST) SPF_KEY_PIECE(0);
-        STAMP4(7);
-        if constexpr (!LAST) SPF_KEY_PIECE(1);
-
-        // ---- polynomial h back to the torus
-        {
-            c64 Ep[4], Op[4];
+        // ---- inverse split; every wave posts its two E' and two O' values into the inboxes of the two waves that transform
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                Ep[i] = cadd(V[i], V[i + 4]);
-                Op[i] = cmul_tw<-1>(csub(V[i], V[i + 4]), wc[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                reinterpret_cast<c64*>(mine)[i * 64 + lane] = {w == 0 ? Op[i].re : Ep[i].re, w == 0 ? Op[i].im : Ep[i].im};
-            wg_barrier(); // 7
-            if constexpr (!LAST) SPF_KEY_PIECE(2);
-            c64 in4[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) in4[i] = reinterpret_cast<const c64*>(partner)[i * 64 + lane];
-            sched_fence();
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const c64 in = in4[i];
-                V[i] = {w == 0 ? Ep[i].re : in.re, w == 0 ? Ep[i].im : in.im};
-                V[4 + i] = {w == 0 ? in.re : Op[i].re, w == 0 ? in.im : Op[i].im};
-            }
+        for (int i = 0; i < 2; i++) {
+            const c64 Ep = cadd(P[i], P[2 + i]);
+            const c64 Op = cmul_tw<-1>(csub(P[i], P[2 + i]), wc_lds[64 * (2 * j + i)]);
+            reinterpret_cast<c64*>(image(0, h, 0))[(w * 4 + 2 * j + i) * 64 + lane] = Ep;
+            reinterpret_cast<c64*>(image(1, h, 0))[(w * 4 + 2 * j + i) * 64 + lane] = Op;
         }
-        STAMP4(8);
-        if constexpr (!LAST) SPF_KEY_PIECE(3);
-        fft512_single<-1, 7>(V, mineB, tab, lane); // image B: the partner may still be reading the cross data in A
-        STAMP4(9);
-        if constexpr (!LAST) SPF_KEY_PIECE(4);
-        {
+        STAMP8(7);
+        wg_barrier(); // D
+        STAMP8(8);
+        if constexpr (!LAST) SPF_KEY_PIECE(1);
+        if constexpr (J == 0) {
+            c64 U[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) U[r] = reinterpret_cast<const c64*>(mine)[r * 64 + lane];
+            sched_fence();
+            if constexpr (!LAST) SPF_KEY_PIECE(2);
+            STAMP8(9);
+            fft512_single<-1, 7>(U, mine, tab, lane); // its exchanges follow the inbox reads in this wave's own LDS queue
+            STAMP8(10);
+            if constexpr (!LAST) SPF_KEY_PIECE(3);
             uint64_t t[16];
-            untwist_to_torus_bits(V, twist, t);
+            untwist_to_torus_bits(U, twist_lds, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] += t[e];
+            STAMP8(11);
+        } else {
+            if constexpr (!LAST) { SPF_KEY_PIECE(2); SPF_KEY_PIECE(3); }
         }
-        STAMP4(10);
-        // the next step's staging writes this wave's own image A, which nobody reads after barrier 8
     };
     for (uint32_t step = 0; step + 1 < a.n; step++) cmux_step(step, std::false_type{});
     cmux_step(a.n - 1, std::true_type{});
-
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + i] = st_acc[i];
+        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * 8 + wv) * 16 + i] = st_acc[i];
     }
 #endif
-#undef STAMP4
+#undef STAMP8
 #undef SPF_KEY_PIECE
-    uint64_t* out = a.out + (size_t)ct * a.out_stride;
-    if (!a.sample_extract) {
+    if constexpr (J == 0) {
+        uint64_t* out = a.out + (size_t)ct * a.out_stride;
+        if (!a.sample_extract) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) out[h * kN + coef2(e)] = acc[e];
-    } else {
+            for (int e = 0; e < 16; e++) out[h * kN + coef2(e)] = acc[e];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            int c = coef2(e);
-            if (h == 0) {
-                if (c == 0) out[0] = acc[e]; else out[kN - c] = (uint64_t)0 - acc[e];
-            } else if (c == 0) {
-                out[kN] = acc[e];
+            for (int e = 0; e < 16; e++) {
+                int c = coef2(e);
+                if (h == 0) {
+                    if (c == 0) out[0] = acc[e]; else out[kN - c] = (uint64_t)0 - acc[e];
+                } else if (c == 0) {
+                    out[kN] = acc[e];
+                }
             }
         }
     }
 }
 
-// one copy of the body per sample parity (see blind_rotate2p_kernel)
+// one copy of the body per (parity, digit)
 template <int L, int LOGB, int MIX = 1>
-__global__ __launch_bounds__(256, 1) void blind_rotate4_kernel(BlindRotateArgs a)
+__global__ __launch_bounds__(512) void blind_rotate8_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate4_body<L, LOGB, 1, MIX>(a, smem);
-    else blind_rotate4_body<L, LOGB, 0, MIX>(a, smem);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv >> 2) {
+        if (wv & 1) blind_rotate8_body<L, LOGB, 1, 1, MIX>(a, smem);
+        else blind_rotate8_body<L, LOGB, 0, 1, MIX>(a, smem);
+    } else {
+        if (wv & 1) blind_rotate8_body<L, LOGB, 1, 0, MIX>(a, smem);
+        else blind_rotate8_body<L, LOGB, 0, 0, MIX>(a, smem);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1235,7 +1234,7 @@ __global__ __launch_bounds__(128 * G, 2) void cmux_kernel(CmuxArgs a)
 // ------------------------------------------------------------------------------------------
 // cmux4_kernel: the LATENCY shape of cmux_kernel — four waves per gate, one gate per workgroup, for
 // the levels of a gate graph that hold at most one gate per CU (a ripple-carry chain is 1-4 gates per
-// level, and its depth, not its width, is what a run waits for).  Same split as blind_rotate4_kernel:
+// level, and its depth, not its width, is what a run waits for).  Four waves per ciphertext (parity x polynomial):
 // wave (w, h) = sample parity w x polynomial h.  Each pair of waves decomposes ONE polynomial of
 // d1 - d0 and pushes its four digits through two `fft512_pair_pipelined`s; the pairs then publish their four
 // transforms in LDS and wave (w, h) runs the whole accumulation chain of OUTPUT polynomial h over the
@@ -1254,7 +1253,7 @@ __device__ __forceinline__ void cmux4_body(const CmuxArgs& a, char* smem)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int w = W; // sample parity: one copy of the body per parity (see blind_rotate4_kernel)
+    constexpr int w = W; // sample parity: one copy of the body per parity (see blind_rotate2p_kernel)
     const int h = wv >> 1;
 #ifdef SPF_STAMPS
     uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

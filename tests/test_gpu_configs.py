@@ -156,7 +156,7 @@ def test_config2_batch_4096_pbs_univariate_every_ciphertext(full, plain_pbs_4096
 
 def test_config2_plain_pbs_512_and_ragged_1031(full, plain_pbs_4096):
     """The same ciphertexts through the two-ciphertexts-per-workgroup shape (B = 512: `blind_rotate2p2_kernel<2,16,14>`,
-    every output against the oracle), the four-wave latency shape (B = 200) and a ragged throughput launch (B = 1031 =
+    every output against the oracle), the latency shape (B = 200) and a ragged throughput launch (B = 1031 =
     257 workgroups of four + 3)."""
     ks, eng = full
     lwe, lut, exp = plain_pbs_4096
@@ -164,7 +164,7 @@ def test_config2_plain_pbs_512_and_ragged_1031(full, plain_pbs_4096):
     assert eng.last_blind_rotate_kernel() == "blind_rotate2p2_kernel<2,16,14>"
     assert np.array_equal(got, exp[:512])
     got = eng.generalized_pbs(lwe[3000:3200], lut, 0, 0, 0)
-    assert eng.last_blind_rotate_kernel() == "blind_rotate4_kernel<2,16>"
+    assert eng.last_blind_rotate_kernel() == "blind_rotate8_kernel<2,16>"
     assert np.array_equal(got, exp[3000:3200])
     got = dev_bootstrap(eng, lwe[1000:2031], lut, 0, 0, 0)        # one launch: 257 workgroups of four + 3
     assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,14>"

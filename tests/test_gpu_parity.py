@@ -113,14 +113,21 @@ def test_saturating_cast_quirk_is_reproduced():
     assert np.array_equal(got[0], exp)
 
 
-# ---- the same edge vectors through EVERY blind-rotation body.  The two tests above run B = 4 / B = 1, i.e. the four-wave
+# ---- the same edge vectors through EVERY blind-rotation body.  The two tests above run B = 4 / B = 1, i.e. the
 # latency kernel only; the throughput bodies (`blind_rotate2p_body`, four or two ciphertexts per workgroup, each in an
 # even-rotation and a mixing instantiation) have their own conversion fast path / fallback (`torus_bits16`), their own
 # gather hand-overs and their own ragged tail.  One launch per batch (device-pointer entry points).
 
-EDGE_BATCHES = [1030, 600, 400, 100]   # 2p ragged, 2p, 2p2, four-wave
-EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,14", 600: "blind_rotate2p_kernel<2,16,14",
-               400: "blind_rotate2p2_kernel<2,16,14", 100: "blind_rotate4_kernel<2,16"}
+EDGE_BATCHES = [1030, 600, 400, 100]   # 2p ragged, 2p, 2p2, eight-wave latency shape
+_EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,14", 600: "blind_rotate2p_kernel<2,16,14",
+                400: "blind_rotate2p2_kernel<2,16,14"}
+
+
+def _edge_kernel(B, even):
+    """the kernel a batch of B must have gone to (the latency shape has one instantiation for both rotation kinds)"""
+    if B not in _EDGE_KERNEL:
+        return "blind_rotate8_kernel<2,16" + (",even>" if even else ">")
+    return _EDGE_KERNEL[B] + (",even>" if even else ">")
 
 
 def _edge_lwe(B, n):
@@ -148,7 +155,7 @@ def test_identity_steps_and_extreme_words_every_shape(small, B):
     lwe = _edge_lwe(B, SMALL_N)
     # even rotations (log_v = 2, the circuit bootstrap) ...
     got = dev_bootstrap(eng, lwe)
-    assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + ",even>"
+    assert eng.last_blind_rotate_kernel() == _edge_kernel(B, True)
     rot = lwe.copy()
     rot[:, -1] += np.uint64(1 << 62)
     _, exp = O.bench_generalized_pbs(rot, O.fill_cbs_lut(P), ks.bsk_fft, P, 8, 0, 2)
@@ -157,7 +164,7 @@ def test_identity_steps_and_extreme_words_every_shape(small, B):
     # ... and mixing ones (log_v = 0, the plain PBS), with a LUT per ciphertext
     luts = random_glwe(0xED6F, B, P.glwe_len)
     got = dev_bootstrap(eng, lwe, luts, 0, 0, 0)
-    assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + ">"
+    assert eng.last_blind_rotate_kernel() == _edge_kernel(B, False)
     _, exp = O.bench_generalized_pbs(lwe, luts, ks.bsk_fft, P, 8, 0, 0)
     bad = np.nonzero((got != exp).any(axis=1))[0]
     assert bad.size == 0, f"mixing: {bad.size} ciphertexts differ, first {bad[:8]}"
@@ -205,7 +212,7 @@ def test_saturating_cast_quirk_every_shape(B, key_const, label):
         if log_v:
             _, exp = O.bench_generalized_pbs(lwe, luts, bsk, P, 8, 0, log_v)
         got = dev_bootstrap(eng, lwe, luts, 0, log_v, 0)
-        assert eng.last_blind_rotate_kernel() == EDGE_KERNEL[B] + (",even>" if log_v else ">")
+        assert eng.last_blind_rotate_kernel() == _edge_kernel(B, bool(log_v))
         bad = np.nonzero((got != exp).any(axis=1))[0]
         assert bad.size == 0, f"{label}, log_v {log_v}: {bad.size} ciphertexts differ, first {bad[:8]}"
 
