@@ -80,7 +80,12 @@ const char *spf_last_error(const spf_ctx *ctx);
 /* ---- keys: `ComputeKey` fields (crypto/keys.rs:306-318) ------------------------------- */
 
 /* `ComputeKey::bs_key` : BootstrapKeyFft<Complex<f64>>.  n_complex must equal
- * lwe_dimension * (k+1)*l_pbs*(k+1)*N/2.  Host pointer; copied to HBM. */
+ * lwe_dimension * (k+1)*l_pbs*(k+1)*N/2.  Host pointer; copied to HBM.  The engine also keeps a copy
+ * scaled by 2^-10 for its blind-rotation kernels (the inverse transform's 1/N travels with the key: exact
+ * for every spectrum a torus polynomial has, results unchanged), so a key holding a NaN or a non-zero
+ * magnitude outside [2^-900, 2^1000) — which no forward transform produces — is refused with
+ * SPF_ERR_INVALID_ARGUMENT here and in spf_key_blob_commit(ctx, 0), and leaves the context without a
+ * bootstrap key. */
 spf_status spf_load_bootstrap_key(spf_ctx *ctx, const double *bsk_fft, size_t n_complex);
 /* `ComputeKey::ks_key` : LweKeyswitchKey<u64>.  n_words = k*N * l_ks * (lwe_dimension+1). */
 spf_status spf_load_keyswitch_key(spf_ctx *ctx, const uint64_t *ksk, size_t n_words);

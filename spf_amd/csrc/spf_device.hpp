@@ -1071,7 +1071,10 @@ __device__ __forceinline__ void torus_bits16(const double (&tv)[16], uint64_t (&
 #ifndef SPF_UNTWIST_PRE
 #define SPF_UNTWIST_PRE 0
 #endif
-template <bool MANTISSA_FORM = false>
+// PRESCALED: the 1/1024 of the inverse transform is already in V — the blind-rotation kernels multiply with a bootstrap key
+// whose device image carries it (`scale_bootstrap_key_kernel`); a power of two commutes with every rounding on the way, so the
+// words are the same and 32 multiplications per polynomial are not executed
+template <bool MANTISSA_FORM = false, bool PRESCALED = false>
 __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64* twist_lds, uint64_t (&t)[16])
 {
     double tv[16];
@@ -1083,7 +1086,8 @@ __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c
 #endif
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) {
-        c64 xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        c64 xs = V[n1];
+        if constexpr (!PRESCALED) xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
 #if SPF_UNTWIST_PRE
         c64 u = cmul_nf_conj(xs, twf[n1]);
 #else

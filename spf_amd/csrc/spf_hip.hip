@@ -51,7 +51,8 @@ struct spf_ctx {
     std::string err;               // last error message; guarded by err_mu (read and written from any thread)
     mutable std::mutex err_mu;
     c64* d_tables = nullptr;
-    c64* d_bsk = nullptr;
+    c64* d_bsk = nullptr;        // the caller's spectra (what spf_key_blob hands out and a broadcast replicates)
+    c64* d_bsk_scaled = nullptr; // the same times 2^-10: what the blind-rotation kernels read (finish_bootstrap_key)
     size_t bsk_bytes = 0;
     bool bsk_ready = false;
     uint64_t* d_ksk = nullptr;
@@ -229,7 +230,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     // modulus switch needs log_modulus - log_v >= 1 and shifts below 64
     if (log_v >= 12 || log_chi >= 52) return fail(c, SPF_ERR_INVALID_ARGUMENT, "log_v / log_chi out of range");
     BlindRotateArgs a{};
-    a.lwe_in = d_lwe; a.lut = d_lut; a.lut_stride = lut_stride; a.bsk = c->d_bsk;
+    a.lwe_in = d_lwe; a.lut = d_lut; a.lut_stride = lut_stride; a.bsk = SPF_BSK_PRESCALED ? c->d_bsk_scaled : c->d_bsk;
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
     a.n = c->prm.lwe_dimension; a.B = (uint32_t)B; a.log_chi = log_chi; a.log_v = log_v;
     a.body_rotate = body_rotate; a.sample_extract = extract ? 1u : 0u;
@@ -498,7 +499,7 @@ void spf_destroy(spf_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& v : c->timed)
         for (auto& t : v) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_ksk, (void*)c->d_cbs_lut,
+    for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_bsk_scaled, (void*)c->d_ksk, (void*)c->d_cbs_lut,
                     c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->ks_dig.p,
                     c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
         if (p) (void)hipFree(p);
@@ -507,6 +508,33 @@ void spf_destroy(spf_ctx* c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
     delete c;
+}
+
+// The blind-rotation kernels read a copy of the bootstrap key scaled by 2^-10 (the 1/N of the inverse transform travels with
+// the key through the multiply-accumulate: exact, and 32 multiplications per polynomial and step are not executed).  Built
+// whenever the caller's image is complete; a value no forward transform of a torus polynomial produces (NaN, non-zero magnitude
+// outside [2^-900, 2^1000)), where scaling first could round differently from scaling last, makes the key unusable instead.
+static spf_status finish_bootstrap_key(spf_ctx* c)
+{
+#if SPF_BSK_PRESCALED
+    c->bsk_ready = false;
+    const size_t n_complex = (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count);
+    if (!c->d_bsk_scaled) HIPCHK(c, hipMalloc((void**)&c->d_bsk_scaled, n_complex * sizeof(c64)));
+    spf_status st = ensure(c, c->aux, sizeof(unsigned int));
+    if (st != SPF_OK) return st;
+    unsigned int* d_bad = (unsigned int*)c->aux.p;
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(scale_bootstrap_key_kernel, dim3(4 * (unsigned)c->n_cu), dim3(256), 0, c->stream,
+                       (const double*)c->d_bsk, (double*)c->d_bsk_scaled, 2 * n_complex, d_bad);
+    HIPCHK(c, hipGetLastError());
+    unsigned int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad)
+        return fail(c, SPF_ERR_INVALID_ARGUMENT,
+                    "bootstrap key holds a value that is no forward transform of a torus polynomial (NaN, or a non-zero magnitude outside [2^-900, 2^1000))");
+#endif
+    return SPF_OK;
 }
 
 spf_status spf_key_blob(spf_ctx* c, int which, void** dev_ptr, size_t* bytes)
@@ -541,7 +569,11 @@ spf_status spf_key_blob_commit(spf_ctx* c, int which)
     if (!c) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null context");
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device)); // the byte planes are allocated and built on THIS context's GPU
-    if (which == 0 && c->d_bsk) c->bsk_ready = true, c->ggsw_const_ready = false;
+    if (which == 0 && c->d_bsk) {
+        spf_status st = finish_bootstrap_key(c);
+        if (st != SPF_OK) return st;
+        c->bsk_ready = true, c->ggsw_const_ready = false;
+    }
     else if (which == 1 && c->d_ksk) {
         spf_status st = build_ks_planes(c);
         if (st != SPF_OK) return st;
@@ -563,7 +595,13 @@ spf_status spf_load_bootstrap_key(spf_ctx* c, const double* bsk_fft, size_t n_co
     spf_status s = spf_key_blob(c, 0, &p, &bytes);
     if (s != SPF_OK) return s;
     std::lock_guard<std::recursive_mutex> g(c->mu);
+    c->bsk_ready = false;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(p, bsk_fft, bytes, hipMemcpyHostToDevice));
+    {
+        spf_status st = finish_bootstrap_key(c);
+        if (st != SPF_OK) return st;
+    }
     c->bsk_ready = true, c->ggsw_const_ready = false;
     return SPF_OK;
 }

@@ -152,6 +152,9 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #ifndef SPF_BR_OPT
 #define SPF_BR_OPT 14
 #endif
+#ifndef SPF_BSK_PRESCALED
+#define SPF_BSK_PRESCALED 1 // the device image of the bootstrap key carries the inverse transform's 1/1024 (scale_bootstrap_key_kernel)
+#endif
 #ifndef SPF_TWIST_PRE
 #define SPF_TWIST_PRE 1     // the eight twist factors of a polynomial requested at once ...
 #endif
@@ -560,7 +563,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             uint64_t t[16];
-            untwist_to_torus_bits(WW[q], twist, t);
+            untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(WW[q], twist, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[q][e] += t[e];
             if (q == 0) SPF_PRIO_POINT(16);
@@ -619,6 +622,24 @@ __global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 2, MIX>(a, smem);
     else blind_rotate2p_body<L, LOGB, OPT, 0, 2, MIX>(a, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// scale_bootstrap_key_kernel: the blind-rotation kernels read the caller's bootstrap-key spectra times 2^-10, so that the product
+// spectra come out of the multiply-accumulate already carrying the 1/N of the inverse transform (N/2 = 1024 complex points).
+// Exact for every value a forward transform of a torus polynomial can produce; `bad` is raised for a non-zero magnitude
+// outside [2^-900, 2^1000) (or a NaN), where scaling first could round differently from scaling last — such a key is refused
+// at load time instead of being bootstrapped with differently.
+__global__ void scale_bootstrap_key_kernel(const double* key, double* scaled, size_t n, unsigned int* bad)
+{
+    bool flagged = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = key[i];
+        const double m = __builtin_fabs(v);
+        if (!(m == 0.0 || (m >= 0x1p-900 && m < 0x1p1000))) flagged = true;
+        scaled[i] = v * 0x1p-10;
+    }
+    if (flagged) atomicOr(bad, 1u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -864,7 +885,7 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
             STAMP8(10);
             if constexpr (!LAST) SPF_KEY_PIECE(3);
             uint64_t t[16];
-            untwist_to_torus_bits(U, twist_lds, t);
+            untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(U, twist_lds, t);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] += t[e];
             STAMP8(11);

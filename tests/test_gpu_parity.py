@@ -266,6 +266,25 @@ def test_empty_batch_and_bad_arguments(small):
         eng2.circuit_bootstrap_pbs(np.zeros((1, SMALL_N + 1), dtype=np.uint64))
 
 
+@pytest.mark.parametrize("value", [float("nan"), 5e-324, 2.0 ** -901, 2.0 ** 1000, float("inf")])
+def test_bootstrap_key_no_transform_could_produce_is_refused(small, value):
+    """The blind-rotation kernels read the key times 2^-10 (the inverse transform's 1/N rides through the multiply-accumulate:
+    exact for every spectrum a torus polynomial has).  A value where scaling first could round differently from scaling last
+    is refused at load time, the engine does not bootstrap with it; a good key afterwards works again."""
+    ks, _ = small
+    eng = spf_amd.Engine(to_engine_params(ks.params))
+    bad = ks.bsk_fft.copy()
+    bad.reshape(-1)[12345] = complex(1.0, value)
+    with pytest.raises(spf_amd.SpfError, match="forward transform"):
+        eng.load_bootstrap_key(bad)
+    lwe = random_lwe_batch(77, 3, SMALL_N)
+    with pytest.raises(spf_amd.SpfError):
+        eng.circuit_bootstrap_pbs(lwe)
+    eng.load_bootstrap_key(ks.bsk_fft)
+    exp = np.stack([O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params) for i in range(3)])
+    assert np.array_equal(eng.circuit_bootstrap_pbs(lwe), exp)
+
+
 def test_evaluation_mirror_writes_outputs(small):
     ks, _ = small
     P = ks.params
