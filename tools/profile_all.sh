@@ -8,9 +8,13 @@ ARGS=${3---no-extras}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# the kernel trace times the bench's own default run (20 timed steps behind 5 warm-up steps: the first launches of a process
+# run 3-5 % slower); the counter passes, which serialise and slow the kernels anyway, take two steps
+TRACE_CMD="python3 bench.py --steps 20 --warmup 5 --batch $BATCH --no-cpu-baseline --no-live-counters $ARGS"
 CMD="python3 bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline --no-live-counters $ARGS"
-echo "$CMD" > $OUT/command.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+echo "trace: $TRACE_CMD" > $OUT/command.txt
+echo "pmc:   $CMD" >> $OUT/command.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE_CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 echo "pmc1 rc=$?"

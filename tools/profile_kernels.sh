@@ -11,8 +11,10 @@ for CASE in ${CASES:-"cmux 4096" "cmux 16384" "cmux 256" "keyswitch 4096" "cbs 4
   OUT=$ROOT/$1_$2
   mkdir -p $OUT
   CMD="python3 tools/kernel_bench.py $1 $2 4"
-  echo "$CMD" > $OUT/command.txt
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace failed: $CASE"; exit 1; }
+  TRACE_CMD="python3 tools/kernel_bench.py $1 $2 12"   # more launches for the timing row: the first ones of a process run slower
+  echo "trace: $TRACE_CMD" > $OUT/command.txt
+  echo "pmc:   $CMD" >> $OUT/command.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE_CMD > $OUT/trace.log 2>&1 || { echo "trace failed: $CASE"; exit 1; }
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1 || exit 1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || exit 1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1 || exit 1
