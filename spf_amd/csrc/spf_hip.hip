@@ -1699,8 +1699,7 @@ void spf_pool_destroy(spf_pool* p)
         p->cv_set.notify_all();
         p->cv_idle.wait(lk, [&] { return p->blocked == 0; });
         for (auto& b : p->collecting) // batches with tickets nobody collected
-            for (hipEvent_t e : {b->ev_in, b->ev_k, b->ev_out})
-                if (e) (void)hipEventDestroy(e);
+            b->destroy_events();
     }
     p->free_sets();
     (void)hipStreamDestroy(p->s_in);

@@ -30,6 +30,7 @@
 #pragma once
 #include "../../include/spf_hip.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -41,12 +42,16 @@
 #include <deque>
 #include <exception>
 #include <memory>
+#include <pthread.h>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
+#ifndef SPF_POOL_AT_ONCE
+#define SPF_POOL_AT_ONCE (3 * (size_t)ctx->n_cu / 2)
+#endif
 namespace spf_pool_impl {
 
 enum Op { OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3, N_OPS = 4 };
@@ -57,6 +62,7 @@ struct Slot {
     void* out;
     uint64_t ticket;
     bool delivered; // output already copied to `out` (by the launcher, for a ticket nobody collected in time)
+    uintptr_t who;  // the submitting thread (see `last_members`)
 };
 
 struct Staging {
@@ -69,18 +75,49 @@ struct Staging {
     bool busy = false;
 };
 
+inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expected)
+{
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t>* w)
+{
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
 struct Batch {
     int op = 0, set = 0;
     size_t cap = 0;               // slots of this batch
     size_t n = 0, n_ready = 0;    // slots taken / inputs copied in
     size_t n_collected = 0;
+    size_t n_returning = 0;       // members submitted by a thread that was in the previous batch of this kind
     bool closed = false, done = false;
     bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
-    std::atomic<uint32_t> done_word{0}; // 0 -> 1 when the batch is done: what its waiters sleep on (futex)
-    spf_status st = SPF_OK;
+    // The outputs leave the GPU in chunks of kChunkSlots slots (the last chunk takes the rest), each with its own event and its
+    // own word: the waiters of a chunk sleep on its word (futex, 0 -> 1 when its bytes are in pinned memory or the batch
+    // failed) and copy out while the later chunks are still crossing PCIe.
+    static constexpr size_t kChunkSlots = 64;
+    static constexpr int kMaxChunks = 8;
+    static int chunk_of(size_t slot) { return (int)std::min<size_t>(slot / kChunkSlots, kMaxChunks - 1); }
+    std::atomic<uint32_t> chunk_word[kMaxChunks] = {};
+    int n_chunks = 0; // set when the batch is enqueued
+    std::atomic<spf_status> st{SPF_OK}; // (atomic: the completion thread may still record a late copy failure while the waiters
+                                        // of an earlier chunk read it)
     std::chrono::steady_clock::time_point t0, t_last, t_done, t_close, t_enq, t_ready, t_sync;
     std::vector<Slot> slots;
-    hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_k = nullptr;
+    hipEvent_t ev_chunk[kMaxChunks] = {}; // the last one of a batch is "everything is out"
+    void destroy_events()
+    {
+        for (hipEvent_t* e : {&ev_in, &ev_k})
+            if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        for (hipEvent_t& e : ev_chunk)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
+    void wake_chunk(int i)
+    {
+        chunk_word[i].store(1, std::memory_order_release);
+        futex_wake_all(&chunk_word[i]);
+    }
 };
 
 } // namespace spf_pool_impl
@@ -109,6 +146,7 @@ struct spf_pool {
     spf_pool_impl::Staging sets[spf_pool_impl::kSets];
     hipStream_t s_in = nullptr;           // host-to-device copies; kernels run on ctx->stream, device-to-host on ctx->copy_stream
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
+    std::vector<uintptr_t> last_members[spf_pool_impl::N_OPS]; // threads of the most recently finished batch of a kind, sorted
     size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
                                                               // (pinned staging is sized by what the callers actually produce:
                                                               // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
@@ -192,15 +230,6 @@ struct spf_pool {
         }
     }
 
-    static void futex_wait(std::atomic<uint32_t>* w, uint32_t expected)
-    {
-        (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
-    }
-    static void futex_wake_all(std::atomic<uint32_t>* w)
-    {
-        (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
-    }
-
     // output of one slot to its caller's buffer (any thread; the pinned buffer is stable while the batch is collecting)
     void deliver(const Batch& b, size_t slot) const
     {
@@ -215,9 +244,7 @@ struct spf_pool {
             sets[b->set].busy = false;
             for (auto it = collecting.begin(); it != collecting.end(); ++it)
                 if (it->get() == b.get()) { collecting.erase(it); break; }
-            for (hipEvent_t e : {b->ev_in, b->ev_k, b->ev_out})
-                if (e) (void)hipEventDestroy(e);
-            b->ev_in = b->ev_k = b->ev_out = nullptr;
+            b->destroy_events();
             if (set_waiters) cv_set.notify_all();
         }
     }
@@ -272,7 +299,9 @@ struct spf_pool {
         size_t slot;
         try {
             slot = b->n;
-            b->slots.push_back(Slot{out, next_ticket, false});
+            const uintptr_t who = (uintptr_t)pthread_self();
+            b->slots.push_back(Slot{out, next_ticket, false, who});
+            if (std::binary_search(last_members[op].begin(), last_members[op].end(), who)) b->n_returning++;
             tickets.emplace(next_ticket, std::make_pair(b, slot));
         } catch (const std::exception&) {
             if (b->slots.size() > b->n) b->slots.pop_back();
@@ -285,6 +314,8 @@ struct spf_pool {
         if (b->n == b->cap) {
             cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(op);
+        } else if (everybody_is_back(*b)) {
+            cv_work.notify_all(); // the launcher need not wait for more
         }
         size_t in[3], outsz;
         in_out_sizes(op, in, outsz);
@@ -300,6 +331,16 @@ struct spf_pool {
         // closed batch just got its last input
         if (slot == 0 || (b->closed && b->n_ready == b->n)) cv_work.notify_all();
         return SPF_OK;
+    }
+
+    // `mu` held.  Synchronous callers come back: the threads of the batch that just finished collect their outputs and submit
+    // again.  Once every one of them is in the filling batch and the pool holds no other open ticket, nobody is left to wait for.
+    // (Threads the pool has not seen in the previous batch do not count: for callers arriving for the first time the coalescing
+    // window is `max_wait`, as documented.)
+    bool everybody_is_back(const Batch& b) const
+    {
+        const std::vector<uintptr_t>& last = last_members[b.op];
+        return b.n > 1 && !last.empty() && b.n_returning >= last.size() && tickets.size() == b.n;
     }
 
     // `mu` held: the batch of `op` takes no more members; the launcher enqueues it once every member's input is in
@@ -353,7 +394,8 @@ struct spf_pool {
             blocked++;
         }
         // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
-        while (b->done_word.load(std::memory_order_acquire) == 0) futex_wait(&b->done_word, 0);
+        std::atomic<uint32_t>& word = b->chunk_word[spf_pool_impl::Batch::chunk_of(slot)];
+        while (word.load(std::memory_order_acquire) == 0) spf_pool_impl::futex_wait(&word, 0);
         const spf_status st = b->st;
         // (`delivered` is only ever set for an unclaimed ticket, under the mutex this thread's claim went through)
         if (st == SPF_OK && !b->slots[slot].delivered) deliver(*b, slot); // this caller's output, by this caller's thread
@@ -384,9 +426,11 @@ struct spf_pool {
 #else
         constexpr unsigned kEvFlags = hipEventDisableTiming;
 #endif
-        if (hipEventCreateWithFlags(&b.ev_in, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&b.ev_k, kEvFlags) != hipSuccess ||
-            hipEventCreateWithFlags(&b.ev_out, kEvFlags) != hipSuccess)
+        b.n_chunks = Batch::chunk_of(B - 1) + 1;
+        if (hipEventCreateWithFlags(&b.ev_in, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&b.ev_k, kEvFlags) != hipSuccess)
             return SPF_ERR_HIP;
+        for (int i = 0; i < b.n_chunks; i++)
+            if (hipEventCreateWithFlags(&b.ev_chunk[i], kEvFlags) != hipSuccess) return SPF_ERR_HIP;
         for (int k = 0; k < 3; k++)
             if (in[k] && hipMemcpyAsync(s.d_in[k], s.h_in[k], B * in[k], hipMemcpyHostToDevice, s_in) != hipSuccess) return SPF_ERR_HIP;
         if (hipEventRecord(b.ev_in, s_in) != hipSuccess) return SPF_ERR_HIP;
@@ -413,8 +457,14 @@ struct spf_pool {
         if (hipEventRecord(b.ev_k, sk) != hipSuccess) return SPF_ERR_HIP;
         hipStream_t so = ctx->copy_stream;
         if (hipStreamWaitEvent(so, b.ev_k, 0) != hipSuccess) return SPF_ERR_HIP;
-        if (hipMemcpyAsync(s.h_out, s.d_out, B * out, hipMemcpyDeviceToHost, so) != hipSuccess) return SPF_ERR_HIP;
-        if (hipEventRecord(b.ev_out, so) != hipSuccess) return SPF_ERR_HIP;
+        for (int i = 0; i < b.n_chunks; i++) {
+            const size_t first = (size_t)i * Batch::kChunkSlots;
+            const size_t count = (i + 1 < b.n_chunks ? first + Batch::kChunkSlots : B) - first;
+            if (hipMemcpyAsync(static_cast<uint8_t*>(s.h_out) + first * out, static_cast<const uint8_t*>(s.d_out) + first * out, count * out,
+                               hipMemcpyDeviceToHost, so) != hipSuccess)
+                return SPF_ERR_HIP;
+            if (hipEventRecord(b.ev_chunk[i], so) != hipSuccess) return SPF_ERR_HIP;
+        }
         return SPF_OK;
     }
 
@@ -469,7 +519,10 @@ struct spf_pool {
                 // time on the GPU (a caller needs that long to copy 256 KiB out and come back when its CPU is shared).
                 const auto now = std::chrono::steady_clock::now();
                 if (!idle_since_valid) { idle_since = now; idle_since_valid = true; }
-                if (filling[op]->n < 3 * (size_t)ctx->n_cu / 2) {
+                // Everybody is here: every open ticket of the pool belongs to this batch (the callers of the previous batch have
+                // collected their outputs and come back), so nobody is left to wait for — close without the quiet time.
+                const bool everybody = everybody_is_back(*filling[op]);
+                if (!everybody && filling[op]->n < SPF_POOL_AT_ONCE) {
                     // (a small batch also waits for the copy out of the batch before it: those callers are the ones to come back)
                     if (!in_flight.empty() && now < idle_since + std::chrono::milliseconds(20)) {
                         cv_work.wait_for(lk, std::chrono::milliseconds(1));
@@ -504,7 +557,16 @@ struct spf_pool {
                 last_gpu_span = std::chrono::steady_clock::now() - b->t_enq;
                 cv_work.notify_all();
                 lk.unlock();
-                if (!k_ok || hipEventSynchronize(b->ev_out) != hipSuccess) b->st = SPF_ERR_HIP;
+                if (!k_ok) b->st = SPF_ERR_HIP;
+                // all chunks but the last: their waiters copy out while the rest is still on its way.  (A failure from here on
+                // reaches the waiters of the chunks still asleep; the bytes already handed out were complete.)  The last chunk is
+                // woken below, behind the bookkeeping that its waiters' `collected_one` relies on.
+                for (int i = 0; i + 1 < b->n_chunks; i++) {
+                    if (b->st == SPF_OK && hipEventSynchronize(b->ev_chunk[i]) != hipSuccess) b->st = SPF_ERR_HIP;
+                    b->wake_chunk(i);
+                }
+                if (b->st == SPF_OK && hipEventSynchronize(b->ev_chunk[b->n_chunks - 1]) != hipSuccess) b->st = SPF_ERR_HIP;
+                if (b->st != SPF_OK) (void)hipStreamSynchronize(ctx->copy_stream); // nothing may still be writing the staging set
                 b->t_sync = std::chrono::steady_clock::now();
             } else {
                 // something was enqueued before the failure: let it drain before the staging set is reused
@@ -523,16 +585,23 @@ struct spf_pool {
             {
                 auto us = [](auto d) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(d).count(); };
                 float gpu_ms = -1.f;
-                if (b->ev_in && b->ev_out) (void)hipEventElapsedTime(&gpu_ms, b->ev_in, b->ev_out);
+                if (b->ev_in && b->n_chunks > 0 && b->ev_chunk[b->n_chunks - 1])
+                    (void)hipEventElapsedTime(&gpu_ms, b->ev_in, b->ev_chunk[b->n_chunks - 1]);
                 fprintf(stderr, "[pool] batch op %d n %zu: filled %ld us, closed->inputs in %ld us, enqueue %ld us, enqueued->event %ld us (gpu h2d..d2h %.0f us), event->marked %ld us\n", b->op, b->n,
                         us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), gpu_ms * 1e3f, us(b->t_done - b->t_sync));
             }
 #endif
             collecting.push_back(b);
+            {
+                std::vector<uintptr_t>& last = last_members[b->op];
+                last.clear();
+                for (size_t i = 0; i < b->n; i++) last.push_back(b->slots[i].who);
+                std::sort(last.begin(), last.end());
+            }
             n_launches++;
             n_ops += b->n;
-            b->done_word.store(1, std::memory_order_release);
-            futex_wake_all(&b->done_word);
+            for (int i = 0; i < spf_pool_impl::Batch::kMaxChunks; i++) // the last chunk — or, for a batch that failed, all of them
+                if (b->chunk_word[i].load(std::memory_order_relaxed) == 0) b->wake_chunk(i);
             cv_work.notify_all(); // the launcher closes the batch that filled meanwhile
         }
     }

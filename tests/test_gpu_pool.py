@@ -58,6 +58,38 @@ def test_pool_matches_batch_entry_points_and_coalesces(rig):
     assert launches < ops / 4, (ops, launches)   # it really batched
 
 
+def test_pool_big_batches_leave_in_chunks_and_every_caller_gets_its_own_bytes(rig):
+    """A batch of more than 64 members copies its outputs out in several chunks, each with its own event and wake-up word
+    (the callers of the first chunk copy out while the last is still crossing PCIe).  200 callers at once, twice in a row (the
+    second round re-uses staging sets and words), every output against the batch entry point."""
+    ks, eng = rig
+    P = ks.params
+    n_ops = 200
+    ggsw = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(random_lwe_batch(21, 4, P.N * P.k)))
+    sel = ggsw[np.arange(n_ops) % 4]
+    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20000)
+    try:
+        for rnd in range(2):
+            a = random_glwe(30 + rnd, n_ops, P.glwe_len)
+            b = random_glwe(40 + rnd, n_ops, P.glwe_len)
+            exp = eng.cmux(sel, a, b)
+            got = np.zeros((n_ops, P.glwe_len), dtype=np.uint64)
+
+            def one(i):
+                pool.cmux(got[i], sel[i], a[i], b[i])
+                return i
+
+            ops0, launches0 = pool.stats()
+            with ThreadPoolExecutor(max_workers=n_ops) as ex:
+                assert sorted(ex.map(one, range(n_ops))) == list(range(n_ops))
+            ops1, launches1 = pool.stats()
+            assert np.array_equal(got, exp)
+            assert ops1 - ops0 == n_ops
+            assert (ops1 - ops0) / (launches1 - launches0) > 64, (ops1 - ops0, launches1 - launches0)   # some batch had several chunks
+    finally:
+        pool.close()
+
+
 def test_pool_single_caller_and_keyswitch(rig):
     ks, eng = rig
     P = ks.params
