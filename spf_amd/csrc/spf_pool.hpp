@@ -92,13 +92,17 @@ struct Batch {
     size_t n_returning = 0;       // members submitted by a thread that was in the previous batch of this kind
     bool closed = false, done = false;
     bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
-    // The outputs leave the GPU in chunks of kChunkSlots slots (the last chunk takes the rest), each with its own event and its
-    // own word: the waiters of a chunk sleep on its word (futex, 0 -> 1 when its bytes are in pinned memory or the batch
-    // failed) and copy out while the later chunks are still crossing PCIe.
-    static constexpr size_t kChunkSlots = 64;
-    static constexpr int kMaxChunks = 8;
-    static int chunk_of(size_t slot) { return (int)std::min<size_t>(slot / kChunkSlots, kMaxChunks - 1); }
-    std::atomic<uint32_t> chunk_word[kMaxChunks] = {};
+    // The outputs leave the GPU in up to kMaxChunks copies (each a multiple of kWordSlots slots, all but the last equal), each with
+    // its own event.  The waiters sleep on the word of their slot group (futex, 0 -> 1 when the group's bytes are in pinned
+    // memory or the batch failed): the callers of the first chunk copy out and come back while the later chunks are still
+    // crossing PCIe.  (Words per 64 slots rather than per chunk: a waiter may go to sleep before the batch is closed, when
+    // its size — and so the chunk boundaries — is not known yet.)
+    static constexpr size_t kWordSlots = 64;
+    static constexpr int kMaxWords = 64; // 4096 slots; the last word also takes whatever lies beyond
+    static constexpr int kMaxChunks = 16;
+    static int word_of(size_t slot) { return (int)std::min<size_t>(slot / kWordSlots, kMaxWords - 1); }
+    std::atomic<uint32_t> chunk_word[kMaxWords] = {};
+    size_t chunk_slots = 0; // slots per copy (set with n_chunks)
     int n_chunks = 0; // set when the batch is enqueued
     std::atomic<spf_status> st{SPF_OK}; // (atomic: the completion thread may still record a late copy failure while the waiters
                                         // of an earlier chunk read it)
@@ -113,10 +117,17 @@ struct Batch {
         for (hipEvent_t& e : ev_chunk)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
-    void wake_chunk(int i)
+    void wake_word(int w)
     {
-        chunk_word[i].store(1, std::memory_order_release);
-        futex_wake_all(&chunk_word[i]);
+        chunk_word[w].store(1, std::memory_order_release);
+        futex_wake_all(&chunk_word[w]);
+    }
+    void wake_chunk(int i) // the words of copy i
+    {
+        const int w0 = word_of((size_t)i * chunk_slots);
+        const int w1 = i + 1 < n_chunks ? word_of((size_t)(i + 1) * chunk_slots - 1) : kMaxWords - 1;
+        for (int w = w0; w <= w1; w++)
+            if (chunk_word[w].load(std::memory_order_relaxed) == 0) wake_word(w);
     }
 };
 
@@ -394,7 +405,7 @@ struct spf_pool {
             blocked++;
         }
         // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
-        std::atomic<uint32_t>& word = b->chunk_word[spf_pool_impl::Batch::chunk_of(slot)];
+        std::atomic<uint32_t>& word = b->chunk_word[spf_pool_impl::Batch::word_of(slot)];
         while (word.load(std::memory_order_acquire) == 0) spf_pool_impl::futex_wait(&word, 0);
         const spf_status st = b->st;
         // (`delivered` is only ever set for an unclaimed ticket, under the mutex this thread's claim went through)
@@ -426,7 +437,12 @@ struct spf_pool {
 #else
         constexpr unsigned kEvFlags = hipEventDisableTiming;
 #endif
-        b.n_chunks = Batch::chunk_of(B - 1) + 1;
+        {
+            const size_t groups = (B + Batch::kWordSlots - 1) / Batch::kWordSlots;
+            b.n_chunks = (int)std::min<size_t>(groups, Batch::kMaxChunks);
+            b.chunk_slots = (groups + b.n_chunks - 1) / b.n_chunks * Batch::kWordSlots;
+            b.n_chunks = (int)((B + b.chunk_slots - 1) / b.chunk_slots);
+        }
         if (hipEventCreateWithFlags(&b.ev_in, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&b.ev_k, kEvFlags) != hipSuccess)
             return SPF_ERR_HIP;
         for (int i = 0; i < b.n_chunks; i++)
@@ -458,8 +474,8 @@ struct spf_pool {
         hipStream_t so = ctx->copy_stream;
         if (hipStreamWaitEvent(so, b.ev_k, 0) != hipSuccess) return SPF_ERR_HIP;
         for (int i = 0; i < b.n_chunks; i++) {
-            const size_t first = (size_t)i * Batch::kChunkSlots;
-            const size_t count = (i + 1 < b.n_chunks ? first + Batch::kChunkSlots : B) - first;
+            const size_t first = (size_t)i * b.chunk_slots;
+            const size_t count = std::min(b.chunk_slots, B - first);
             if (hipMemcpyAsync(static_cast<uint8_t*>(s.h_out) + first * out, static_cast<const uint8_t*>(s.d_out) + first * out, count * out,
                                hipMemcpyDeviceToHost, so) != hipSuccess)
                 return SPF_ERR_HIP;
@@ -600,8 +616,8 @@ struct spf_pool {
             }
             n_launches++;
             n_ops += b->n;
-            for (int i = 0; i < spf_pool_impl::Batch::kMaxChunks; i++) // the last chunk — or, for a batch that failed, all of them
-                if (b->chunk_word[i].load(std::memory_order_relaxed) == 0) b->wake_chunk(i);
+            for (int w = 0; w < spf_pool_impl::Batch::kMaxWords; w++) // the last chunk — or, for a batch that failed, all of them
+                if (b->chunk_word[w].load(std::memory_order_relaxed) == 0) b->wake_word(w);
             cv_work.notify_all(); // the launcher closes the batch that filled meanwhile
         }
     }
