@@ -283,6 +283,17 @@ def test_bootstrap_key_no_transform_could_produce_is_refused(small, value):
     eng.load_bootstrap_key(ks.bsk_fft)
     exp = np.stack([O.cbs_pbs(lwe[i], ks.bsk_fft, ks.params) for i in range(3)])
     assert np.array_equal(eng.circuit_bootstrap_pbs(lwe), exp)
+    # the same through the blob a broadcast fills: the commit is where the copy for the kernels is built and checked
+    ptr, nbytes = eng.key_blob(0)
+    assert nbytes == bad.nbytes
+    eng.device_upload(ptr, bad)
+    with pytest.raises(spf_amd.SpfError, match="forward transform"):
+        eng.key_blob_commit(0)
+    with pytest.raises(spf_amd.SpfError):
+        eng.circuit_bootstrap_pbs(lwe)
+    eng.device_upload(ptr, ks.bsk_fft)
+    eng.key_blob_commit(0)
+    assert np.array_equal(eng.circuit_bootstrap_pbs(lwe), exp)
 
 
 def test_evaluation_mirror_writes_outputs(small):
