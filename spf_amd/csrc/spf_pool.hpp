@@ -124,8 +124,9 @@ struct Batch {
     }
     void wake_chunk(int i) // the words of copy i
     {
+        // (the last word stands for every slot from 64 * (kMaxWords - 1) on, however many: only the last copy wakes it)
         const int w0 = word_of((size_t)i * chunk_slots);
-        const int w1 = i + 1 < n_chunks ? word_of((size_t)(i + 1) * chunk_slots - 1) : kMaxWords - 1;
+        const int w1 = i + 1 < n_chunks ? std::min(word_of((size_t)(i + 1) * chunk_slots - 1), kMaxWords - 2) : kMaxWords - 1;
         for (int w = w0; w <= w1; w++)
             if (chunk_word[w].load(std::memory_order_relaxed) == 0) wake_word(w);
     }

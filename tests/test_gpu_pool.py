@@ -90,6 +90,32 @@ def test_pool_big_batches_leave_in_chunks_and_every_caller_gets_its_own_bytes(ri
         pool.close()
 
 
+def test_pool_one_thread_many_tickets_beyond_4096_slots(rig):
+    """One thread may hold many tickets (asynchronous submit, wait later).  5 000 keyswitches in a row: the batches grow up to —
+    and, with the usual timing, past — the 4 096 slots that have wake-up words of their own (the slots beyond share the last
+    word, which only the last copy wakes); collected last ticket first."""
+    ks, eng = rig
+    P = ks.params
+    n_ops = 5000
+    lwe1 = random_lwe_batch(77, n_ops, P.N * P.k)
+    exp = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+    pool = spf_amd.Pool(eng, max_batch=8192, max_wait_us=20000)
+    try:
+        got = np.zeros((n_ops, P.lwe_n + 1), dtype=np.uint64)
+        for rnd in range(3):   # the first rounds grow the staging sets (the slot count doubles whenever a batch fills up)
+            got[:] = 0
+            ops0, launches0 = pool.stats()
+            tickets = [pool.submit_keyswitch(got[i], lwe1[i]) for i in range(n_ops)]
+            for t in reversed(tickets):   # the last slots first
+                pool.wait(t)
+            ops1, launches1 = pool.stats()
+            assert np.array_equal(got, exp)
+            assert ops1 - ops0 == n_ops
+        assert launches1 - launches0 <= 3, launches1 - launches0   # (typically two: ~400 at once, then everything else)
+    finally:
+        pool.close()
+
+
 def test_pool_single_caller_and_keyswitch(rig):
     ks, eng = rig
     P = ks.params
