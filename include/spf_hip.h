@@ -388,7 +388,7 @@ spf_status spf_device_free(spf_ctx *ctx, void *dev_ptr);
 spf_status spf_device_upload(spf_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 spf_status spf_device_download(spf_ctx *ctx, void *stream, void *host_dst, const void *dev_src, size_t bytes);
 /* Name of the blind-rotation kernel the most recent bootstrap launch of this context used (the shape is
- * picked from the batch size: four waves per ciphertext, the paired latency shape, or the throughput
+ * picked from the batch size: eight waves per ciphertext, two ciphertexts per workgroup, or the throughput
  * shape).  For measurement records; never NULL. */
 const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
 /* The same for the CMUX family (spf_cmux*, spf_glev_cmux*, spf_multiply_glwe_ggsw*, gate graphs): four waves per gate up
