@@ -172,6 +172,29 @@ def test_identity_steps_and_extreme_words_every_shape(small, B):
     assert np.array_equal(u, np.stack([O.sample_extract(g, 0, P.N, P.k) for g in exp]))
 
 
+@pytest.mark.parametrize("B", [1, 2, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2049])
+def test_dispatch_boundaries_every_output_against_the_oracle(small, B):
+    """The batch sizes where the launch changes shape (one ciphertext per CU / two per workgroup / four per workgroup), each
+    side of them, and the first sizes of a second chip round: ONE launch per batch through the device-pointer entry points,
+    every ciphertext against the oracle, both rotation kinds."""
+    ks, eng = small
+    P = ks.params
+    lwe = random_lwe_batch(0xB0D0 + B, B, SMALL_N)
+    got = dev_bootstrap(eng, lwe)
+    name = eng.last_blind_rotate_kernel()
+    assert name.startswith("blind_rotate8" if B <= 256 else "blind_rotate2p2" if B <= 512 else "blind_rotate2p_"), name
+    rot = lwe.copy()
+    rot[:, -1] += np.uint64(1 << 62)
+    _, exp = O.bench_generalized_pbs(rot, O.fill_cbs_lut(P), ks.bsk_fft, P, 8, 0, 2)
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"even: {bad.size} ciphertexts differ, first {bad[:8]}"
+    luts = random_glwe(0xB0D1 + B, B, P.glwe_len)
+    got = dev_bootstrap(eng, lwe, luts, 0, 0, 0)
+    _, exp = O.bench_generalized_pbs(lwe, luts, ks.bsk_fft, P, 8, 0, 0)
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"mixing: {bad.size} ciphertexts differ, first {bad[:8]}"
+
+
 def _const_key_engine(value):
     """n = 1; the only non-zero key polynomial (row b, level 0 <-> top digit, output polynomial b) is the constant
     `value`: the external product is then top_digit(diff_b) * value, coefficient by coefficient"""
