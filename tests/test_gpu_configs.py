@@ -259,7 +259,8 @@ def test_big_batches_are_bit_stable_run_to_run(full):
     register reused while a load into it is still in flight, as r02's cmux_kernel allowed for the dead selector-row
     loads of a gate's last round — passes every small parity test.  Same inputs, three runs, every word equal, for the
     streaming CMUX at 4096 gates (2048 workgroups) and for the whole circuit bootstrap (blind rotation, trace with its
-    parked accumulator half, scheme switch) at 2048 ciphertexts; plus the first and last unit against the oracle."""
+    parked accumulator half, scheme switch) at 2048 ciphertexts; plus every sixteenth of them (and every workgroup slot, both sides of
+    a chip round) against the oracle."""
     ks, eng = full
     P = ks.params
     rng = np.random.default_rng(0xD37)
@@ -287,7 +288,9 @@ def test_big_batches_are_bit_stable_run_to_run(full):
     again = eng.circuit_bootstrap(lwe)
     bad = np.nonzero((again.reshape(B, -1).view(np.uint64) != first.reshape(B, -1).view(np.uint64)).any(axis=1))[0]
     assert bad.size == 0, f"circuit bootstrap: {bad.size} ciphertexts differ between two runs, first {bad[:8]}"
-    for i in (0, B - 1):
+    # against the oracle: every slot of a bootstrap workgroup (4 ciphertexts) and of a trace / scheme-switch workgroup (4 units =
+    # one ciphertext), both sides of a chip round of the bootstrap (1024), the last ciphertexts
+    for i in sorted(set(range(0, B, 16)) | {1, 2, 3, 517, 1022, 1023, 1025, 1538, B - 2, B - 1}):
         exp = O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P)
         assert np.array_equal(first[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), i
 
