@@ -56,8 +56,9 @@ def _self_launch(gpus: int) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed launches first (the first launches of a process run 3-5 %% slower: clocks, key first touch)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ciphertexts per GPU per step (default: 4096 on one GPU = BASELINE configs[1]; 8192 per GPU "
                          "on several = configs[3], 65536 bootstraps over 8 GPUs)")
