@@ -326,6 +326,8 @@ struct spf_pool {
         if (b->n == b->cap) {
             cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(op);
+        } else if (b->n == 2 * (size_t)ctx->n_cu && cap_here(b->n)) {
+            close_batch(op);
         } else if (everybody_is_back(*b)) {
             cv_work.notify_all(); // the launcher need not wait for more
         }
@@ -353,6 +355,24 @@ struct spf_pool {
     {
         const std::vector<uintptr_t>& last = last_members[b.op];
         return b.n > 1 && !last.empty() && b.n_returning >= last.size() && tickets.size() == b.n;
+    }
+
+    // `mu` held.  Two ciphertexts per CU is the largest batch of the two-per-workgroup shape of the bootstrap (6.9 ms); one
+    // ciphertext more costs 9.9 ms (four per workgroup on half a chip).  While kernels of the pool are running, a batch that
+    // reaches that size is closed there (it queues behind the running kernels) if the callers that are not in flight number
+    // fewer than a quarter more: the few left over lead the next batch, and the groups of callers that take turns on the GPU
+    // settle at 512 (T = 1 024: 52.9 k -> 64.4 k/s).  (The same rule at ONE ciphertext per CU helps 768 callers, 41.6 k -> 56.9 k,
+    // but pulls 1 024 callers from groups of 512 down to groups of 256, 64.4 k -> 56.6 k: not applied.)
+    bool cap_here(size_t n) const
+    {
+        size_t flying = 0;
+        bool busy = false;
+        for (auto& f : in_flight)
+            if (!f->kernels_done) { // (the callers of a batch that is copying out are on their way back into this one)
+                flying += f->n;
+                busy = true;
+            }
+        return busy && tickets.size() - flying < n + n / 4;
     }
 
     // `mu` held: the batch of `op` takes no more members; the launcher enqueues it once every member's input is in
