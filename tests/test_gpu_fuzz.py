@@ -1,0 +1,79 @@
+"""Randomised differential test of the bootstrap entry points against the oracle (r04).
+
+Every case draws a batch size (weighted towards the sizes where the launch changes shape), an LWE dimension, the
+(log_chi, log_v, body rotation) arguments, a shared or per-ciphertext LUT and the entry point (generalized bootstrap,
+univariate bootstrap with the fused sample extract, circuit-bootstrap bootstrap), runs it as ONE launch through the
+device-pointer forms and compares every output word with `spfo_bench_generalized_pbs`.  The default suite runs a few cases;
+`SPF_FUZZ_CASES=N` (and `SPF_FUZZ_SEED`) turn it into a soak — `profiles/r04_fuzz.md` records the r04 run."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import spf_amd
+from util import dev_bootstrap, gpu_available, keyset, random_glwe, to_engine_params
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("SPF_FUZZ_CASES", "12"))
+SEED = int(os.environ.get("SPF_FUZZ_SEED", "20260401"))
+LWE_DIMS = (1, 3, 20)
+SIZES = (1, 2, 3, 7, 64, 100, 255, 256, 257, 300, 511, 512, 513, 600, 1023, 1024, 1025, 1031, 1100, 2047, 2050)
+
+
+@pytest.fixture(scope="module")
+def engines():
+    if not gpu_available():
+        pytest.skip("needs a GPU")
+    out = {}
+    for n in LWE_DIMS:
+        ks = keyset(0x5EED0001, n, with_ksk=False)
+        eng = spf_amd.Engine(to_engine_params(ks.params))
+        eng.load_bootstrap_key(ks.bsk_fft)
+        out[n] = (ks, eng)
+    return out
+
+
+def test_random_bootstrap_calls_against_the_oracle(engines):
+    rng = np.random.default_rng(SEED)
+    log = []
+    for case in range(CASES):
+        n = int(rng.choice(LWE_DIMS))
+        ks, eng = engines[n]
+        P = ks.params
+        B = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 1200))
+        lwe = rng.integers(0, 1 << 64, size=(B, n + 1), dtype=np.uint64)
+        if rng.random() < 0.3:   # identity steps, extreme words
+            rows = rng.integers(0, B, size=max(1, B // 7))
+            lwe[rows, : n] = rng.choice(np.array([0, (1 << 64) - 1, 1 << 63], dtype=np.uint64), size=(rows.size, 1))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:      # the circuit bootstrap's bootstrap: fixed LUT, log_v = 2, body rotated by 2^62
+            got = dev_bootstrap(eng, lwe)
+            rot = lwe.copy()
+            rot[:, -1] += np.uint64(1 << 62)
+            _, exp = O.bench_generalized_pbs(rot, O.fill_cbs_lut(P), ks.bsk_fft, P, 8, 0, 2)
+            what = "cbs"
+        else:
+            shared = rng.random() < 0.4
+            lut = random_glwe(int(rng.integers(1 << 30)), 1 if shared else B, P.glwe_len)
+            lut = lut[0] if shared else lut
+            if kind == 1:  # univariate: log_chi = log_v = 0, sample extract fused
+                got = dev_bootstrap(eng, lwe, lut, extract=True)
+                _, exp = O.bench_generalized_pbs(lwe, lut, ks.bsk_fft, P, 8, 0, 0, extract=True)
+                what = f"univariate lut={'shared' if shared else 'each'}"
+            else:
+                log_chi, log_v = int(rng.integers(0, 7)), int(rng.integers(0, 5))
+                body_rotate = int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.7 else 0
+                got = dev_bootstrap(eng, lwe, lut, log_chi, log_v, body_rotate)
+                rot = lwe.copy()
+                rot[:, -1] += np.uint64(body_rotate)
+                _, exp = O.bench_generalized_pbs(rot, lut, ks.bsk_fft, P, 8, log_chi, log_v)
+                what = f"generalized chi={log_chi} v={log_v} rot={'random' if body_rotate else 0} lut={'shared' if shared else 'each'}"
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        log.append(f"{case}: n={n} B={B} {what} kernel={eng.last_blind_rotate_kernel()}")
+        assert bad.size == 0, f"case {log[-1]} (seed {SEED}): {bad.size} ciphertexts differ, first {bad[:8]}"
+    report = os.environ.get("SPF_FUZZ_REPORT")
+    if report:
+        with open(report, "w") as f:
+            f.write("\n".join(log) + "\n")
