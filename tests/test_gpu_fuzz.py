@@ -77,3 +77,66 @@ def test_random_bootstrap_calls_against_the_oracle(engines):
     if report:
         with open(report, "w") as f:
             f.write("\n".join(log) + "\n")
+
+
+@pytest.fixture(scope="module")
+def tail_rig():
+    if not gpu_available():
+        pytest.skip("needs a GPU")
+    ks = keyset(0x5EED0001, 12)
+    P = ks.params
+    r = O.Rng(0x7A11)
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    return ks, ak, ssk, eng
+
+
+def test_random_tail_cmux_and_keyswitch_calls_against_the_oracle(tail_rig):
+    """The rows either side of the bootstrap: keyswitch (every output), trace + rotate, scheme switch, the whole circuit
+    bootstrap, CMUX with a selector per gate or shared, at random batch sizes (the trace and the scheme switch take four units
+    per workgroup, the CMUX two gates per workgroup or four waves per gate); a random sample of each batch against the oracle."""
+    ks, ak, ssk, eng = tail_rig
+    P = ks.params
+    rng = np.random.default_rng(SEED + 1)
+    sizes = (1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 300, 513, 700, 1025)
+    for case in range(max(4, CASES // 2)):
+        B = int(rng.choice(sizes)) if rng.random() < 0.8 else int(rng.integers(1, 800))
+        pick = sorted(set([0, B - 1]) | set(int(i) for i in rng.integers(0, B, size=min(B, 6))))
+        kind = int(rng.integers(0, 5))
+        tag = f"case {case} (seed {SEED + 1}): B={B} kind={kind}"
+        if kind == 0:
+            lwe1 = rng.integers(0, 1 << 64, size=(B, P.k * P.N + 1), dtype=np.uint64)
+            got = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+            for i in pick:
+                assert np.array_equal(got[i], O.keyswitch_lwe(lwe1[i], ks.ksk, P.N, P.lwe_n, P.ks_radix_log, P.ks_count)), (tag, i)
+        elif kind == 1:
+            glwe = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            got = eng.mod_switch_trace_and_rotate(glwe)
+            for i in pick:
+                assert np.array_equal(got[i], O.mod_switch_trace_and_rotate(glwe[i], ak, P)), (tag, i)
+        elif kind == 2:
+            glev = rng.integers(0, 1 << 64, size=(B, P.cbs_count, P.glwe_len), dtype=np.uint64)
+            got = eng.scheme_switch(glev)
+            for i in pick:
+                assert np.array_equal(got[i].view(np.float64), O.scheme_switch_fft(glev[i], ssk, P).view(np.float64)), (tag, i)
+        elif kind == 3:
+            lwe0 = rng.integers(0, 1 << 64, size=(B, P.lwe_n + 1), dtype=np.uint64)
+            got = eng.circuit_bootstrap(lwe0)
+            for i in pick[:4]:
+                exp = O.circuit_bootstrap(lwe0[i], ks.bsk_fft, ak, ssk, P)
+                assert np.array_equal(got[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), (tag, i)
+        else:
+            n_c = 2 * P.cbs_count * 2 * (P.N // 2)
+            shared = rng.random() < 0.3
+            g = ((rng.standard_normal((1 if shared else B, n_c)) + 1j * rng.standard_normal((1 if shared else B, n_c)))
+                 * 2.0 ** 60).astype(np.complex128)
+            a = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            b = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            sel = np.broadcast_to(g, (B, n_c)) if shared else g
+            got = eng.cmux(np.ascontiguousarray(sel), a, b)
+            for i in pick:
+                assert np.array_equal(got[i], O.cmux(a[i], b[i], sel[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), (tag, i)
