@@ -140,3 +140,65 @@ def test_random_tail_cmux_and_keyswitch_calls_against_the_oracle(tail_rig):
             got = eng.cmux(np.ascontiguousarray(sel), a, b)
             for i in pick:
                 assert np.array_equal(got[i], O.cmux(a[i], b[i], sel[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), (tag, i)
+
+
+def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
+    """Random gate graphs through `spf_graph_*`: levels 1 to 300 gates wide (the executor sends a level to the four-waves-per-gate
+    kernel or to the streaming kernel by its width), operands drawn from every earlier level, CMux / Not / GlweAdd / MulXN mixed,
+    selectors produced inside the graph (KeyswitchL1toL0 -> CircuitBootstrap).  Every output against the same operations run
+    level by level through the batch entry points (which the tests above hold against the oracle)."""
+    from spf_amd import FheOp, ValueKind
+    ks, ak, ssk, eng = tail_rig
+    P = ks.params
+    rng = np.random.default_rng(SEED + 2)
+    for case in range(max(2, CASES // 6)):
+        g = spf_amd.FheCircuit(eng)
+        n_in, n_sel = int(rng.integers(2, 9)), int(rng.integers(1, 7))
+        glwe_in = rng.integers(0, 1 << 64, size=(n_in, P.glwe_len), dtype=np.uint64)
+        lwe1_in = rng.integers(0, 1 << 64, size=(n_sel, P.k * P.N + 1), dtype=np.uint64)
+        val_nodes = [g.add_input(ValueKind.GLWE1, x) for x in glwe_in]
+        sel_nodes = [g.add_op(FheOp.CircuitBootstrap, [g.add_op(FheOp.KeyswitchL1toL0, [g.add_input(ValueKind.LWE1, x)])])
+                     for x in lwe1_in]
+        sel_vals = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(lwe1_in))
+        vals = [x for x in glwe_in]                      # eager value of val_nodes[i]
+        depth = int(rng.integers(2, 8))
+        for lvl in range(depth):
+            width = int(rng.choice((1, 2, 3, 5, 40, 70, 260, 300)))
+            avail = len(val_nodes)
+            ops = rng.integers(0, 4, size=width)
+            ia, ib = rng.integers(0, avail, size=width), rng.integers(0, avail, size=width)
+            isel = rng.integers(0, n_sel, size=width)
+            amt = rng.integers(0, 4096, size=width)
+            new_nodes, new_vals = [], [None] * width
+            for k in range(width):
+                if ops[k] == 0:
+                    new_nodes.append(g.add_op(FheOp.CMux, [sel_nodes[isel[k]], val_nodes[ia[k]], val_nodes[ib[k]]]))
+                elif ops[k] == 1:
+                    new_nodes.append(g.add_op(FheOp.Not, [val_nodes[ia[k]]]))
+                elif ops[k] == 2:
+                    new_nodes.append(g.add_op(FheOp.GlweAdd, [val_nodes[ia[k]], val_nodes[ib[k]]]))
+                else:
+                    new_nodes.append(g.add_op(FheOp.MulXN, [val_nodes[ia[k]]], int(amt[k])))
+            # the same level through the batch entry points
+            A = np.stack([vals[i] for i in ia])
+            Bv = np.stack([vals[i] for i in ib])
+            mux = np.nonzero(ops == 0)[0]
+            if mux.size:
+                r = eng.cmux(np.ascontiguousarray(sel_vals[isel[mux]]), A[mux], Bv[mux])
+                for j, k in enumerate(mux):
+                    new_vals[k] = r[j]
+            for k in np.nonzero(ops == 1)[0]:
+                new_vals[k] = eng.glwe_not(A[k:k + 1])[0]
+            for k in np.nonzero(ops == 2)[0]:
+                new_vals[k] = eng.glwe_xor(A[k:k + 1], Bv[k:k + 1])[0]
+            for k in np.nonzero(ops == 3)[0]:
+                new_vals[k] = eng.glwe_mul_xn(A[k:k + 1], int(amt[k]))[0]
+            val_nodes += new_nodes
+            vals += new_vals
+        check = sorted(set(range(len(val_nodes) - len(new_nodes), len(val_nodes))) |
+                       set(int(i) for i in rng.integers(n_in, len(val_nodes), size=20)))
+        outs = {i: g.add_output(val_nodes[i], ValueKind.GLWE1) for i in check}
+        g.run()
+        for i in check:
+            assert np.array_equal(outs[i], vals[i]), f"graph case {case} (seed {SEED + 2}): node {i} of {len(val_nodes)}"
+        g.close()
