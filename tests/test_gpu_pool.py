@@ -244,3 +244,48 @@ def test_pool_survives_tickets_nobody_collects_in_time(rig):
     ops, launches = pool.stats()
     assert ops >= n - 2 and launches >= (n - 2) // 2
     pool.close()                                             # tickets n-2, n-1 never collected
+
+
+def test_pool_under_native_load_every_caller_gets_its_own_output(rig):
+    """The drop-in scenario with the load generator of the bench leg (tools/pool_driver.cpp: native threads, each looping
+    KeyswitchL1toL0 -> CircuitBootstrap on its own ciphertext through the pool for a second): 300 callers, so the batches leave
+    in several chunks and close by the rules of a running pipeline; afterwards every caller's last output must be the circuit
+    bootstrap of ITS input (against the batch entry points on the same inputs)."""
+    import ctypes as C
+    import os
+    import subprocess
+    ks, eng = rig
+    P = ks.params
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv_path = os.path.join(root, "tools", "bin", "libpool_driver.so")
+    src = os.path.join(root, "tools", "pool_driver.cpp")
+    if not os.path.exists(drv_path) or os.path.getmtime(drv_path) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(drv_path), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", os.path.join(root, "include"),
+                        "-o", drv_path, src], check=True)
+    drv = C.CDLL(drv_path)
+    drv.spf_pool_drive_collect.restype = C.c_long
+    drv.spf_pool_drive_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t,
+                                           C.c_size_t, C.POINTER(C.c_double), C.c_void_p]
+    T = int(os.environ.get("SPF_POOL_SOAK_THREADS", "300"))          # (a soak: 1024 threads for 20 s, profiles/r04_fuzz.md)
+    seconds = float(os.environ.get("SPF_POOL_SOAK_SECONDS", "1.0"))
+    lwe1 = random_lwe_batch(0xD21, 1, P.N * P.k)[0]
+    inputs = np.tile(lwe1, (T, 1))
+    inputs[:, 0] += np.arange(T, dtype=np.uint64)
+    exp = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(inputs))
+    n_doubles = eng.params.cbs_ggsw_complex * 2
+    got = np.zeros((T, n_doubles), dtype=np.float64)
+    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=200)
+    try:
+        el = C.c_double()
+        lib = eng._lib
+        n = drv.spf_pool_drive_collect(pool._h, C.cast(lib.spf_pool_submit_keyswitch_circuit_bootstrap, C.c_void_p),
+                                       C.cast(lib.spf_pool_wait, C.c_void_p), T, seconds, lwe1.ctypes.data, lwe1.size, n_doubles,
+                                       C.byref(el), got.ctypes.data)
+        ops, launches = pool.stats()
+    finally:
+        pool.close()
+    assert n >= T, n                       # every caller completed at least one operation
+    assert ops == n and launches < n / 16, (n, ops, launches)
+    assert np.array_equal(got, exp.reshape(T, -1).view(np.float64))
+    print(f"pool soak: {T} callers, {el.value:.1f} s, {n} operations in {launches} launches")

@@ -18,9 +18,11 @@ typedef spf_status (*wait_fn)(spf_pool*, uint64_t);
 
 // `threads` callers loop submit(keyswitch + circuit bootstrap of ONE L1 LWE) + wait for `seconds`; inputs are copies of
 // `lwe1` (lwe1_words words), every thread owns its 256 KiB output.  Returns operations completed, -1 on an error status;
-// *elapsed_s = wall time from the first submit to the last wait.
-long spf_pool_drive(spf_pool* pool, submit_fn submit, wait_fn wait, int threads, double seconds, const uint64_t* lwe1,
-                    size_t lwe1_words, size_t ggsw_doubles, double* elapsed_s, double* first_out_checksum)
+// *elapsed_s = wall time from the first submit to the last wait.  all_out (may be null): threads x ggsw_doubles, every caller's
+// LAST output, for the test that checks each caller got its own bytes under load (caller t's input is lwe1 with t added to
+// word 0).
+static long drive(spf_pool* pool, submit_fn submit, wait_fn wait, int threads, double seconds, const uint64_t* lwe1,
+                  size_t lwe1_words, size_t ggsw_doubles, double* elapsed_s, double* first_out_checksum, double* all_out)
 {
     std::atomic<long> done{0};
     std::atomic<int> failed{0};
@@ -50,7 +52,22 @@ long spf_pool_drive(spf_pool* pool, submit_fn submit, wait_fn wait, int threads,
     double s = 0;
     for (size_t i = 0; i < ggsw_doubles; i += 997) s += out[0][i] * 1e-60;
     *first_out_checksum = s;
+    if (all_out)
+        for (int t = 0; t < threads; t++) std::memcpy(all_out + (size_t)t * ggsw_doubles, out[(size_t)t].data(), ggsw_doubles * sizeof(double));
     return failed.load() ? -1 : done.load();
+}
+
+long spf_pool_drive(spf_pool* pool, submit_fn submit, wait_fn wait, int threads, double seconds, const uint64_t* lwe1,
+                    size_t lwe1_words, size_t ggsw_doubles, double* elapsed_s, double* first_out_checksum)
+{
+    return drive(pool, submit, wait, threads, seconds, lwe1, lwe1_words, ggsw_doubles, elapsed_s, first_out_checksum, nullptr);
+}
+
+long spf_pool_drive_collect(spf_pool* pool, submit_fn submit, wait_fn wait, int threads, double seconds, const uint64_t* lwe1,
+                            size_t lwe1_words, size_t ggsw_doubles, double* elapsed_s, double* all_out)
+{
+    double ck;
+    return drive(pool, submit, wait, threads, seconds, lwe1, lwe1_words, ggsw_doubles, elapsed_s, &ck, all_out);
 }
 
 }
