@@ -37,6 +37,27 @@ TRACE_FLOP_PER_CT = 4 * 11 * (8 * 51200 + 12 * 8192 + 6 * 6144 + 2 * 8192)
 SCHEME_SWITCH_FLOP_PER_CT = 4 * (19 * 51200 + 30 * 8192 + 17 * 6144 + 2 * 8192)
 
 
+def _host_cpus():
+    """CPUs this process can actually run on at once: (min(affinity mask, cgroup CFS quota), CPUs visible, quota in CPUs or
+    None).  The GPU box shows 256 CPUs and grants 16 through cpu.max: threads beyond the quota only take turns."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota_cpus = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], txt[1]
+            else:
+                quota, period = txt[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0]
+            if quota not in ("max", "-1"):
+                quota_cpus = int(quota) / int(period)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = visible if quota_cpus is None else max(1, min(visible, int(quota_cpus)))
+    return usable, visible, quota_cpus
+
+
 def _self_launch(gpus: int) -> int:
     """`python3 bench.py --gpus N` from a bare shell (no launcher, WORLD_SIZE unset): start the N ranks as CHILD
     processes through torch.distributed.run and relay their output.  Nothing in this process has touched the GPU
@@ -78,8 +99,17 @@ def main() -> int:
                          "dominant kernel for THIS build on THIS box (three short child processes, about a minute)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo to rehearse "
                     "the N>1 path with several ranks on one GPU)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from THIS process through the C ABI's device group (spf_group_*: keys "
+                         "replicated inside the library by RCCL, one host thread and stream per device) instead of one "
+                         "torch.distributed rank per GPU")
+    ap.add_argument("--devices", default="",
+                    help="with --single-process: comma-separated HIP ordinals of the group's members (default 0..gpus-1); a "
+                         "device may repeat, e.g. 0,0 rehearses a two-member group on a one-GPU box")
     args = ap.parse_args()
 
+    if args.single_process:
+        return _single_process_main(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return _self_launch(args.gpus)
 
@@ -311,7 +341,7 @@ def main() -> int:
             cnt = min(B, 64)
             bsk_host = blobs[0].cpu().numpy().view(np.complex128)
             _, exp = O.bench_generalized_pbs(lwe0[:cnt].cpu().numpy().view(np.uint64), lut_h, bsk_host, O.DEFAULT_128,
-                                             max(1, min(os.cpu_count() or 1, 64)), 0, 0, extract=True, native=True)
+                                             max(1, min(_host_cpus()[0], 64)), 0, 0, extract=True, native=True)
             out["gpu_outputs_bit_equal_on_sample"] = bool(np.array_equal(exp, lwe1_out[:cnt].cpu().numpy().view(np.uint64)))
             out["sample"] = f"{cnt} of the {B} bench ciphertexts against oracle/spf_oracle.c (spfo_pbs_univariate)"
         return out
@@ -456,8 +486,8 @@ def main() -> int:
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as O
-        cores = os.cpu_count() or 1
-        threads = max(1, min(cores, 64))
+        threads, cpus_visible, cfs_quota = _host_cpus()   # one bootstrap per thread on the CPUs that can run at once
+        threads = max(1, min(threads, 64))
         OP = O.DEFAULT_128
         bsk_host = blobs[0].cpu().numpy().view(np.complex128)
         # calibrate on one bootstrap, then size the sample for ~cpu_seconds of wall time
@@ -470,7 +500,9 @@ def main() -> int:
         cpu = {"value": round(count / secs, 3), "unit": "PBS/s", "cores": threads, "kind": "port",
                "sample": f"{count} of the {B} bench ciphertexts, one bootstrap per thread on {threads} host threads "
                          f"(oracle/spf_oracle.c, gcc -O3 -march=native, {secs:.1f} s)",
+               "cpus_visible": cpus_visible, "cfs_quota_cpus": cfs_quota,
                "single_thread_ms_per_pbs": round(t1 * 1e3, 1),
+               "value_over_cores_per_single_thread": round((count / secs) / (threads / max(t1, 1e-9)), 3),
                "gpu_outputs_bit_equal_on_sample": bool(np.array_equal(out, gpu_sample))}
 
     if rank == 0:
@@ -512,6 +544,151 @@ def main() -> int:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def _single_process_main(args) -> int:
+    """`--gpus N --single-process`: the headline step on N devices driven by ONE host process through spf_group_* — what a
+    Rust `Evaluation` owning the whole node does.  Same line shape as the rank-per-GPU form; weak scaling
+    (--batch per member); the timed region is K steps enqueued on every member's stream between two synchronisations of
+    every device.  Also times the host-pointer group call (the batch cut into ceil(B / G) ranges, PCIe inside)."""
+    import torch
+
+    import spf_amd
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
+        return 2
+    devices = [int(x) for x in args.devices.split(",") if x != ""] or list(range(args.gpus))
+    if len(devices) != args.gpus:
+        print(f"bench.py: --devices lists {len(devices)} members, --gpus says {args.gpus}", file=sys.stderr)
+        return 2
+    if max(devices) >= torch.cuda.device_count():
+        print(f"bench.py: device {max(devices)} not present ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        return 2
+    G = len(devices)
+    P = spf_amd.DEFAULT_128
+    spf_amd.build_library()
+    B = args.batch if args.batch > 0 else (4096 if G == 1 else 8192)
+    t_keys0 = time.time()
+    grp = spf_amd.Group(P, devices=devices)
+    members = [grp.member(i) for i in range(G)]
+    # synthetic keys generated on member 0's device straight into its key blobs, committed there, then replicated by the
+    # library (RCCL broadcast over the distinct devices, device-to-device for a repeated device)
+    dev0 = torch.device("cuda", devices[0])
+    from spf_amd.sharding import _DevArray
+    g = torch.Generator(device=dev0)
+    g.manual_seed(0x5EED0001)
+    with torch.cuda.device(dev0):
+        for which in (0, 1, 2, 3):
+            ptr, nbytes = members[0].key_blob(which)
+            blob = torch.as_tensor(_DevArray(ptr, nbytes), device=dev0)
+            if which == 1:
+                src = torch.randint(-(2 ** 63), 2 ** 63 - 1, (nbytes // 8,), generator=g, device=dev0, dtype=torch.int64)
+            else:
+                src = torch.randn(nbytes // 8, generator=g, device=dev0, dtype=torch.float64) * (2.0 ** 67)
+            blob.copy_(src.view(torch.uint8))
+            del src
+        torch.cuda.synchronize(dev0)
+        for which in (0, 1, 2, 3):
+            members[0].key_blob_commit(which)
+    t_rep0 = time.perf_counter()
+    grp.replicate_keys()
+    t_rep = time.perf_counter() - t_rep0
+    rep = grp.replication_stats()
+
+    lwe0, out, streams = [], [], []
+    for i, d in enumerate(devices):
+        dv = torch.device("cuda", d)
+        gi = torch.Generator(device=dv)
+        gi.manual_seed(0x5EED0100 + i)
+        lwe0.append(torch.randint(-(2 ** 63), 2 ** 63 - 1, (B, P.lwe0_words), generator=gi, device=dv, dtype=torch.int64))
+        out.append(torch.empty((B, P.glwe_words), device=dv, dtype=torch.int64))
+        streams.append(torch.cuda.Stream(device=dv))   # one stream per MEMBER (two members on one device do not share one)
+
+    def step():
+        for i in range(G):
+            members[i].circuit_bootstrap_pbs_dev(streams[i].cuda_stream, B, lwe0[i].data_ptr(), out[i].data_ptr())
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    for m in members:
+        m.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    kms = []
+    for m in members:
+        ms, launches = m.last_kernel_ms("pbs")
+        m.set_timing(False)
+        kms.append(ms)
+    kernel_name = members[0].last_blind_rotate_kernel()
+    value = G * B * args.steps / dt
+    kernel_ms = max(kms)
+    tf = FLOP_PER_PBS * B / (kernel_ms * 1e-3) / 1e12
+
+    # the host-pointer group call: ONE host batch of G x B ciphertexts, cut into G contiguous ranges inside the library
+    lwe_h = np.concatenate([x.cpu().numpy().view(np.uint64) for x in lwe0])
+    out_h = np.zeros((G * B, P.glwe_words), dtype=np.uint64)
+    grp.circuit_bootstrap_pbs(lwe_h, out=out_h)
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        grp.circuit_bootstrap_pbs(lwe_h, out=out_h)
+    t_h = (time.perf_counter() - t0) / reps
+    same = all(bool(np.array_equal(out_h[i * B:(i + 1) * B], out[i].cpu().numpy().view(np.uint64))) for i in range(G))
+
+    cpu = None
+    if G == 1 and not args.no_cpu_baseline:
+        import oracle as O
+        threads = max(1, min(_host_cpus()[0], 64))
+        ptr, nbytes = members[0].key_blob(0)
+        bsk_host = torch.as_tensor(_DevArray(ptr, nbytes), device=dev0).cpu().numpy().view(np.complex128)
+        cnt = threads
+        secs, exp = O.bench_cbs_pbs(lwe_h[:cnt], bsk_host, O.DEFAULT_128, threads)
+        cpu = {"value": round(cnt / secs, 3), "unit": "PBS/s", "cores": threads, "kind": "port",
+               "sample": f"{cnt} of the bench ciphertexts, one per host thread (oracle/spf_oracle.c)",
+               "gpu_outputs_bit_equal_on_sample": bool(np.array_equal(exp, out_h[:cnt]))}
+
+    line = {
+        "metric": "programmable bootstraps/sec (CMUX gates/sec) at default 128-bit params",
+        "value": round(value, 2), "unit": "PBS/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"batch of {B} independent circuit-bootstrap PBS per GPU, DEFAULT_128 "
+                               "(n=637, N=2048, k=1, pbs_radix 2x16), keys resident in HBM",
+                   "batch_per_gpu": B, "global_batch": B * G, "devices": devices,
+                   "parallelism": f"ONE host process, spf_group of {G} members, batch-sharded, keys replicated in-library"},
+        "roofline": {"bound": "fp64", "achieved": round(tf, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / FP64_PEAK_TFLOPS, 4), "traffic": None, "kernel": kernel_name,
+                     "kernel_ms": round(kernel_ms, 3), "kernel_ms_min_max_over_members": [round(min(kms), 3), round(max(kms), 3)],
+                     "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
+                     "note": "per member; two members on one device share its CUs (a rehearsal, not a measurement)"
+                             if len(set(devices)) < G else "per member"},
+        "cpu_baseline": cpu,
+        "rccl": {"backend": "rccl (in-library: ncclCommInitAll + in-place ncclBroadcast, single process)"
+                            if rep["transport"] == "rccl" else rep["transport"],
+                 "world_size": rep["rccl_world_size"] if rep["transport"] == "rccl" else G,
+                 "members": G, "distinct_devices": len(set(devices)),
+                 "broadcast_s": round(rep["wire_seconds"], 4), "comm_init_s": round(rep["comm_init_seconds"], 4),
+                 "replicate_keys_s": round(t_rep, 4), "broadcast_bytes": rep["bytes_per_member"],
+                 "broadcast_GBs": round(rep["bytes_per_member"] / max(rep["wire_seconds"], 1e-9) / 1e9, 2)},
+        "key_broadcast_s": round(rep["wire_seconds"], 4), "key_broadcast_bytes": rep["bytes_per_member"],
+        "pcie_inclusive": {"pbs_per_s": round(G * B / t_h, 1), "ms_per_batch": round(t_h * 1e3, 3),
+                           "note": "spf_group_circuit_bootstrap_pbs_batch: one pageable host batch of G x B ciphertexts cut into G "
+                                   "contiguous ranges, each member's H2D / kernels / sliced D2H on its own thread and stream",
+                           "same_words_as_device_path": same},
+        "setup_s": round(time.time() - t_keys0, 2),
+    }
+    print(json.dumps(line))
+    grp.close()
     return 0
 
 
@@ -623,13 +800,7 @@ def _bench_evaluation_pool(eng, P, dev, torch, thread_counts=(64, 256, 1024), se
     drv.spf_pool_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_size_t,
                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
     cpus_before = os.sched_getaffinity(0)
-    n_quota = len(cpus_before)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n_quota = max(1, min(n_quota, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
+    n_quota = _host_cpus()[0]
     os.sched_setaffinity(0, set(sorted(cpus_before)[:n_quota]))   # the driver's threads inherit it
     out_cpus = n_quota
     lib = eng._lib

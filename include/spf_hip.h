@@ -396,6 +396,91 @@ const char *spf_last_blind_rotate_kernel(spf_ctx *ctx);
  * exceed the Infinity Cache.  Never NULL. */
 const char *spf_last_cmux_kernel(spf_ctx *ctx);
 
+/* ---- device groups: every GPU of a node from ONE host process (SURVEY.md §8 b / e) -------------------------------- *
+ *
+ * The caller being replaced is one process: `Evaluation` holds an `Arc<ComputeKey>` (crypto/evaluation.rs:144-197) and is
+ * called from the rayon workers of one `CircuitProcessor` (circuit_processor/mod.rs:201-209).  A group is what that one
+ * `Evaluation` owns on a multi-GPU node: one context per listed device (a device may be listed more than once: that many
+ * contexts on it), the evaluation keys replicated INSIDE the library, and batch entry points that cut a host batch into
+ * contiguous ranges of ceil(B / G) — bootstraps are independent units, there is no data-path collective — and drive every
+ * member from its own host thread and stream.
+ *
+ * Keys: the loaders put the key on member 0 (host -> HBM) and replicate it: one RCCL communicator over the distinct
+ * devices (`ncclCommInitAll`, single process) and an in-place `ncclBroadcast` of each key blob from member 0 over xGMI;
+ * further members on an already served device take a device-to-device copy; every member then derives its own images
+ * (keyswitch byte planes, scaled bootstrap key).  librccl.so is loaded on first use (dlopen); transport can be forced with
+ * the environment variable SPF_GROUP_TRANSPORT = "rccl" (default whenever the group has more than one member; also taken
+ * for a one-member group when set explicitly) or "peer" (hipMemcpyPeerAsync, no RCCL).  A missing librccl.so with
+ * transport rccl is SPF_ERR_HIP, never a silent change of transport.
+ *
+ * Failures: a member whose call fails with SPF_ERR_HIP is taken out of rotation and its range is re-queued over the
+ * remaining members ("a failed GPU's shard is re-queued by host"); the call fails only when no member is
+ * left.  Any other status (invalid argument, missing key) is the caller's error and is returned at once.
+ * `spf_group_set_member_enabled` drains or re-admits a device by hand.
+ *
+ * Thread safety: every entry point may be called from any number of host threads; calls are queued per member. */
+typedef struct spf_group spf_group;
+spf_status spf_group_create(const spf_params *params, const int *device_ids, int n_devices, spf_group **out);
+void spf_group_destroy(spf_group *grp);
+int spf_group_size(const spf_group *grp);
+/* member i's context: for the `_dev` entry points, gate graphs and measurement hooks on that device.  Owned by the group. */
+spf_ctx *spf_group_ctx(spf_group *grp, int member);
+/* message of the last failing group call (storage of the calling thread, as spf_last_error) */
+const char *spf_group_last_error(const spf_group *grp);
+
+/* `ComputeKey` fields (crypto/keys.rs:306-318): upload to member 0, replicate, derive.  Same argument meaning as the
+ * single-context loaders above. */
+spf_status spf_group_load_bootstrap_key(spf_group *grp, const double *bsk_fft, size_t n_complex);
+spf_status spf_group_load_keyswitch_key(spf_group *grp, const uint64_t *ksk, size_t n_words);
+spf_status spf_group_load_automorphism_key(spf_group *grp, const double *ak_fft, size_t n_complex);
+spf_status spf_group_load_scheme_switch_key(spf_group *grp, const double *ssk_fft, size_t n_complex);
+spf_status spf_group_load_compute_key_bincode(spf_group *grp, const uint8_t *bytes, size_t len);
+/* replicate whatever member 0 holds (keys put there through spf_group_ctx(grp, 0), e.g. generated on the device into
+ * spf_key_blob + spf_key_blob_commit) */
+spf_status spf_group_replicate_keys(spf_group *grp);
+/* totals since the group was created: seconds on the wire (communicator set-up counted separately), bytes received per
+ * member, ranks of the RCCL communicator (0 = RCCL not used), transport name ("rccl", "peer", "none"; never NULL) */
+spf_status spf_group_replication_stats(spf_group *grp, double *wire_seconds, double *comm_init_seconds, size_t *bytes_per_member,
+                                       int *rccl_world_size, const char **transport);
+/* take a member out of rotation (enabled = 0) or back in (1; also clears a recorded failure) */
+spf_status spf_group_set_member_enabled(spf_group *grp, int member, int enabled);
+/* members in rotation now */
+int spf_group_members_in_rotation(spf_group *grp);
+/* testing hook: the next `count` calls dispatched to `member` fail with SPF_ERR_HIP before touching the device */
+spf_status spf_group_debug_fail_next(spf_group *grp, int member, int count);
+
+/* The host-pointer batch forms over the group: same arguments as spf_*_batch, results word-identical to one context. */
+spf_status spf_group_keyswitch_lwe_l1_lwe_l0_batch(spf_group *grp, size_t B, const uint64_t *lwe1_in, uint64_t *lwe0_out);
+spf_status spf_group_generalized_pbs_batch(spf_group *grp, size_t B, const uint64_t *lwe0_in, const uint64_t *lut_glwe,
+                                           size_t lut_stride, uint32_t log_chi, uint32_t log_v, uint64_t body_rotate,
+                                           uint64_t *glwe_out);
+spf_status spf_group_pbs_univariate_batch(spf_group *grp, size_t B, const uint64_t *lwe0_in, const uint64_t *lut_glwe,
+                                          size_t lut_stride, uint64_t *lwe1_out);
+spf_status spf_group_circuit_bootstrap_pbs_batch(spf_group *grp, size_t B, const uint64_t *lwe0_in, uint64_t *glwe_out);
+spf_status spf_group_circuit_bootstrap_batch(spf_group *grp, size_t B, const uint64_t *lwe0_in, double *ggsw_fft_out);
+spf_status spf_group_mod_switch_trace_and_rotate_batch(spf_group *grp, size_t B, const uint64_t *glwe_in, uint64_t *glev_out);
+spf_status spf_group_scheme_switch_batch(spf_group *grp, size_t B, const uint64_t *glev_in, double *ggsw_fft_out);
+spf_status spf_group_sample_extract_l1_batch(spf_group *grp, size_t B, const uint64_t *glwe_in, size_t idx, uint64_t *lwe1_out);
+spf_status spf_group_glwe_not_batch(spf_group *grp, size_t B, const uint64_t *glwe_in, uint64_t *glwe_out);
+spf_status spf_group_glwe_xor_batch(spf_group *grp, size_t B, const uint64_t *a, const uint64_t *b, uint64_t *glwe_out);
+spf_status spf_group_glwe_mul_xn_batch(spf_group *grp, size_t B, const uint64_t *glwe_in, size_t n, uint64_t *glwe_out);
+spf_status spf_group_cmux_batch(spf_group *grp, size_t B, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
+                                uint64_t *out);
+spf_status spf_group_glev_cmux_batch(spf_group *grp, size_t B, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
+                                     uint64_t *out);
+spf_status spf_group_multiply_glwe_ggsw_batch(spf_group *grp, size_t B, const uint64_t *glwe, const double *ggsw_fft,
+                                              uint64_t *out);
+spf_status spf_group_gate_bootstrap_batch(spf_group *grp, size_t B, const uint64_t *lwe1_in, uint64_t *glwe_out);
+spf_status spf_group_keyswitch_circuit_bootstrap_batch(spf_group *grp, size_t B, const uint64_t *lwe1_in, double *ggsw_fft_out);
+/* `Evaluation::l1ggsw_zero` / `l1ggsw_one` (identical on every member: same keys, same kernels; taken from member 0) */
+spf_status spf_group_l1ggsw_constant(spf_group *grp, int bit, double *ggsw_fft_out);
+
+/* Call coalescing over the group: one pool per member; a calling thread is dealt to a member on its first submit
+ * (round-robin over the members in rotation) and stays there, so that the callers of one device keep coming back to the
+ * same batch.  The handle is used with the spf_pool_submit_*, spf_pool_wait, spf_pool_stats (sums), spf_pool_set_max_inflight
+ * (per member) and spf_pool_destroy entry points above. */
+spf_status spf_pool_create_group(spf_group *grp, size_t max_batch, uint32_t max_wait_us, spf_pool **out);
+
 /* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */
 const char *spf_version(void);
 

@@ -113,6 +113,41 @@ SYMBOLS = [
     ("spf_ciphertext_from_bincode", _I, [C.POINTER(_CParams), _I, _P, _SZ, _P]),
     ("spf_ciphertext_to_bincode", _I, [C.POINTER(_CParams), _I, _P, _P, _SZ, C.POINTER(_SZ)]),
     ("spf_version", C.c_char_p, []),
+    # device groups (one host process, every GPU of the node)
+    ("spf_group_create", _I, [C.POINTER(_CParams), C.POINTER(_I), _I, C.POINTER(_P)]),
+    ("spf_group_destroy", None, [_P]),
+    ("spf_group_size", _I, [_P]),
+    ("spf_group_ctx", _P, [_P, _I]),
+    ("spf_group_last_error", C.c_char_p, [_P]),
+    ("spf_group_load_bootstrap_key", _I, [_P, _P, _SZ]),
+    ("spf_group_load_keyswitch_key", _I, [_P, _P, _SZ]),
+    ("spf_group_load_automorphism_key", _I, [_P, _P, _SZ]),
+    ("spf_group_load_scheme_switch_key", _I, [_P, _P, _SZ]),
+    ("spf_group_load_compute_key_bincode", _I, [_P, _P, _SZ]),
+    ("spf_group_replicate_keys", _I, [_P]),
+    ("spf_group_replication_stats", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_SZ), C.POINTER(_I),
+                                         C.POINTER(C.c_char_p)]),
+    ("spf_group_set_member_enabled", _I, [_P, _I, _I]),
+    ("spf_group_members_in_rotation", _I, [_P]),
+    ("spf_group_debug_fail_next", _I, [_P, _I, _I]),
+    ("spf_group_keyswitch_lwe_l1_lwe_l0_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_generalized_pbs_batch", _I, [_P, _SZ, _P, _P, _SZ, _U32, _U32, _U64, _P]),
+    ("spf_group_pbs_univariate_batch", _I, [_P, _SZ, _P, _P, _SZ, _P]),
+    ("spf_group_circuit_bootstrap_pbs_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_mod_switch_trace_and_rotate_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_scheme_switch_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_sample_extract_l1_batch", _I, [_P, _SZ, _P, _SZ, _P]),
+    ("spf_group_glwe_not_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_glwe_xor_batch", _I, [_P, _SZ, _P, _P, _P]),
+    ("spf_group_glwe_mul_xn_batch", _I, [_P, _SZ, _P, _SZ, _P]),
+    ("spf_group_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
+    ("spf_group_glev_cmux_batch", _I, [_P, _SZ, _P, _P, _P, _P]),
+    ("spf_group_multiply_glwe_ggsw_batch", _I, [_P, _SZ, _P, _P, _P]),
+    ("spf_group_gate_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_keyswitch_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
+    ("spf_group_l1ggsw_constant", _I, [_P, _I, _P]),
+    ("spf_pool_create_group", _I, [_P, _SZ, _U32, C.POINTER(_P)]),
 ]
 
 
@@ -496,16 +531,112 @@ class Engine:
         return ms.value, n.value
 
 
+class _GroupLib:
+    """the library seen through a group handle: `spf_X` resolves to `spf_group_X` where the group has that entry point, so
+    that every host-array method of Engine runs unchanged over the group"""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        if name.startswith("spf_") and not name.startswith("spf_group_"):
+            fn = getattr(self._lib, "spf_group_" + name[4:], None)
+            if fn is not None:
+                return fn
+            if name not in ("spf_version",):   # anything else would take the group handle for a context
+                raise SpfError(-2, f"{name} has no group form: use group.member(i)")
+        return getattr(self._lib, name)
+
+
+class _MemberEngine(Engine):
+    """member i of a group as an Engine (the `_dev` forms, gate graphs, measurement hooks on that device); the context
+    belongs to the group"""
+
+    def __init__(self, group: "Group", member: int):
+        self._lib = group._raw
+        self.params = group.params
+        self.device = group.devices[member]
+        self._group = group   # keeps the owner alive
+        self._h = C.c_void_p(group._raw.spf_group_ctx(group._h, member))
+        if not self._h:
+            raise SpfError(-2, f"group has no member {member}")
+
+    def close(self):
+        self._h = None
+
+
+class Group(Engine):
+    """Every listed GPU behind one handle (`spf_group`): keys replicated inside the library (RCCL broadcast from member 0),
+    host batches cut into contiguous ranges of ceil(B / G).  Has every host-array method of Engine; the device-pointer
+    forms belong to a member: `group.member(i)`."""
+
+    def __init__(self, params: Params = DEFAULT_128, devices=(0,)):
+        self._raw = load_library()
+        self._lib = _GroupLib(self._raw)
+        self.params = params
+        self.devices = [int(d) for d in devices]
+        self.device = self.devices[0]
+        cp = _cparams(params)
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        st = self._raw.spf_group_create(C.byref(cp), ids, len(self.devices), C.byref(h))
+        if st != 0:
+            raise SpfError(st, (self._raw.spf_last_error(None) or b"").decode())
+        self._h = h
+
+    def _ck(self, st: int):
+        if st != 0:
+            raise SpfError(st, (self._raw.spf_group_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._raw.spf_group_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return int(self._raw.spf_group_size(self._h))
+
+    def member(self, i: int) -> Engine:
+        return _MemberEngine(self, i)
+
+    def replicate_keys(self):
+        self._ck(self._raw.spf_group_replicate_keys(self._h))
+
+    def replication_stats(self) -> dict:
+        w, ci, b, ws, t = C.c_double(), C.c_double(), C.c_size_t(), C.c_int(), C.c_char_p()
+        self._ck(self._raw.spf_group_replication_stats(self._h, C.byref(w), C.byref(ci), C.byref(b), C.byref(ws), C.byref(t)))
+        return {"wire_seconds": w.value, "comm_init_seconds": ci.value, "bytes_per_member": b.value,
+                "rccl_world_size": ws.value, "transport": (t.value or b"").decode()}
+
+    def set_member_enabled(self, member: int, enabled: bool):
+        self._ck(self._raw.spf_group_set_member_enabled(self._h, member, 1 if enabled else 0))
+
+    def members_in_rotation(self) -> int:
+        return int(self._raw.spf_group_members_in_rotation(self._h))
+
+    def debug_fail_next(self, member: int, count: int = 1):
+        self._ck(self._raw.spf_group_debug_fail_next(self._h, member, count))
+
+    # the per-context hooks have no group form
+    def key_blob(self, which):
+        raise SpfError(-2, "key blobs belong to a member: group.member(i).key_blob(which)")
+
+    key_blob_commit = key_blob
+
+
 class Pool:
     """Call-coalescing front end (`spf_pool`): many threads submit single-ciphertext operations and
     block in wait(); a worker thread runs what is pending as one batch.  The synchronous methods
     below are what a per-op caller (the reference's rayon task) would use."""
 
     def __init__(self, engine: Engine, max_batch: int = 4096, max_wait_us: int = 200):
-        self._lib = engine._lib
+        self._lib = load_library()
         self.engine = engine
         h = C.c_void_p()
-        st = self._lib.spf_pool_create(engine._h, max_batch, max_wait_us, C.byref(h))
+        if isinstance(engine, Group):   # one pool per member, callers dealt across the devices
+            st = self._lib.spf_pool_create_group(engine._h, max_batch, max_wait_us, C.byref(h))
+        else:
+            st = self._lib.spf_pool_create(engine._h, max_batch, max_wait_us, C.byref(h))
         if st != 0:
             raise SpfError(st, "spf_pool_create failed")
         self._h = h
@@ -547,6 +678,9 @@ class Pool:
     def _wait(self, ticket):
         st = self._lib.spf_pool_wait(self._h, ticket)
         if st != 0:
+            if isinstance(self.engine, Group):
+                eng = self.engine.member(min(ticket >> 56, len(self.engine.devices) - 1))
+                raise SpfError(st, (self._lib.spf_last_error(eng._h) or b"").decode())
             raise SpfError(st, (self._lib.spf_last_error(self.engine._h) or b"").decode())
 
     def keyswitch_lwe_l1_lwe_l0(self, output: np.ndarray, input: np.ndarray):

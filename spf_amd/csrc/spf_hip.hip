@@ -569,6 +569,9 @@ spf_status spf_key_blob_commit(spf_ctx* c, int which)
     if (!c) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null context");
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device)); // the byte planes are allocated and built on THIS context's GPU
+    // Whatever filled the blob (a copy on the caller's stream, an RCCL broadcast on its own) must have landed before the derived
+    // images are built from it on this context's stream, which is ordered with no other stream: once per key load.
+    HIPCHK(c, hipDeviceSynchronize());
     if (which == 0 && c->d_bsk) {
         spf_status st = finish_bootstrap_key(c);
         if (st != SPF_OK) return st;
@@ -1671,6 +1674,10 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
 spf_status spf_pool_set_max_inflight(spf_pool* p, size_t max_inflight)
 {
     if (!p || max_inflight == 0) return SPF_ERR_INVALID_ARGUMENT;
+    if (!p->members.empty()) { // a group pool: the bound applies to every member
+        for (spf_pool* q : p->members) (void)spf_pool_set_max_inflight(q, max_inflight);
+        return SPF_OK;
+    }
     std::lock_guard<std::mutex> lk(p->mu);
     p->max_inflight = max_inflight;
     p->cv_space.notify_all();
@@ -1680,6 +1687,11 @@ spf_status spf_pool_set_max_inflight(spf_pool* p, size_t max_inflight)
 void spf_pool_destroy(spf_pool* p)
 {
     if (!p) return;
+    if (!p->members.empty()) { // a group pool owns one pool per member and no threads of its own
+        for (spf_pool* q : p->members) spf_pool_destroy(q);
+        delete p;
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(p->mu);
         p->stop = true;
@@ -1706,33 +1718,67 @@ void spf_pool_destroy(spf_pool* p)
     delete p;
 }
 
+} // extern "C"
+
+// the pool an operation of the calling thread goes to: the pool itself, or — a group pool — the thread's home member
+// (defined with the group, spf_group.hpp)
+static spf_pool* pool_deal(spf_pool* top, int* member);
+
+static spf_status pool_submit(spf_pool* p, int op, const void* a, const void* b, const void* c, void* out, uint64_t* ticket)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    int member = 0;
+    spf_pool* q = pool_deal(p, &member);
+    if (!q) return SPF_ERR_HIP; // no member of the group is in rotation
+    const spf_status st = q->submit(op, a, b, c, out, ticket);
+    if (st == SPF_OK && q != p) *ticket |= (uint64_t)member << spf_pool::kMemberShift;
+    return st;
+}
+
+extern "C" {
+
 spf_status spf_pool_submit_keyswitch(spf_pool* p, const uint64_t* in, uint64_t* out, uint64_t* ticket)
 {
-    return p ? p->submit(spf_pool_impl::OP_KEYSWITCH, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_KEYSWITCH, in, nullptr, nullptr, out, ticket);
 }
 spf_status spf_pool_submit_circuit_bootstrap(spf_pool* p, const uint64_t* in, double* out, uint64_t* ticket)
 {
-    return p ? p->submit(spf_pool_impl::OP_CBS, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_CBS, in, nullptr, nullptr, out, ticket);
 }
 spf_status spf_pool_submit_keyswitch_circuit_bootstrap(spf_pool* p, const uint64_t* in, double* out, uint64_t* ticket)
 {
-    return p ? p->submit(spf_pool_impl::OP_GATE_CBS, in, nullptr, nullptr, out, ticket) : SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_GATE_CBS, in, nullptr, nullptr, out, ticket);
 }
 spf_status spf_pool_submit_cmux(spf_pool* p, const double* sel, const uint64_t* a, const uint64_t* b, uint64_t* out,
                                 uint64_t* ticket)
 {
     if (!p || !a || !b) return SPF_ERR_INVALID_ARGUMENT;
-    return p->submit(spf_pool_impl::OP_CMUX, sel, a, b, out, ticket);
+    return pool_submit(p, spf_pool_impl::OP_CMUX, sel, a, b, out, ticket);
 }
 
 spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)
 {
-    return p ? p->wait(ticket) : SPF_ERR_INVALID_ARGUMENT;
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    if (!p->members.empty()) {
+        const uint64_t member = ticket >> spf_pool::kMemberShift;
+        if (member >= p->members.size()) return SPF_ERR_INVALID_ARGUMENT;
+        return p->members[member]->wait(ticket & (((uint64_t)1 << spf_pool::kMemberShift) - 1));
+    }
+    return p->wait(ticket);
 }
 
 spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
 {
     if (!p || !ops || !launches) return SPF_ERR_INVALID_ARGUMENT;
+    if (!p->members.empty()) {
+        *ops = *launches = 0;
+        for (spf_pool* q : p->members) {
+            uint64_t o = 0, l = 0;
+            (void)spf_pool_stats(q, &o, &l);
+            *ops += o; *launches += l;
+        }
+        return SPF_OK;
+    }
     std::lock_guard<std::mutex> lk(p->mu);
     *ops = p->n_ops; *launches = p->n_launches;
     return SPF_OK;
@@ -1741,3 +1787,4 @@ spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
 } // extern "C"
 
 #include "spf_graph.hpp"
+#include "spf_group.hpp"

@@ -134,8 +134,18 @@ struct Batch {
 
 } // namespace spf_pool_impl
 
+struct spf_group;
+
 struct spf_pool {
     using Batch = spf_pool_impl::Batch;
+    // A pool over a device group (spf_pool_create_group) is only a dealer: one ordinary pool per member, the calling thread's
+    // home member decided on its first submit; tickets carry the member in their top byte.  Nothing below `members` is used then.
+    static constexpr int kMemberShift = 56;
+    std::vector<spf_pool*> members;
+    spf_group* grp = nullptr;
+    std::mutex deal_mu;
+    std::unordered_map<uintptr_t, int> home; // calling thread -> member
+    size_t next_home = 0;
     spf_ctx* ctx = nullptr;
     spf_params prm{};
     size_t max_batch = 4096;
