@@ -575,7 +575,7 @@ class Group(Engine):
         self._lib = _GroupLib(self._raw)
         self.params = params
         self.devices = [int(d) for d in devices]
-        self.device = self.devices[0]
+        self.device = self.devices[0] if self.devices else -1
         cp = _cparams(params)
         ids = (C.c_int * len(self.devices))(*self.devices)
         h = C.c_void_p()

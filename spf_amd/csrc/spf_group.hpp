@@ -305,11 +305,13 @@ spf_status replicate_blob(spf_group* g, int which)
         if (i && b != bytes) return gfail(g, SPF_ERR_INVALID_ARGUMENT, "key blobs of the members differ in size");
         bytes = b;
     }
-    const auto t0 = std::chrono::steady_clock::now();
     auto hipfail = [&](const char* what, hipError_t e) { return gfail(g, SPF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
     if (g->transport == spf_group::T_RCCL) {
-        spf_status s = ensure_rccl(g);
+        spf_status s = ensure_rccl(g); // (communicator set-up is timed by itself: comm_init_seconds)
         if (s != SPF_OK) return s;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (g->transport == spf_group::T_RCCL) {
         // in place: the root sends from its blob, everyone else receives into theirs; one call per rank inside a group
         // (a single thread drives every rank of the communicator)
         ncclResult_t r = g->rccl.GroupStart();

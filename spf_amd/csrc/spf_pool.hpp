@@ -61,7 +61,8 @@ constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: c
 struct Slot {
     void* out;
     uint64_t ticket;
-    bool delivered; // output already copied to `out` (by the launcher, for a ticket nobody collected in time)
+    uint8_t delivered; // 0: output still in the staging set; 1: being copied to `out` by reclaim() on the owner's behalf (the lock is
+                       // dropped for the copy: a wait() that arrives meanwhile parks on cv_deliver); 2: in `out`
     uintptr_t who;  // the submitting thread (see `last_members`)
 };
 
@@ -151,7 +152,7 @@ struct spf_pool {
     size_t max_batch = 4096;
     std::chrono::microseconds max_wait{200};
     std::mutex mu;
-    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_flight;
+    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_flight, cv_deliver;
     std::shared_ptr<Batch> filling[spf_pool_impl::N_OPS];
     std::deque<std::shared_ptr<Batch>> closing;                                     // closed, waiting for their members' input copies
     std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, waited for by the completer
@@ -322,7 +323,7 @@ struct spf_pool {
         try {
             slot = b->n;
             const uintptr_t who = (uintptr_t)pthread_self();
-            b->slots.push_back(Slot{out, next_ticket, false, who});
+            b->slots.push_back(Slot{out, next_ticket, 0, who});
             if (std::binary_search(last_members[op].begin(), last_members[op].end(), who)) b->n_returning++;
             tickets.emplace(next_ticket, std::make_pair(b, slot));
         } catch (const std::exception&) {
@@ -409,12 +410,14 @@ struct spf_pool {
                 if (sl.delivered || claimed.count(sl.ticket)) continue; // (a claimed ticket's waiter is copying right now)
                 auto it = tickets.find(sl.ticket);
                 if (it == tickets.end()) continue;                      // collected already
-                sl.delivered = true;
                 if (b->st == SPF_OK) {
-                    lk.unlock();
+                    sl.delivered = 1; // (a wait() for this ticket that arrives during the copy must not return before it ends:
+                    lk.unlock();      //  the caller may free or read `out` the moment wait returns, spf_hip.h)
                     deliver(*b, i);
                     lk.lock();
                 }
+                sl.delivered = 2;
+                cv_deliver.notify_all();
                 collected_one(b); // the ticket stays open (its status is still to be fetched), its bytes are out
                 if (!sets[b->set].busy) return;
             }
@@ -439,11 +442,13 @@ struct spf_pool {
         std::atomic<uint32_t>& word = b->chunk_word[spf_pool_impl::Batch::word_of(slot)];
         while (word.load(std::memory_order_acquire) == 0) spf_pool_impl::futex_wait(&word, 0);
         const spf_status st = b->st;
-        // (`delivered` is only ever set for an unclaimed ticket, under the mutex this thread's claim went through)
-        if (st == SPF_OK && !b->slots[slot].delivered) deliver(*b, slot); // this caller's output, by this caller's thread
-        std::lock_guard<std::mutex> lk(mu);
-        if (!b->slots[slot].delivered) {
-            b->slots[slot].delivered = true;
+        // (`delivered` leaves 0 only for an unclaimed ticket, under the mutex this thread's claim went through: what this thread
+        // reads here without the lock is either 0 for good, or the 1 / 2 that reclaim() set before the claim)
+        if (st == SPF_OK && b->slots[slot].delivered == 0) deliver(*b, slot); // this caller's output, by this caller's thread
+        std::unique_lock<std::mutex> lk(mu);
+        cv_deliver.wait(lk, [&] { return b->slots[slot].delivered != 1; }); // a delivery on this ticket's behalf is still copying
+        if (b->slots[slot].delivered == 0) {
+            b->slots[slot].delivered = 2;
             collected_one(b);
         }
         tickets.erase(ticket);

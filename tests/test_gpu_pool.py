@@ -246,6 +246,50 @@ def test_pool_survives_tickets_nobody_collects_in_time(rig):
     pool.close()                                             # tickets n-2, n-1 never collected
 
 
+def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig):
+    """reclaim() copies an uncollected output to the caller's buffer with the pool's lock dropped; a wait() for
+    that ticket arriving DURING the copy must not return before the copy has ended (the caller may read or free `out` the
+    moment wait returns).  Circuit bootstraps (256 KiB outputs, the longest copies); every set held by uncollected batches;
+    one thread's submit triggers the delivery while other threads wait for exactly those tickets and compare at once."""
+    import threading
+    import time
+    ks, eng = rig
+    P = ks.params
+    lwe0 = random_lwe_batch(41, 8, SMALL_N)
+    exp = eng.circuit_bootstrap(lwe0)
+    for rnd in range(4):
+        pool = spf_amd.Pool(eng, max_batch=2, max_wait_us=100)
+        pool.set_max_inflight(64)
+        outs = [np.zeros(eng.params.cbs_ggsw_complex, dtype=np.complex128) for _ in range(8)]
+        tk = []
+        for i in range(6):                                   # three batches of two: every staging set held
+            t = spf_amd._ffi.C.c_uint64()
+            x = np.ascontiguousarray(lwe0[i])
+            st = pool._lib.spf_pool_submit_circuit_bootstrap(pool._h, x.ctypes.data_as(spf_amd._ffi.C.c_void_p),
+                                                             outs[i].ctypes.data_as(spf_amd._ffi.C.c_void_p), spf_amd._ffi.C.byref(t))
+            assert st == 0
+            tk.append(t.value)
+        time.sleep(0.3 + 0.01 * rnd)                         # past the grace period: the next submit delivers the leftovers
+        bad = []
+
+        def waiter(i):
+            pool._wait(tk[i])
+            if not np.array_equal(outs[i].view(np.float64), exp[i].view(np.float64)):
+                bad.append(i)
+
+        def submitter():
+            pool.circuit_bootstrap(outs[6], lwe0[6])         # no set free: reclaim() runs inside this submit
+
+        th = [threading.Thread(target=submitter)] + [threading.Thread(target=waiter, args=(i,)) for i in range(6)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, (rnd, bad)
+        assert np.array_equal(outs[6].view(np.float64), exp[6].view(np.float64))
+        pool.close()
+
+
 def test_pool_under_native_load_every_caller_gets_its_own_output(rig):
     """The drop-in scenario with the load generator of the bench leg (tools/pool_driver.cpp: native threads, each looping
     KeyswitchL1toL0 -> CircuitBootstrap on its own ciphertext through the pool for a second): 300 callers, so the batches leave
