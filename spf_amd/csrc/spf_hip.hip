@@ -38,6 +38,12 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+// intermediates of the keyswitch (digits [Mpad][K], digit sums [Mpad]) and of the circuit bootstrap (lo-noise GLWE, GLEV): one set
+// per stream of work that may run concurrently — the context's own for the entry points, one per staging set of a pool
+struct Scratch {
+    DevBuf ks_dig, ks_rowsum, cbs_glwe, cbs_glev;
+};
+
 // kernels whose launches spf_set_timing brackets with hipEvents on the launch stream (spf_last_kernel_ms)
 enum TimedKernel { T_PBS = 0, T_KS, T_TRACE, T_SS, T_CMUX, T_COUNT };
 const char* const kTimedNames[T_COUNT] = {"pbs", "keyswitch", "trace", "scheme_switch", "cmux"};
@@ -62,14 +68,13 @@ struct spf_ctx {
     DevBuf in, out, mid, aux;      // staging for the host-pointer entry points
     int8_t* d_ksk_planes = nullptr; // key byte planes for the int8-MFMA keyswitch [Npad][K]
     size_t ks_npad = 0;
-    DevBuf ks_dig, ks_rowsum;       // per-call digits [Mpad][K] and digit sums [Mpad]
+    Scratch scr;                    // intermediates of the entry points (keyswitch digits, circuit-bootstrap GLWE / GLEV)
     c64* d_ak = nullptr;            // automorphism key, FFT'd: [log2 N][l_tr][2][N/2]
     size_t ak_bytes = 0;
     bool ak_ready = false;
     c64* d_ssk = nullptr;           // scheme-switch key, FFT'd: [l_ss][2][N/2]
     size_t ssk_bytes = 0;
     bool ssk_ready = false;
-    DevBuf cbs_glwe, cbs_glev;      // circuit-bootstrap intermediates (lo-noise GLWE, GLEV)
     double* d_ggsw_const = nullptr; // l1ggsw_zero | l1ggsw_one (Evaluation::new, evaluation.rs:161-197), built on first use
     bool ggsw_const_ready = false;  // reset whenever a key of the circuit bootstrap changes
     int n_cu = 256;                // compute units of the device (picks the blind-rotation shape)
@@ -82,8 +87,6 @@ struct spf_ctx {
     bool timing = false;
     std::vector<TimedLaunch> timed[T_COUNT];
 };
-
-#include "spf_pool.hpp"
 
 namespace {
 
@@ -222,7 +225,7 @@ struct TimedScope {
 spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe,
                                const uint64_t* d_lut, size_t lut_stride, uint32_t log_chi,
                                uint32_t log_v, uint64_t body_rotate, uint64_t* d_out,
-                               size_t out_stride, bool extract)
+                               size_t out_stride, bool extract, int per_wg_hint = 0)
 {
     if (!c->bsk_ready) return fail(c, SPF_ERR_NO_KEY, "bootstrap key not loaded");
     if (B == 0) return SPF_OK;
@@ -237,9 +240,11 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     // Shape by batch size: at most one ciphertext per CU -> eight waves per ciphertext (blind_rotate8_kernel, latency);
     // up to two per CU -> the paired schedule with two ciphertexts per workgroup (blind_rotate2p2_kernel);
     // beyond -> four ciphertexts per workgroup, one workgroup per CU, two waves per SIMD (blind_rotate2p_kernel).
+    // per_wg_hint (the pool): ciphertexts per workgroup the CALLER wants at least — a batch that shares the chip with other
+    // batches in flight takes the shape of the whole population, so that the batches tile the CUs instead of each spreading thin.
     const size_t n_cu = (size_t)c->n_cu;
-    const bool quad = B <= n_cu;
-    const bool pair2 = !quad && B <= 2 * n_cu;
+    const bool quad = B <= n_cu && per_wg_hint <= 1;
+    const bool pair2 = !quad && B <= 2 * n_cu && per_wg_hint <= 2;
     const size_t per_wg = quad ? 1 : (pair2 ? 2 : 4);
     dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(pair2 ? 256 : 512);
     TimedScope ts(c, s, T_PBS);
@@ -334,8 +339,9 @@ spf_status build_ks_planes(spf_ctx* c)
 }
 
 spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_in,
-                            uint64_t* d_out)
+                            uint64_t* d_out, Scratch* sc = nullptr)
 {
+    if (!sc) sc = &c->scr;
     if (!c->ksk_ready) return fail(c, SPF_ERR_NO_KEY, "keyswitch key not loaded");
     if (B == 0) return SPF_OK;
     if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
@@ -346,9 +352,9 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
     const bool mfma = c->d_ksk_planes != nullptr; // (null when the radix does not fit the int8 formulation: keyswitch_kernel)
     const size_t K = (size_t)a.n_in * a.count, mpad = (B + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
     if (mfma) {
-        spf_status st = ensure(c, c->ks_dig, mpad * K);
+        spf_status st = ensure(c, sc->ks_dig, mpad * K);
         if (st != SPF_OK) return st;
-        st = ensure(c, c->ks_rowsum, mpad * sizeof(int));
+        st = ensure(c, sc->ks_rowsum, mpad * sizeof(int));
         if (st != SPF_OK) return st;
     }
     TimedScope ts(c, s, T_KS);
@@ -357,11 +363,11 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
         if (st != SPF_OK) return st;
     }
     if (mfma) {
-        HIPCHK(c, hipMemsetAsync(c->ks_rowsum.p, 0, mpad * sizeof(int), s));
-        hipLaunchKernelGGL(ks_digits_kernel, dim3((unsigned)B), dim3(256), 0, s, d_in, (int8_t*)c->ks_dig.p,
-                           (int*)c->ks_rowsum.p, a.n_in, a.B, a.radix_log, a.count);
+        HIPCHK(c, hipMemsetAsync(sc->ks_rowsum.p, 0, mpad * sizeof(int), s));
+        hipLaunchKernelGGL(ks_digits_kernel, dim3((unsigned)B), dim3(256), 0, s, d_in, (int8_t*)sc->ks_dig.p,
+                           (int*)sc->ks_rowsum.p, a.n_in, a.B, a.radix_log, a.count);
         KsGemmArgs g{};
-        g.A = (const int8_t*)c->ks_dig.p; g.Bt = c->d_ksk_planes; g.rowsum = (const int*)c->ks_rowsum.p;
+        g.A = (const int8_t*)sc->ks_dig.p; g.Bt = c->d_ksk_planes; g.rowsum = (const int*)sc->ks_rowsum.p;
         g.in = d_in; g.out = d_out; g.B = a.B; g.n_in = a.n_in; g.n_out = a.n_out; g.K = (uint32_t)K;
         dim3 grid((unsigned)(c->ks_npad / KSG_TILE), (unsigned)(mpad / KSG_TILE));
         hipLaunchKernelGGL(ks_gemm_lds_kernel, grid, dim3(256), kKsLdsBytes, s, g); // operand tiles staged through LDS by LDS-DMA
@@ -500,8 +506,8 @@ void spf_destroy(spf_ctx* c)
     for (auto& v : c->timed)
         for (auto& t : v) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_bsk_scaled, (void*)c->d_ksk, (void*)c->d_cbs_lut,
-                    c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->ks_dig.p,
-                    c->ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->cbs_glwe.p, c->cbs_glev.p})
+                    c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->scr.ks_dig.p,
+                    c->scr.ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->scr.cbs_glwe.p, c->scr.cbs_glev.p})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->d_ggsw_const) (void)hipFree(c->d_ggsw_const);
@@ -808,6 +814,24 @@ spf_status spf_scheme_switch_dev(spf_ctx* c, void* stream, size_t B, const uint6
     return launch_scheme_switch(c, (hipStream_t)stream, B, d_glev, d_ggsw);
 }
 
+// circuit_bootstrap_via_trace_and_scheme_switch (circuit_bootstrapping.rs:342-385) on `s`, intermediates in `sc`
+static spf_status circuit_bootstrap_chain(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe, double* d_ggsw, Scratch* sc,
+                                          int per_wg_hint)
+{
+    spf_status st = tail_supported(c);
+    if (st != SPF_OK) return st;
+    st = ensure(c, sc->cbs_glwe, B * glwe_words(c->prm) * 8);
+    if (st != SPF_OK) return st;
+    st = ensure(c, sc->cbs_glev, B * c->prm.cbs_radix_count * glwe_words(c->prm) * 8);
+    if (st != SPF_OK) return st;
+    st = launch_blind_rotate(c, s, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62,
+                             (uint64_t*)sc->cbs_glwe.p, glwe_words(c->prm), false, per_wg_hint);
+    if (st != SPF_OK) return st;
+    st = launch_trace(c, s, B, (const uint64_t*)sc->cbs_glwe.p, (uint64_t*)sc->cbs_glev.p);
+    if (st != SPF_OK) return st;
+    return launch_scheme_switch(c, s, B, (const uint64_t*)sc->cbs_glev.p, d_ggsw);
+}
+
 spf_status spf_circuit_bootstrap_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_lwe, double* d_ggsw)
 {
     if (!c || (B && (!d_lwe || !d_ggsw))) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
@@ -815,20 +839,7 @@ spf_status spf_circuit_bootstrap_dev(spf_ctx* c, void* stream, size_t B, const u
     if (B > 0x0fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    spf_status st = tail_supported(c);
-    if (st != SPF_OK) return st;
-    // circuit_bootstrap_via_trace_and_scheme_switch (circuit_bootstrapping.rs:342-385)
-    st = ensure(c, c->cbs_glwe, B * glwe_words(c->prm) * 8);
-    if (st != SPF_OK) return st;
-    st = ensure(c, c->cbs_glev, B * c->prm.cbs_radix_count * glwe_words(c->prm) * 8);
-    if (st != SPF_OK) return st;
-    hipStream_t s = (hipStream_t)stream;
-    st = launch_blind_rotate(c, s, B, d_lwe, c->d_cbs_lut, 0, 0, ceil_log2(c->prm.cbs_radix_count), (uint64_t)1 << 62,
-                             (uint64_t*)c->cbs_glwe.p, glwe_words(c->prm), false);
-    if (st != SPF_OK) return st;
-    st = launch_trace(c, s, B, (const uint64_t*)c->cbs_glwe.p, (uint64_t*)c->cbs_glev.p);
-    if (st != SPF_OK) return st;
-    return launch_scheme_switch(c, s, B, (const uint64_t*)c->cbs_glev.p, d_ggsw);
+    return circuit_bootstrap_chain(c, (hipStream_t)stream, B, d_lwe, d_ggsw, &c->scr, 0);
 }
 
 spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_glwe, size_t idx, uint64_t* d_out)
@@ -1632,7 +1643,55 @@ const char* spf_last_cmux_kernel(spf_ctx* c)
     return c->last_cmux_kernel;
 }
 
+} // extern "C"
+
 // ---------------------------------------------------------------- call-coalescing pool
+// what a pool's launcher thread calls for a batch of a staging set: the set's own stream and intermediates, so that the batches of
+// several sets run on the GPU at the same time, and the shape of the whole population of callers (per_wg_hint, launch_blind_rotate)
+static spf_status pool_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_in, uint64_t* d_out, Scratch* sc)
+{
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_keyswitch(c, s, B, d_in, d_out, sc);
+}
+static spf_status pool_circuit_bootstrap(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe, double* d_ggsw, Scratch* sc,
+                                         int per_wg_hint)
+{
+    if (B == 0) return SPF_OK;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return circuit_bootstrap_chain(c, s, B, d_lwe, d_ggsw, sc, per_wg_hint);
+}
+// a set's intermediates sized for `cap` operations up front (growing them later would hipFree, i.e. wait for the whole device,
+// with other batches in flight)
+static spf_status scratch_reserve(spf_ctx* c, Scratch& sc, size_t cap, bool keyswitch, bool circuit_bootstrap)
+{
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    spf_status st = SPF_OK;
+    if (keyswitch && c->d_ksk_planes) {
+        const size_t K = (size_t)c->prm.glwe_size * c->prm.polynomial_degree * c->prm.ks_radix_count;
+        const size_t mpad = (cap + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
+        st = ensure(c, sc.ks_dig, mpad * K);
+        if (st == SPF_OK) st = ensure(c, sc.ks_rowsum, mpad * sizeof(int));
+    }
+    if (st == SPF_OK && circuit_bootstrap) {
+        st = ensure(c, sc.cbs_glwe, cap * glwe_words(c->prm) * 8);
+        if (st == SPF_OK) st = ensure(c, sc.cbs_glev, cap * c->prm.cbs_radix_count * glwe_words(c->prm) * 8);
+    }
+    return st;
+}
+static void scratch_free(Scratch& sc)
+{
+    for (DevBuf* b : {&sc.ks_dig, &sc.ks_rowsum, &sc.cbs_glwe, &sc.cbs_glev}) {
+        if (b->p) (void)hipFree(b->p);
+        *b = DevBuf{};
+    }
+}
+
+#include "spf_pool.hpp"
+
+extern "C" {
 
 spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, spf_pool** out)
 {
@@ -1642,9 +1701,16 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     p->ctx = c; p->prm = c->prm; p->max_batch = max_batch;
     p->max_inflight = 4 * max_batch; // flow control: cf. the reference's bounded token channel (circuit_processor/mod.rs:139)
     p->max_wait = std::chrono::microseconds(max_wait_us);
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) != hipSuccess) {
+    if (const char* e = getenv("SPF_POOL_GROUPS")) p->groups = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("SPF_POOL_MIN_GROUP")) p->min_group = (size_t)std::max(1, atoi(e));
+    bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) == hipSuccess;
+    for (auto& set : p->sets)
+        streams_ok = streams_ok && hipStreamCreateWithFlags(&set.sk, hipStreamNonBlocking) == hipSuccess;
+    if (!streams_ok) {
+        p->free_sets();
+        if (p->s_in) (void)hipStreamDestroy(p->s_in);
         delete p;
-        return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the copy stream");
+        return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the pool's streams");
     }
     try {
         p->launcher = std::thread([p] {
@@ -1663,6 +1729,7 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         p->cv_work.notify_all();
         p->cv_flight.notify_all();
         if (p->launcher.joinable()) p->launcher.join();
+        p->free_sets();
         (void)hipStreamDestroy(p->s_in);
         delete p;
         return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the pool threads: ") + e.what());

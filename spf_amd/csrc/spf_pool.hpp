@@ -23,9 +23,16 @@
 //     time per 1.9 s of wall time (a wake storm per batch, then a convoy on the mutex) and ran the process into its CPU
 //     quota (tools/pool_probe.py: 15 of 18 scheduler periods throttled); the pool's mutex is held for a few hundred
 //     nanoseconds at a time (slot bookkeeping), never across a copy, a sleep or a HIP call;
-//   * three staging sets (pinned host + device buffers, grown on demand): one filling, one in flight, one being
-//     collected.  A set returns to the pool when every ticket of its batch has been collected; tickets nobody waits for
+//   * six staging sets (pinned host + device buffers, grown on demand), each with its own kernel stream and its own
+//     intermediates.  A set returns to the pool when every ticket of its batch has been collected; tickets nobody waits for
 //     are delivered by the launcher after a grace period, so that abandoned tickets cannot wedge the pipeline.
+// r05: several batches RESIDENT on the GPU at once.  Synchronous callers make throughput = callers / (kernel latency + host
+// turn-around): r04 ran one batch's kernels at a time (one stream, the context's intermediates), so a thousand callers took turns
+// as two groups of 512 on the two-per-workgroup shape, and 256 callers idled the GPU for the 2 ms it takes them to copy 64 MB out
+// and come back (0.72 of the device-resident rate either way).  Now a batch closes as soon as it holds a QUARTER of the callers
+// in the pool (or everybody who can come is there), every batch is launched with the workgroup shape the WHOLE population would
+// get (one / two / four ciphertexts per workgroup: launch_blind_rotate's per_wg_hint), so that up to four batches tile the CUs
+// side by side, each on its set's stream: while one group copies out and comes back, the others compute.
 // Errors follow the reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters.
 #pragma once
 #include "../../include/spf_hip.h"
@@ -55,7 +62,8 @@
 namespace spf_pool_impl {
 
 enum Op { OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3, N_OPS = 4 };
-constexpr int kSets = 3;
+constexpr int kSets = 6;          // up to four batches with kernels on the GPU, one collecting, one filling
+constexpr int kMaxRunning = 4;
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
 
 struct Slot {
@@ -74,6 +82,9 @@ struct Staging {
     void* d_mid = nullptr;
     size_t cap_in[3] = {0, 0, 0}, cap_out = 0, cap_mid = 0;
     bool busy = false;
+    hipStream_t sk = nullptr; // this set's kernels (created with the pool)
+    Scratch scr;              // ... and their intermediates
+    size_t scr_cap = 0;       // operations the intermediates are sized for
 };
 
 inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expected)
@@ -91,6 +102,7 @@ struct Batch {
     size_t n = 0, n_ready = 0;    // slots taken / inputs copied in
     size_t n_collected = 0;
     size_t n_returning = 0;       // members submitted by a thread that was in the previous batch of this kind
+    int per_wg = 0;               // workgroup shape of its bootstrap (the population's, decided when it is enqueued)
     bool closed = false, done = false;
     bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
     // The outputs leave the GPU in up to kMaxChunks copies (each a multiple of kWordSlots slots, all but the last equal), each with
@@ -162,6 +174,7 @@ struct spf_pool {
     size_t blocked = 0;                   // callers inside submit() / wait(): destroy waits until they have left
     size_t space_waiters = 0, set_waiters = 0; // submitters parked on back-pressure / on a staging set
     size_t max_inflight = 16384;          // submit blocks while this many tickets are open (back-pressure)
+    size_t groups = 4, min_group = 32;    // a batch closes at population / groups members, never below min_group (SPF_POOL_GROUPS, SPF_POOL_MIN_GROUP)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
     bool stop = false;
@@ -170,9 +183,10 @@ struct spf_pool {
     hipStream_t s_in = nullptr;           // host-to-device copies; kernels run on ctx->stream, device-to-host on ctx->copy_stream
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
     std::vector<uintptr_t> last_members[spf_pool_impl::N_OPS]; // threads of the most recently finished batch of a kind, sorted
-    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
+    size_t cap_hint[spf_pool_impl::N_OPS] = {256, 256, 256, 256}; // slots of the next batch of a kind: doubles whenever a batch fills up
                                                               // (pinned staging is sized by what the callers actually produce:
                                                               // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
+    bool preparing[spf_pool_impl::N_OPS] = {false, false, false, false}; // a submitter is allocating a set for this kind (lock dropped)
 
     size_t lwe0_bytes() const { return ((size_t)prm.lwe_dimension + 1) * 8; }
     size_t lwe1_bytes() const { return ((size_t)prm.glwe_size * prm.polynomial_degree + 1) * 8; }
@@ -201,7 +215,8 @@ struct spf_pool {
         return std::max<size_t>(1, std::min(max_batch, spf_pool_impl::kMaxStagingBytes / big));
     }
 
-    // ---- staging sets (called with `mu` held; growing a buffer is rare: first use of an operation kind)
+    // ---- staging sets (prepare_set runs with `mu` DROPPED — hipFree / hipMalloc / hipHostMalloc wait for the device —
+    // while `preparing[op]` keeps other submitters of the kind parked; growing a buffer is rare: first use of an operation kind)
     static bool grow_host(void*& p, size_t& cap, size_t bytes)
     {
         if (cap >= bytes) return true;
@@ -236,6 +251,10 @@ struct spf_pool {
             if (!grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
             s.cap_mid = cap * lwe0_bytes();
         }
+        if (op != spf_pool_impl::OP_CMUX && s.scr_cap < cap) {
+            if (scratch_reserve(ctx, s.scr, cap, true, true) != SPF_OK) return false; // (both: the set serves any kind later)
+            s.scr_cap = cap;
+        }
         return true;
     }
     void free_sets()
@@ -249,6 +268,8 @@ struct spf_pool {
             if (s.h_out) (void)hipHostFree(s.h_out);
             if (s.d_out) (void)hipFree(s.d_out);
             if (s.d_mid) (void)hipFree(s.d_mid);
+            scratch_free(s.scr);
+            if (s.sk) (void)hipStreamDestroy(s.sk);
             s = spf_pool_impl::Staging{};
         }
     }
@@ -290,23 +311,31 @@ struct spf_pool {
             if (b) break; // (a batch leaves `filling` the moment it is closed: what is there has room)
             // open a batch on a free staging set
             int set = -1;
-            for (int i = 0; i < kSets; i++) if (!sets[i].busy) { set = i; break; }
+            if (!preparing[op]) // (somebody is allocating a set for this kind right now: its batch is about to appear)
+                for (int i = 0; i < kSets; i++) if (!sets[i].busy) { set = i; break; }
             if (set < 0) {
                 // all sets held: wait for collectors; past the grace period deliver the oldest done batch's leftovers here
                 set_waiters++;
                 const bool timed_out = cv_set.wait_for(lk, std::chrono::milliseconds(20)) == std::cv_status::timeout;
                 set_waiters--;
-                if (timed_out) reclaim(lk);
+                if (timed_out && !preparing[op]) reclaim(lk);
                 if (stop) return SPF_ERR_INVALID_ARGUMENT;
                 continue;
             }
             const size_t cap = std::min(batch_cap(op), cap_hint[op]);
             sets[set].busy = true;
-            if (!prepare_set(sets[set], op, cap)) {
+            preparing[op] = true;
+            lk.unlock(); // (allocation calls wait for the device: never under the pool's mutex)
+            const bool prepared = prepare_set(sets[set], op, cap);
+            lk.lock();
+            preparing[op] = false;
+            if (set_waiters) cv_set.notify_all();
+            if (!prepared) {
                 sets[set].busy = false;
                 cv_set.notify_all();
                 return SPF_ERR_HIP;
             }
+            if (stop) { sets[set].busy = false; return SPF_ERR_INVALID_ARGUMENT; }
             try {
                 b = std::make_shared<Batch>();
                 b->slots.reserve(cap);
@@ -337,8 +366,8 @@ struct spf_pool {
         if (b->n == b->cap) {
             cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(op);
-        } else if (b->n == 2 * (size_t)ctx->n_cu && cap_here(b->n)) {
-            close_batch(op);
+        } else if (b->n >= group_target()) {
+            close_batch(op); // a group's worth: it goes now and shares the chip with the groups already there
         } else if (everybody_is_back(*b)) {
             cv_work.notify_all(); // the launcher need not wait for more
         }
@@ -368,22 +397,24 @@ struct spf_pool {
         return b.n > 1 && !last.empty() && b.n_returning >= last.size() && tickets.size() == b.n;
     }
 
-    // `mu` held.  Two ciphertexts per CU is the largest batch of the two-per-workgroup shape of the bootstrap (6.9 ms); one
-    // ciphertext more costs 9.9 ms (four per workgroup on half a chip).  While kernels of the pool are running, a batch that
-    // reaches that size is closed there (it queues behind the running kernels) if the callers that are not in flight number
-    // fewer than a quarter more: the few left over lead the next batch, and the groups of callers that take turns on the GPU
-    // settle at 512 (T = 1 024: 52.9 k -> 64.4 k/s).  (The same rule at ONE ciphertext per CU helps 768 callers, 41.6 k -> 56.9 k,
-    // but pulls 1 024 callers from groups of 512 down to groups of 256, 64.4 k -> 56.6 k: not applied.)
-    bool cap_here(size_t n) const
+    // `mu` held.  The callers blocked in the pool right now (open tickets) stand for the population that keeps coming back.  A batch
+    // closes at a 1 / `groups` share of it (r05: four groups resident on the GPU side by side; r04 closed at two ciphertexts per CU
+    // while kernels were running and the groups took turns): the groups then rotate — while one copies out and resubmits the
+    // others compute.  Never below `min_group` (a launch has a fixed cost on the launcher thread and in the kernels' prologues).
+    size_t population() const { return tickets.size(); }
+    size_t group_target() const { return std::max(min_group, (population() + groups - 1) / groups); }
+    // ciphertexts per workgroup the bootstrap of a batch should use at least: the shape the whole population would get in one
+    // launch, so that the resident batches tile the CUs (one batch of a quarter of 1 024 callers takes 64 CUs, not 256)
+    int per_wg_hint() const
     {
-        size_t flying = 0;
-        bool busy = false;
-        for (auto& f : in_flight)
-            if (!f->kernels_done) { // (the callers of a batch that is copying out are on their way back into this one)
-                flying += f->n;
-                busy = true;
-            }
-        return busy && tickets.size() - flying < n + n / 4;
+        const size_t pop = population(), n_cu = (size_t)ctx->n_cu;
+        return pop <= n_cu ? 1 : (pop <= 2 * n_cu ? 2 : 4);
+    }
+    size_t running() const
+    {
+        size_t r = 0;
+        for (auto& f : in_flight) r += f->kernels_done ? 0 : 1;
+        return r;
     }
 
     // `mu` held: the batch of `op` takes no more members; the launcher enqueues it once every member's input is in
@@ -486,19 +517,20 @@ struct spf_pool {
         for (int k = 0; k < 3; k++)
             if (in[k] && hipMemcpyAsync(s.d_in[k], s.h_in[k], B * in[k], hipMemcpyHostToDevice, s_in) != hipSuccess) return SPF_ERR_HIP;
         if (hipEventRecord(b.ev_in, s_in) != hipSuccess) return SPF_ERR_HIP;
-        hipStream_t sk = ctx->stream;
+        hipStream_t sk = s.sk; // the set's own stream: batches of different sets run side by side
         if (hipStreamWaitEvent(sk, b.ev_in, 0) != hipSuccess) return SPF_ERR_HIP;
+        Scratch* scr = const_cast<Scratch*>(&s.scr);
         spf_status st;
         switch (b.op) {
         case OP_KEYSWITCH:
-            st = spf_keyswitch_lwe_l1_lwe_l0_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out);
+            st = pool_keyswitch(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out, scr);
             break;
         case OP_CBS:
-            st = spf_circuit_bootstrap_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out);
+            st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out, scr, b.per_wg);
             break;
         case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
-            st = spf_keyswitch_lwe_l1_lwe_l0_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_mid);
-            if (st == SPF_OK) st = spf_circuit_bootstrap_dev(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)s.d_out);
+            st = pool_keyswitch(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_mid, scr);
+            if (st == SPF_OK) st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)s.d_out, scr, b.per_wg);
             break;
         default:
             st = spf_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],
@@ -531,6 +563,7 @@ struct spf_pool {
                 if (b->n_ready < b->n) { cv_work.wait(lk); continue; }
                 closing.pop_front();
                 b->t_ready = std::chrono::steady_clock::now();
+                b->per_wg = per_wg_hint();
                 lk.unlock();
                 spf_status st;
                 try {
@@ -558,9 +591,9 @@ struct spf_pool {
                 continue;
             }
             if (!stop) {
-                bool gpu_busy = false;
-                for (auto& f : in_flight) gpu_busy = gpu_busy || !f->kernels_done;
-                if (gpu_busy) { idle_since_valid = false; cv_work.wait_for(lk, std::chrono::milliseconds(50)); continue; }
+                // (time-based closing only while the GPU has room for another resident batch; a batch that reaches its group's
+                // size is closed by the submit that completes it, whatever runs)
+                if (running() >= (size_t)kMaxRunning) { idle_since_valid = false; cv_work.wait_for(lk, std::chrono::milliseconds(50)); continue; }
                 // The GPU is free.  The callers of the batch that just finished are copying their outputs out and will be
                 // back within a few hundred microseconds: launching what has gathered so far would split the callers into
                 // two groups that take turns on a half-empty GPU (T = 64: two groups of 32, each paying the full latency of
@@ -576,7 +609,9 @@ struct spf_pool {
                 const bool everybody = everybody_is_back(*filling[op]);
                 if (!everybody && filling[op]->n < SPF_POOL_AT_ONCE) {
                     // (a small batch also waits for the copy out of the batch before it: those callers are the ones to come back)
-                    if (!in_flight.empty() && now < idle_since + std::chrono::milliseconds(20)) {
+                    bool copying_out = false;
+                    for (auto& f : in_flight) copying_out = copying_out || f->kernels_done;
+                    if (copying_out && now < idle_since + std::chrono::milliseconds(20)) {
                         cv_work.wait_for(lk, std::chrono::milliseconds(1));
                         continue;
                     }
@@ -624,7 +659,7 @@ struct spf_pool {
                 // something was enqueued before the failure: let it drain before the staging set is reused
                 (void)hipSetDevice(ctx->device);
                 (void)hipStreamSynchronize(s_in);
-                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipStreamSynchronize(sets[b->set].sk);
                 (void)hipStreamSynchronize(ctx->copy_stream);
             }
             lk.lock();
