@@ -23,6 +23,14 @@
 
 using namespace spf;
 
+// HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
+// run their kernels one after the other: with the default, two bootstrap launches on two streams took 7.45 ms, with more queues
+// 3.76 (tools/concurrency_probe.py).  The pool keeps several batches resident on the GPU at once, each on its own stream, beside
+// the streams of the context and of the caller — so the library asks for more queues, unless the environment already says
+// otherwise.  The runtime reads the variable when it initialises (first HIP call of the process); this runs when the library is
+// loaded.  A process that has initialised HIP before loading the library keeps its setting: export GPU_MAX_HW_QUEUES there.
+__attribute__((constructor(101))) static void spf_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -1681,6 +1689,14 @@ static spf_status scratch_reserve(spf_ctx* c, Scratch& sc, size_t cap, bool keys
     }
     return st;
 }
+static spf_status pool_copy_in(spf_ctx* c, hipStream_t s, const void* src, void* dst, size_t bytes)
+{
+    const size_t words = bytes / 8;
+    if (words == 0) return SPF_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 4 * (size_t)c->n_cu);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(blocks), dim3(256), 0, s, (const uint64_t*)src, (uint64_t*)dst, words);
+    return hipGetLastError() == hipSuccess ? SPF_OK : SPF_ERR_HIP;
+}
 static void scratch_free(Scratch& sc)
 {
     for (DevBuf* b : {&sc.ks_dig, &sc.ks_rowsum, &sc.cbs_glwe, &sc.cbs_glev}) {
@@ -1701,8 +1717,8 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     p->ctx = c; p->prm = c->prm; p->max_batch = max_batch;
     p->max_inflight = 4 * max_batch; // flow control: cf. the reference's bounded token channel (circuit_processor/mod.rs:139)
     p->max_wait = std::chrono::microseconds(max_wait_us);
-    if (const char* e = getenv("SPF_POOL_GROUPS")) p->groups = (size_t)std::max(1, atoi(e));
-    if (const char* e = getenv("SPF_POOL_MIN_GROUP")) p->min_group = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("SPF_POOL_GROUPS")) p->groups = (size_t)std::min(std::max(1, atoi(e)), spf_pool_impl::kMaxGroups);
+    if (const char* e = getenv("SPF_POOL_PACE")) p->pace_div = atoi(e); // (experiments: -1 = no pacing)
     bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) == hipSuccess;
     for (auto& set : p->sets)
         streams_ok = streams_ok && hipStreamCreateWithFlags(&set.sk, hipStreamNonBlocking) == hipSuccess;

@@ -1797,6 +1797,16 @@ __global__ void glwe_linear_kernel(const uint64_t* a, const uint64_t* b, uint64_
     }
 }
 
+// words u64 from `src` (pinned host memory, read by the GPU over PCIe, or device memory) to `dst`: the pool's copy-in.  A kernel
+// on the batch's own stream instead of a hipMemcpyAsync: the runtime hands those to ONE in-order SDMA queue per direction pair,
+// where a host-to-device copy of a new batch stood behind the device-to-host copy of another batch that was still waiting for
+// its kernels — up to a whole bootstrap (profiles/r05_pool.md).
+__global__ void copy_words_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+
 // Row gather for the graph executor: dst row r = the `words` u64 at src[r] (operands of one level of
 // a gate graph live wherever their producers wrote them; the batched kernels want them contiguous).
 __global__ void gather_rows_kernel(const uint64_t* const* src, uint64_t* dst, uint32_t rows, uint32_t words)

@@ -56,14 +56,11 @@
 #include <unordered_set>
 #include <vector>
 
-#ifndef SPF_POOL_AT_ONCE
-#define SPF_POOL_AT_ONCE (3 * (size_t)ctx->n_cu / 2)
-#endif
 namespace spf_pool_impl {
 
 enum Op { OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3, N_OPS = 4 };
-constexpr int kSets = 6;          // up to four batches with kernels on the GPU, one collecting, one filling
-constexpr int kMaxRunning = 4;
+constexpr int kMaxGroups = 8;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
+constexpr int kSets = 2 * kMaxGroups; // per group one batch in flight / being collected and one filling
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
 
 struct Slot {
@@ -97,7 +94,7 @@ inline void futex_wake_all(std::atomic<uint32_t>* w)
 }
 
 struct Batch {
-    int op = 0, set = 0;
+    int op = 0, set = 0, lane = 0; // lane = op * kMaxGroups + caller group
     size_t cap = 0;               // slots of this batch
     size_t n = 0, n_ready = 0;    // slots taken / inputs copied in
     size_t n_collected = 0;
@@ -165,7 +162,11 @@ struct spf_pool {
     std::chrono::microseconds max_wait{200};
     std::mutex mu;
     std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_flight, cv_deliver;
-    std::shared_ptr<Batch> filling[spf_pool_impl::N_OPS];
+    static constexpr int kLanes = spf_pool_impl::N_OPS * spf_pool_impl::kMaxGroups;
+    std::shared_ptr<Batch> filling[kLanes];                                           // per (operation kind, caller group)
+    std::unordered_map<uintptr_t, size_t> home_group;                               // calling thread -> its arrival number (group = arrival % groups: sticky)
+    size_t next_group = 0;
+    std::unordered_map<uintptr_t, int> open_by_thread;                              // submitting thread -> its open tickets
     std::deque<std::shared_ptr<Batch>> closing;                                     // closed, waiting for their members' input copies
     std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, waited for by the completer
     std::deque<std::shared_ptr<Batch>> collecting;                                  // done, not yet fully collected
@@ -174,19 +175,21 @@ struct spf_pool {
     size_t blocked = 0;                   // callers inside submit() / wait(): destroy waits until they have left
     size_t space_waiters = 0, set_waiters = 0; // submitters parked on back-pressure / on a staging set
     size_t max_inflight = 16384;          // submit blocks while this many tickets are open (back-pressure)
-    size_t groups = 4, min_group = 32;    // a batch closes at population / groups members, never below min_group (SPF_POOL_GROUPS, SPF_POOL_MIN_GROUP)
+    size_t groups = 0;                    // caller groups in use: 0 = by population (groups_now), else SPF_POOL_GROUPS = 1 .. kMaxGroups
+    int pace_div = 0;                     // pacing: a batch starts no sooner than 1 / pace_div of a batch's GPU time after the previous one (0 = groups; SPF_POOL_PACE)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
     bool stop = false;
     std::thread launcher, completer;
     spf_pool_impl::Staging sets[spf_pool_impl::kSets];
-    hipStream_t s_in = nullptr;           // host-to-device copies; kernels run on ctx->stream, device-to-host on ctx->copy_stream
+    hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
-    std::vector<uintptr_t> last_members[spf_pool_impl::N_OPS]; // threads of the most recently finished batch of a kind, sorted
-    size_t cap_hint[spf_pool_impl::N_OPS] = {256, 256, 256, 256}; // slots of the next batch of a kind: doubles whenever a batch fills up
+    std::vector<uintptr_t> last_members[kLanes]; // threads of the most recently finished batch of a lane, sorted
+    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
                                                               // (pinned staging is sized by what the callers actually produce:
                                                               // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
-    bool preparing[spf_pool_impl::N_OPS] = {false, false, false, false}; // a submitter is allocating a set for this kind (lock dropped)
+    bool preparing[kLanes] = {}; // a submitter is allocating a set for this lane (lock dropped)
+    int outstanding[kLanes] = {}; // closed batches of the lane that have not completed yet
 
     size_t lwe0_bytes() const { return ((size_t)prm.lwe_dimension + 1) * 8; }
     size_t lwe1_bytes() const { return ((size_t)prm.glwe_size * prm.polynomial_degree + 1) * 8; }
@@ -222,7 +225,7 @@ struct spf_pool {
         if (cap >= bytes) return true;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false; // (the GPU reads / the host reads it in place)
         cap = bytes;
         return true;
     }
@@ -305,30 +308,49 @@ struct spf_pool {
         cv_space.wait(lk, [&] { return stop || tickets.size() < max_inflight; });
         space_waiters--;
         if (stop) return SPF_ERR_INVALID_ARGUMENT;
+        // The caller's group: dealt round-robin on the thread's first submit, kept from then on.  The threads of a group meet in
+        // the same batches, call after call — so a group's batch is complete the moment the members of its previous batch are
+        // back (everybody_is_back), whatever the other groups are doing, and a straggler only ever delays itself.
+        const uintptr_t who = (uintptr_t)pthread_self();
+        int grp = 0;
+        {
+            size_t arrival;
+            auto it = home_group.find(who);
+            if (it != home_group.end()) arrival = it->second;
+            else {
+                arrival = next_group++;
+                try {
+                    home_group.emplace(who, arrival);
+                } catch (const std::exception&) { // (out of memory: dealt again next time)
+                }
+            }
+            grp = (int)(arrival % groups_now());
+        }
+        const int lane = op * kMaxGroups + grp;
         std::shared_ptr<Batch> b;
         for (;;) {
-            b = filling[op];
+            b = filling[lane];
             if (b) break; // (a batch leaves `filling` the moment it is closed: what is there has room)
             // open a batch on a free staging set
             int set = -1;
-            if (!preparing[op]) // (somebody is allocating a set for this kind right now: its batch is about to appear)
+            if (!preparing[lane]) // (somebody is allocating a set for this lane right now: its batch is about to appear)
                 for (int i = 0; i < kSets; i++) if (!sets[i].busy) { set = i; break; }
             if (set < 0) {
                 // all sets held: wait for collectors; past the grace period deliver the oldest done batch's leftovers here
                 set_waiters++;
                 const bool timed_out = cv_set.wait_for(lk, std::chrono::milliseconds(20)) == std::cv_status::timeout;
                 set_waiters--;
-                if (timed_out && !preparing[op]) reclaim(lk);
+                if (timed_out && !preparing[lane]) reclaim(lk);
                 if (stop) return SPF_ERR_INVALID_ARGUMENT;
                 continue;
             }
             const size_t cap = std::min(batch_cap(op), cap_hint[op]);
             sets[set].busy = true;
-            preparing[op] = true;
+            preparing[lane] = true;
             lk.unlock(); // (allocation calls wait for the device: never under the pool's mutex)
             const bool prepared = prepare_set(sets[set], op, cap);
             lk.lock();
-            preparing[op] = false;
+            preparing[lane] = false;
             if (set_waiters) cv_set.notify_all();
             if (!prepared) {
                 sets[set].busy = false;
@@ -344,17 +366,20 @@ struct spf_pool {
                 cv_set.notify_all();
                 return SPF_ERR_HIP;
             }
-            b->op = op; b->set = set; b->cap = cap;
-            filling[op] = b;
+            b->op = op; b->set = set; b->cap = cap; b->lane = lane;
+            filling[lane] = b;
             break;
         }
         size_t slot;
         try {
             slot = b->n;
-            const uintptr_t who = (uintptr_t)pthread_self();
             b->slots.push_back(Slot{out, next_ticket, 0, who});
-            if (std::binary_search(last_members[op].begin(), last_members[op].end(), who)) b->n_returning++;
+            // a caller "comes back" when it submits with nothing else outstanding (the synchronous pattern); a thread that
+            // submits many tickets before it waits for any is not waited for — its batches close on the timer or when full
+            int& mine_open = open_by_thread[who]; // (may allocate: before the ticket exists)
             tickets.emplace(next_ticket, std::make_pair(b, slot));
+            if (mine_open == 0 && std::binary_search(last_members[lane].begin(), last_members[lane].end(), who)) b->n_returning++;
+            mine_open++;
         } catch (const std::exception&) {
             if (b->slots.size() > b->n) b->slots.pop_back();
             return SPF_ERR_HIP;
@@ -365,9 +390,7 @@ struct spf_pool {
         *ticket = next_ticket++;
         if (b->n == b->cap) {
             cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
-            close_batch(op);
-        } else if (b->n >= group_target()) {
-            close_batch(op); // a group's worth: it goes now and shares the chip with the groups already there
+            close_batch(lane);
         } else if (everybody_is_back(*b)) {
             cv_work.notify_all(); // the launcher need not wait for more
         }
@@ -387,22 +410,27 @@ struct spf_pool {
         return SPF_OK;
     }
 
-    // `mu` held.  Synchronous callers come back: the threads of the batch that just finished collect their outputs and submit
-    // again.  Once every one of them is in the filling batch and the pool holds no other open ticket, nobody is left to wait for.
-    // (Threads the pool has not seen in the previous batch do not count: for callers arriving for the first time the coalescing
-    // window is `max_wait`, as documented.)
+    // `mu` held.  Synchronous callers come back: the threads of the group's batch that just finished collect their outputs and
+    // submit again.  Once every one of them is in the filling batch nobody is left to wait for.  (Threads the group has not seen
+    // in its previous batch do not count: for callers arriving for the first time the coalescing window is `max_wait`.)
     bool everybody_is_back(const Batch& b) const
     {
-        const std::vector<uintptr_t>& last = last_members[b.op];
-        return b.n > 1 && !last.empty() && b.n_returning >= last.size() && tickets.size() == b.n;
+        const std::vector<uintptr_t>& last = last_members[b.lane];
+        return b.n > 0 && !last.empty() && b.n_returning >= last.size();
     }
 
-    // `mu` held.  The callers blocked in the pool right now (open tickets) stand for the population that keeps coming back.  A batch
-    // closes at a 1 / `groups` share of it (r05: four groups resident on the GPU side by side; r04 closed at two ciphertexts per CU
-    // while kernels were running and the groups took turns): the groups then rotate — while one copies out and resubmits the
-    // others compute.  Never below `min_group` (a launch has a fixed cost on the launcher thread and in the kernels' prologues).
+    // `mu` held.  The callers blocked in the pool right now (open tickets) stand for the population that keeps coming back.
     size_t population() const { return tickets.size(); }
-    size_t group_target() const { return std::max(min_group, (population() + groups - 1) / groups); }
+    // Caller groups in use.  Measured (tools/pool_bench.py, fraction of the device-resident rate at 64 / 256 / 1 024 callers):
+    // two groups 0.91 / 0.71 / 0.73, three 0.94 / 0.76 / 0.75, four 0.88 / 0.79 / 0.69, six 0.79 / 0.67 / 0.63 (r04, one group at
+    // a time: 0.83 / 0.72 / 0.72).  Four groups while the population fits the chip at two ciphertexts per CU; beyond that the
+    // bootstraps of the resident batches subscribe every CU (four per CU) and a fourth group only queues its keyswitch, trace and
+    // copy kernels behind them: three.
+    size_t groups_now() const
+    {
+        if (groups) return groups;
+        return population() > 2 * (size_t)ctx->n_cu ? 3 : 4;
+    }
     // ciphertexts per workgroup the bootstrap of a batch should use at least: the shape the whole population would get in one
     // launch, so that the resident batches tile the CUs (one batch of a quarter of 1 024 callers takes 64 CUs, not 256)
     int per_wg_hint() const
@@ -417,14 +445,26 @@ struct spf_pool {
         return r;
     }
 
-    // `mu` held: the batch of `op` takes no more members; the launcher enqueues it once every member's input is in
-    void close_batch(int op)
+    // `mu` held: the batch of `lane` takes no more members; the launcher enqueues it once every member's input is in
+    void close_batch(int lane)
     {
-        std::shared_ptr<Batch> b = filling[op];
+        std::shared_ptr<Batch> b = filling[lane];
         if (!b) return;
         b->closed = true;
         b->t_close = std::chrono::steady_clock::now();
-        filling[op].reset();
+        filling[lane].reset();
+        // the group's next batch is complete when THESE callers are back (and it does not close on the timer before this batch is
+        // done: a member that missed this batch waits for its group instead of becoming a group of one that runs out of phase
+        // with it for ever — measured: single-ciphertext launches of 3.7 ms each, alternating with the group's)
+        try {
+            std::vector<uintptr_t>& last = last_members[lane];
+            last.clear();
+            for (size_t i = 0; i < b->n; i++) last.push_back(b->slots[i].who);
+            std::sort(last.begin(), last.end());
+        } catch (const std::exception&) {
+            last_members[lane].clear(); // (out of memory: the next batch closes on the timer)
+        }
+        outstanding[lane]++;
         closing.push_back(b);
         cv_work.notify_all();
     }
@@ -484,6 +524,10 @@ struct spf_pool {
         }
         tickets.erase(ticket);
         claimed.erase(ticket);
+        {
+            auto it = open_by_thread.find(b->slots[slot].who);
+            if (it != open_by_thread.end() && --it->second <= 0) open_by_thread.erase(it);
+        }
         blocked--;
         if (space_waiters) cv_space.notify_all();
         if (stop) cv_idle.notify_all();
@@ -499,11 +543,9 @@ struct spf_pool {
         const Staging& s = sets[b.set];
         const size_t B = b.n;
         if (hipSetDevice(ctx->device) != hipSuccess) return SPF_ERR_HIP;
-#ifdef SPF_POOL_TRACE
+        // (timing events on purpose: with hipEventDisableTiming the same run gave 32.8 k instead of 46.2 k operations per second at 256
+        // callers — hipEventSynchronize on such an event returned late, by about the batch's remaining work in its stream — r05q)
         constexpr unsigned kEvFlags = hipEventDefault;
-#else
-        constexpr unsigned kEvFlags = hipEventDisableTiming;
-#endif
         {
             const size_t groups = (B + Batch::kWordSlots - 1) / Batch::kWordSlots;
             b.n_chunks = (int)std::min<size_t>(groups, Batch::kMaxChunks);
@@ -514,11 +556,15 @@ struct spf_pool {
             return SPF_ERR_HIP;
         for (int i = 0; i < b.n_chunks; i++)
             if (hipEventCreateWithFlags(&b.ev_chunk[i], kEvFlags) != hipSuccess) return SPF_ERR_HIP;
-        for (int k = 0; k < 3; k++)
-            if (in[k] && hipMemcpyAsync(s.d_in[k], s.h_in[k], B * in[k], hipMemcpyHostToDevice, s_in) != hipSuccess) return SPF_ERR_HIP;
-        if (hipEventRecord(b.ev_in, s_in) != hipSuccess) return SPF_ERR_HIP;
-        hipStream_t sk = s.sk; // the set's own stream: batches of different sets run side by side
-        if (hipStreamWaitEvent(sk, b.ev_in, 0) != hipSuccess) return SPF_ERR_HIP;
+        // Everything of a batch — copy in, kernels, copies out — goes on the SET's stream, in order, and nothing waits for an event
+        // of another stream: batches of different sets run side by side, a batch's copies run under the other batches' kernels
+        // anyway, and no barrier packet of one batch sits in a hardware queue in front of another batch's kernels (r05: with
+        // separate copy streams tied to the kernel streams by events, streams that shared a hardware queue with a copy stream
+        // stood behind its "wait for batch A's kernels" — the resident batches ran one after the other).
+        hipStream_t sk = s.sk;
+        for (int k = 0; k < 3; k++) // (a kernel that reads the pinned buffer, not an SDMA copy: spf_kernels.hpp, copy_words_kernel)
+            if (in[k] && pool_copy_in(ctx, sk, s.h_in[k], s.d_in[k], B * in[k]) != SPF_OK) return SPF_ERR_HIP;
+        if (hipEventRecord(b.ev_in, sk) != hipSuccess) return SPF_ERR_HIP;
         Scratch* scr = const_cast<Scratch*>(&s.scr);
         spf_status st;
         switch (b.op) {
@@ -539,8 +585,7 @@ struct spf_pool {
         }
         if (st != SPF_OK) return st;
         if (hipEventRecord(b.ev_k, sk) != hipSuccess) return SPF_ERR_HIP;
-        hipStream_t so = ctx->copy_stream;
-        if (hipStreamWaitEvent(so, b.ev_k, 0) != hipSuccess) return SPF_ERR_HIP;
+        hipStream_t so = sk;
         for (int i = 0; i < b.n_chunks; i++) {
             const size_t first = (size_t)i * b.chunk_slots;
             const size_t count = std::min(b.chunk_slots, B - first);
@@ -561,8 +606,18 @@ struct spf_pool {
             if (!closing.empty()) {
                 std::shared_ptr<Batch> b = closing.front();
                 if (b->n_ready < b->n) { cv_work.wait(lk); continue; }
+                // Pacing: resident batches that start together also finish together — their copies out queue behind each other
+                // and their callers come back in one crowd, i.e. they behave as ONE big batch and the GPU idles through the
+                // common turn-around.  A batch therefore starts no sooner than a 1 / groups share of a batch's time on the GPU
+                // after the previous one: once spread out, the groups keep their phases (each comes back one cycle later), and
+                // while one copies out and resubmits the others compute.
+                if (!stop && running() > 0 && pace_div >= 0) {
+                    const auto due = last_enq + std::min<std::chrono::steady_clock::duration>(last_gpu_span / (pace_div > 0 ? pace_div : (int)groups_now()), std::chrono::milliseconds(5));
+                    if (std::chrono::steady_clock::now() < due) { cv_work.wait_until(lk, due); continue; }
+                }
                 closing.pop_front();
                 b->t_ready = std::chrono::steady_clock::now();
+                last_enq = b->t_ready;
                 b->per_wg = per_wg_hint();
                 lk.unlock();
                 spf_status st;
@@ -578,51 +633,29 @@ struct spf_pool {
                 cv_flight.notify_all();
                 continue;
             }
-            // 2. the filling batch with the oldest first member: close it when the GPU has no kernels of the pool in flight and that
-            // member has waited max_wait, or — the GPU busy — the moment the kernels of the batch in flight have completed
-            // (everything that arrived during kernel k is batch k + 1; its copy in and kernels overlap batch k's copy out);
-            // a full batch was closed by the submit that filled it
-            int op = -1;
-            for (int k = 0; k < N_OPS; k++)
-                if (filling[k] && filling[k]->n > 0 && (op < 0 || filling[k]->t0 < filling[op]->t0)) op = k;
-            if (op < 0) {
+            // 2. time-based closing.  A group's batch is complete when the members of its previous batch are all back (submit
+            // wakes this thread then); otherwise — first-time callers, a member that does not come back — it closes when nobody has
+            // joined it for the quiet time: max_wait, stretched to an eighth of the last batch's time on the GPU (a caller
+            // needs that long to copy 256 KiB out and come back when its CPU is shared), and at most 20 quiet times after its
+            // first member arrived, so that a trickle of arrivals cannot hold it open.
+            int lane = -1;
+            std::chrono::steady_clock::time_point best{};
+            const auto now = std::chrono::steady_clock::now();
+            const auto quiet = std::max(std::chrono::duration_cast<std::chrono::steady_clock::duration>(max_wait),
+                                        std::min<std::chrono::steady_clock::duration>(last_gpu_span / 8, std::chrono::milliseconds(2)));
+            for (int k = 0; k < kLanes; k++) {
+                if (!filling[k] || filling[k]->n == 0) continue;
+                if (outstanding[k] > 0 && !stop) continue; // its group's previous batch is still out: the callers are not back yet
+                const auto due = (stop || everybody_is_back(*filling[k])) ? now : std::min(filling[k]->t_last + quiet, filling[k]->t0 + 20 * quiet);
+                if (lane < 0 || due < best) { lane = k; best = due; }
+            }
+            if (lane < 0) {
                 if (stop) return;
                 cv_work.wait(lk);
                 continue;
             }
-            if (!stop) {
-                // (time-based closing only while the GPU has room for another resident batch; a batch that reaches its group's
-                // size is closed by the submit that completes it, whatever runs)
-                if (running() >= (size_t)kMaxRunning) { idle_since_valid = false; cv_work.wait_for(lk, std::chrono::milliseconds(50)); continue; }
-                // The GPU is free.  The callers of the batch that just finished are copying their outputs out and will be
-                // back within a few hundred microseconds: launching what has gathered so far would split the callers into
-                // two groups that take turns on a half-empty GPU (T = 64: two groups of 32, each paying the full latency of
-                // a launch).  So the batch closes when no member has arrived for max_wait — bounded by 20 x max_wait of
-                // idle GPU, so that a trickle of arrivals cannot hold it open.
-                // With one and a half ciphertexts per CU gathered the GPU is worth starting at once (the callers then settle into two
-                // groups whose kernels run back to back).  The quiet time is max_wait, stretched to an eighth of the last batch's
-                // time on the GPU (a caller needs that long to copy 256 KiB out and come back when its CPU is shared).
-                const auto now = std::chrono::steady_clock::now();
-                if (!idle_since_valid) { idle_since = now; idle_since_valid = true; }
-                // Everybody is here: every open ticket of the pool belongs to this batch (the callers of the previous batch have
-                // collected their outputs and come back), so nobody is left to wait for — close without the quiet time.
-                const bool everybody = everybody_is_back(*filling[op]);
-                if (!everybody && filling[op]->n < SPF_POOL_AT_ONCE) {
-                    // (a small batch also waits for the copy out of the batch before it: those callers are the ones to come back)
-                    bool copying_out = false;
-                    for (auto& f : in_flight) copying_out = copying_out || f->kernels_done;
-                    if (copying_out && now < idle_since + std::chrono::milliseconds(20)) {
-                        cv_work.wait_for(lk, std::chrono::milliseconds(1));
-                        continue;
-                    }
-                    const auto quiet = std::max(std::chrono::duration_cast<std::chrono::steady_clock::duration>(max_wait),
-                                                std::min<std::chrono::steady_clock::duration>(last_gpu_span / 8, std::chrono::milliseconds(2)));
-                    const auto deadline = std::min(std::max(filling[op]->t_last, last_done) + quiet, idle_since + 20 * quiet);
-                    if (now < deadline) { cv_work.wait_until(lk, deadline); continue; }
-                }
-            }
-            idle_since_valid = false;
-            close_batch(op);
+            if (now < best) { cv_work.wait_until(lk, best); continue; }
+            close_batch(lane);
         }
     }
 
@@ -653,14 +686,12 @@ struct spf_pool {
                     b->wake_chunk(i);
                 }
                 if (b->st == SPF_OK && hipEventSynchronize(b->ev_chunk[b->n_chunks - 1]) != hipSuccess) b->st = SPF_ERR_HIP;
-                if (b->st != SPF_OK) (void)hipStreamSynchronize(ctx->copy_stream); // nothing may still be writing the staging set
+                if (b->st != SPF_OK) (void)hipStreamSynchronize(sets[b->set].sk); // nothing may still be writing the staging set
                 b->t_sync = std::chrono::steady_clock::now();
             } else {
                 // something was enqueued before the failure: let it drain before the staging set is reused
                 (void)hipSetDevice(ctx->device);
-                (void)hipStreamSynchronize(s_in);
                 (void)hipStreamSynchronize(sets[b->set].sk);
-                (void)hipStreamSynchronize(ctx->copy_stream);
             }
             lk.lock();
             b->kernels_done = true;
@@ -679,12 +710,7 @@ struct spf_pool {
             }
 #endif
             collecting.push_back(b);
-            {
-                std::vector<uintptr_t>& last = last_members[b->op];
-                last.clear();
-                for (size_t i = 0; i < b->n; i++) last.push_back(b->slots[i].who);
-                std::sort(last.begin(), last.end());
-            }
+            outstanding[b->lane]--;
             n_launches++;
             n_ops += b->n;
             for (int w = 0; w < spf_pool_impl::Batch::kMaxWords; w++) // the last chunk — or, for a batch that failed, all of them
@@ -693,8 +719,7 @@ struct spf_pool {
         }
     }
     bool launcher_gone = false;
-    std::chrono::steady_clock::time_point idle_since; // since when the launcher has seen the GPU free with members waiting
-    bool idle_since_valid = false;
     std::chrono::steady_clock::duration last_gpu_span{0}; // enqueue -> kernels done of the most recent batch
     std::chrono::steady_clock::time_point last_done;      // when the most recent batch was handed to its waiters
+    std::chrono::steady_clock::time_point last_enq;       // when the most recent batch was enqueued (pacing)
 };

@@ -58,10 +58,12 @@ def test_pool_matches_batch_entry_points_and_coalesces(rig):
     assert launches < ops / 4, (ops, launches)   # it really batched
 
 
-def test_pool_big_batches_leave_in_chunks_and_every_caller_gets_its_own_bytes(rig):
+def test_pool_big_batches_leave_in_chunks_and_every_caller_gets_its_own_bytes(rig, monkeypatch):
     """A batch of more than 64 members copies its outputs out in several chunks, each with its own event and wake-up word
     (the callers of the first chunk copy out while the last is still crossing PCIe).  200 callers at once, twice in a row (the
-    second round re-uses staging sets and words), every output against the batch entry point."""
+    second round re-uses staging sets and words), every output against the batch entry point.  (One caller group, so that the
+    200 meet in one batch: by default the pool deals callers to several groups that run side by side.)"""
+    monkeypatch.setenv("SPF_POOL_GROUPS", "1")
     ks, eng = rig
     P = ks.params
     n_ops = 200
