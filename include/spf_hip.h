@@ -241,12 +241,23 @@ spf_status spf_multiply_glwe_ggsw_dev(spf_ctx *ctx, void *stream, size_t B, cons
 
 /* ---- call coalescing: many threads, one ciphertext each -> one batch per launch ----------
  * The reference calls `Evaluation` from many rayon workers with a single ciphertext per call
- * (circuit_processor/mod.rs:192-253).  A pool keeps that calling convention — submit, then wait
- * like the synchronous call it replaces — while a worker thread runs whatever is pending of one
- * kind as ONE batch (up to max_batch operations, or max_wait_us after the oldest arrived).
- * Input and output buffers must stay valid until spf_pool_wait returns for their ticket.
- * spf_pool_wait returns the status of the batch the operation ran in (first-error-wins per
- * batch, as circuit_processor/mod.rs:214-223 does per graph). */
+ * (circuit_processor/mod.rs:192-253).  A pool keeps that calling convention — submit, then wait like the synchronous call it
+ * replaces — and runs what has gathered of one kind as ONE batch.
+ *   Buffers: the INPUT is copied into the pool's pinned staging during submit (it may be released when submit returns); the
+ *     OUTPUT buffer must stay valid until spf_pool_wait returns for its ticket — or, for a ticket nobody waits for, until the
+ *     pool is destroyed: an output left uncollected for 200 ms is written to its buffer by a pool thread so that the staging
+ *     set can be reused (a later wait still returns the status, and never returns while that copy is in progress).
+ *   Batching: a calling thread is dealt to one of up to four caller groups on its first submit and stays there; a group's
+ *     batch closes when it is full (max_batch, and the staging a batch may pin), when every caller of the group's previous
+ *     batch is back, or when nobody has joined it for max_wait_us (stretched to an eighth of the last batch's GPU time, at most
+ *     twenty such quiet times after its first member) — but not on the timer while the group's previous batch is still out.
+ *     The groups' batches run on the GPU side by side, each on its own stream (profiles/r05_pool.md).
+ *   Asynchronous use: a thread may hold many tickets; eight staging sets exist, so a caller that keeps more than eight batches
+ *     uncollected waits in submit until a set is collected (or 200 ms old).
+ *   spf_pool_wait returns the status of the batch the operation ran in (first-error-wins per batch, as
+ *     circuit_processor/mod.rs:214-223 does per graph).
+ *   The library asks the HIP runtime for more hardware queues when it is loaded (GPU_MAX_HW_QUEUES=16 unless set): streams that
+ *   share a hardware queue run their kernels one after the other. */
 typedef struct spf_pool spf_pool;
 spf_status spf_pool_create(spf_ctx *ctx, size_t max_batch, uint32_t max_wait_us, spf_pool **out);
 void spf_pool_destroy(spf_pool *pool); /* drains pending work first */
@@ -261,6 +272,21 @@ spf_status spf_pool_submit_keyswitch_circuit_bootstrap(spf_pool *pool, const uin
 /* `KeylessEvaluation::cmux` for one gate */
 spf_status spf_pool_submit_cmux(spf_pool *pool, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
                                 uint64_t *out, uint64_t *ticket);
+/* The other operations `CircuitProcessor::exec_op` issues per task (circuit_processor/mod.rs:341-540), one ciphertext per call:
+ *   FheOp::SampleExtract(idx) -> `KeylessEvaluation::sample_extract_l1` (crypto/evaluation.rs:126-133); idx >= N is
+ *                                SPF_ERR_INVALID_ARGUMENT.  Calls with different indices run in different batches.
+ *   FheOp::Not / GlweAdd / MulXN(n) -> `not` / `xor` / `mul_xn` (crypto/evaluation.rs:47-66); n is taken mod 2N
+ *   FheOp::MultiplyGgswGlwe -> `multiply_glwe_ggsw` (:104-123)         FheOp::GlevCMux -> `glev_cmux` (:86-101), GLEVs of l_cbs GLWEs
+ *   FheOp::SchemeSwitch -> `Evaluation::scheme_switch` (:231-240) */
+spf_status spf_pool_submit_sample_extract(spf_pool *pool, const uint64_t *glwe_in, size_t idx, uint64_t *lwe1_out, uint64_t *ticket);
+spf_status spf_pool_submit_not(spf_pool *pool, const uint64_t *glwe_in, uint64_t *glwe_out, uint64_t *ticket);
+spf_status spf_pool_submit_glwe_add(spf_pool *pool, const uint64_t *a, const uint64_t *b, uint64_t *glwe_out, uint64_t *ticket);
+spf_status spf_pool_submit_mul_xn(spf_pool *pool, const uint64_t *glwe_in, size_t n, uint64_t *glwe_out, uint64_t *ticket);
+spf_status spf_pool_submit_multiply_ggsw_glwe(spf_pool *pool, const double *ggsw_fft, const uint64_t *glwe, uint64_t *glwe_out,
+                                              uint64_t *ticket);
+spf_status spf_pool_submit_glev_cmux(spf_pool *pool, const double *sel_ggsw_fft, const uint64_t *a, const uint64_t *b,
+                                     uint64_t *glev_out, uint64_t *ticket);
+spf_status spf_pool_submit_scheme_switch(spf_pool *pool, const uint64_t *glev_in, double *ggsw_fft_out, uint64_t *ticket);
 /* Blocks until the operation has run; each ticket can be collected exactly once (an unknown or already
  * collected ticket is SPF_ERR_INVALID_ARGUMENT, never a hang). */
 spf_status spf_pool_wait(spf_pool *pool, uint64_t ticket);

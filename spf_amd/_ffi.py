@@ -85,6 +85,13 @@ SYMBOLS = [
     ("spf_pool_submit_circuit_bootstrap", _I, [_P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_submit_keyswitch_circuit_bootstrap", _I, [_P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_submit_cmux", _I, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_sample_extract", _I, [_P, _P, _SZ, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_not", _I, [_P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_glwe_add", _I, [_P, _P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_mul_xn", _I, [_P, _P, _SZ, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_multiply_ggsw_glwe", _I, [_P, _P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_glev_cmux", _I, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
+    ("spf_pool_submit_scheme_switch", _I, [_P, _P, _P, C.POINTER(_U64)]),
     ("spf_pool_wait", _I, [_P, _U64]),
     ("spf_pool_set_max_inflight", _I, [_P, _SZ]),
     ("spf_pool_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
@@ -720,6 +727,59 @@ class Pool:
         if st != 0:
             raise SpfError(st, "submit failed")
         self._wait(t.value)
+
+    # -- the other FheOp kinds of CircuitProcessor::exec_op (synchronous forms: submit + wait)
+    def _run(self, what, fn, *args):
+        t = C.c_uint64()
+        st = fn(self._h, *args, C.byref(t))
+        if st != 0:
+            raise SpfError(st, f"pool {what}: submit failed")
+        self._wait(t.value)
+
+    def sample_extract_l1(self, output: np.ndarray, glwe: np.ndarray, idx: int):
+        P = self.engine.params
+        x = _in("pool sample_extract", glwe, np.uint64, P.glwe_words)
+        _out("pool sample_extract", output, np.uint64, P.lwe1_words)
+        self._run("sample_extract", self._lib.spf_pool_submit_sample_extract, _ptr(x), int(idx), _ptr(output))
+
+    def glwe_not(self, output: np.ndarray, glwe: np.ndarray):
+        P = self.engine.params
+        x = _in("pool not", glwe, np.uint64, P.glwe_words)
+        _out("pool not", output, np.uint64, P.glwe_words)
+        self._run("not", self._lib.spf_pool_submit_not, _ptr(x), _ptr(output))
+
+    def glwe_add(self, output: np.ndarray, a: np.ndarray, b: np.ndarray):
+        P = self.engine.params
+        a_, b_ = _in("pool glwe_add", a, np.uint64, P.glwe_words), _in("pool glwe_add", b, np.uint64, P.glwe_words)
+        _out("pool glwe_add", output, np.uint64, P.glwe_words)
+        self._run("glwe_add", self._lib.spf_pool_submit_glwe_add, _ptr(a_), _ptr(b_), _ptr(output))
+
+    def mul_xn(self, output: np.ndarray, glwe: np.ndarray, n: int):
+        P = self.engine.params
+        x = _in("pool mul_xn", glwe, np.uint64, P.glwe_words)
+        _out("pool mul_xn", output, np.uint64, P.glwe_words)
+        self._run("mul_xn", self._lib.spf_pool_submit_mul_xn, _ptr(x), int(n), _ptr(output))
+
+    def multiply_glwe_ggsw(self, output: np.ndarray, glwe: np.ndarray, ggsw: np.ndarray):
+        P = self.engine.params
+        g = _in("pool multiply_glwe_ggsw", ggsw, np.complex128, P.cbs_ggsw_complex)
+        x = _in("pool multiply_glwe_ggsw", glwe, np.uint64, P.glwe_words)
+        _out("pool multiply_glwe_ggsw", output, np.uint64, P.glwe_words)
+        self._run("multiply_glwe_ggsw", self._lib.spf_pool_submit_multiply_ggsw_glwe, _ptr(g), _ptr(x), _ptr(output))
+
+    def glev_cmux(self, output: np.ndarray, sel: np.ndarray, a: np.ndarray, b: np.ndarray):
+        P = self.engine.params
+        n = P.cbs_radix_count * P.glwe_words
+        s_ = _in("pool glev_cmux", sel, np.complex128, P.cbs_ggsw_complex)
+        a_, b_ = _in("pool glev_cmux", a, np.uint64, n), _in("pool glev_cmux", b, np.uint64, n)
+        _out("pool glev_cmux", output, np.uint64, n)
+        self._run("glev_cmux", self._lib.spf_pool_submit_glev_cmux, _ptr(s_), _ptr(a_), _ptr(b_), _ptr(output))
+
+    def scheme_switch(self, output: np.ndarray, glev: np.ndarray):
+        P = self.engine.params
+        x = _in("pool scheme_switch", glev, np.uint64, P.cbs_radix_count * P.glwe_words)
+        _out("pool scheme_switch", output, np.complex128, P.cbs_ggsw_complex)
+        self._run("scheme_switch", self._lib.spf_pool_submit_scheme_switch, _ptr(x), _ptr(output))
 
     def stats(self):
         ops, launches = C.c_uint64(), C.c_uint64()

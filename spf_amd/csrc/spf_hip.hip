@@ -1807,13 +1807,14 @@ void spf_pool_destroy(spf_pool* p)
 // (defined with the group, spf_group.hpp)
 static spf_pool* pool_deal(spf_pool* top, int* member);
 
-static spf_status pool_submit(spf_pool* p, int op, const void* a, const void* b, const void* c, void* out, uint64_t* ticket)
+static spf_status pool_submit(spf_pool* p, int op, const void* a, const void* b, const void* c, void* out, uint64_t* ticket,
+                              uint64_t param = 0)
 {
     if (!p) return SPF_ERR_INVALID_ARGUMENT;
     int member = 0;
     spf_pool* q = pool_deal(p, &member);
     if (!q) return SPF_ERR_HIP; // no member of the group is in rotation
-    const spf_status st = q->submit(op, a, b, c, out, ticket);
+    const spf_status st = q->submit(op, a, b, c, out, ticket, param);
     if (st == SPF_OK && q != p) *ticket |= (uint64_t)member << spf_pool::kMemberShift;
     return st;
 }
@@ -1837,6 +1838,43 @@ spf_status spf_pool_submit_cmux(spf_pool* p, const double* sel, const uint64_t* 
 {
     if (!p || !a || !b) return SPF_ERR_INVALID_ARGUMENT;
     return pool_submit(p, spf_pool_impl::OP_CMUX, sel, a, b, out, ticket);
+}
+
+// the remaining `FheOp` kinds of `CircuitProcessor::exec_op` (circuit_processor/mod.rs:341-540)
+spf_status spf_pool_submit_sample_extract(spf_pool* p, const uint64_t* glwe_in, size_t idx, uint64_t* lwe1_out, uint64_t* ticket)
+{
+    if (!p || idx >= p->prm.polynomial_degree) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_SAMPLE_EXTRACT, glwe_in, nullptr, nullptr, lwe1_out, ticket, idx);
+}
+spf_status spf_pool_submit_not(spf_pool* p, const uint64_t* glwe_in, uint64_t* glwe_out, uint64_t* ticket)
+{
+    return pool_submit(p, spf_pool_impl::OP_NOT, glwe_in, nullptr, nullptr, glwe_out, ticket);
+}
+spf_status spf_pool_submit_glwe_add(spf_pool* p, const uint64_t* a, const uint64_t* b, uint64_t* glwe_out, uint64_t* ticket)
+{
+    if (!p || !b) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_GLWE_ADD, a, b, nullptr, glwe_out, ticket);
+}
+spf_status spf_pool_submit_mul_xn(spf_pool* p, const uint64_t* glwe_in, size_t n, uint64_t* glwe_out, uint64_t* ticket)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_MUL_XN, glwe_in, nullptr, nullptr, glwe_out, ticket, n % (2 * (size_t)p->prm.polynomial_degree));
+}
+spf_status spf_pool_submit_multiply_ggsw_glwe(spf_pool* p, const double* ggsw_fft, const uint64_t* glwe, uint64_t* glwe_out,
+                                              uint64_t* ticket)
+{
+    if (!p || !glwe) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_MULTIPLY_GGSW_GLWE, ggsw_fft, glwe, nullptr, glwe_out, ticket);
+}
+spf_status spf_pool_submit_glev_cmux(spf_pool* p, const double* sel_ggsw_fft, const uint64_t* a, const uint64_t* b, uint64_t* glev_out,
+                                     uint64_t* ticket)
+{
+    if (!p || !a || !b) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit(p, spf_pool_impl::OP_GLEV_CMUX, sel_ggsw_fft, a, b, glev_out, ticket);
+}
+spf_status spf_pool_submit_scheme_switch(spf_pool* p, const uint64_t* glev_in, double* ggsw_fft_out, uint64_t* ticket)
+{
+    return pool_submit(p, spf_pool_impl::OP_SCHEME_SWITCH, glev_in, nullptr, nullptr, ggsw_fft_out, ticket);
 }
 
 spf_status spf_pool_wait(spf_pool* p, uint64_t ticket)

@@ -58,7 +58,13 @@
 
 namespace spf_pool_impl {
 
-enum Op { OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3, N_OPS = 4 };
+// one kind per `FheOp` that `CircuitProcessor::exec_op` hands to `Evaluation` (circuit_processor/mod.rs:329-540), plus the
+// KeyswitchL1toL0 -> CircuitBootstrap chain
+enum Op {
+    OP_KEYSWITCH = 0, OP_CBS = 1, OP_CMUX = 2, OP_GATE_CBS = 3,
+    OP_SAMPLE_EXTRACT = 4, OP_NOT = 5, OP_GLWE_ADD = 6, OP_MUL_XN = 7, OP_MULTIPLY_GGSW_GLWE = 8, OP_GLEV_CMUX = 9, OP_SCHEME_SWITCH = 10,
+    N_OPS = 11
+};
 constexpr int kMaxGroups = 8;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
 constexpr int kSets = 2 * kMaxGroups; // per group one batch in flight / being collected and one filling
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
@@ -100,6 +106,7 @@ struct Batch {
     size_t n_collected = 0;
     size_t n_returning = 0;       // members submitted by a thread that was in the previous batch of this kind
     int per_wg = 0;               // workgroup shape of its bootstrap (the population's, decided when it is enqueued)
+    uint64_t param = 0;           // SampleExtract index / MulXN amount: one value per batch (a different one opens a new batch)
     bool closed = false, done = false;
     bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
     // The outputs leave the GPU in up to kMaxChunks copies (each a multiple of kWordSlots slots, all but the last equal), each with
@@ -185,7 +192,7 @@ struct spf_pool {
     hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
     std::vector<uintptr_t> last_members[kLanes]; // threads of the most recently finished batch of a lane, sorted
-    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
+    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
                                                               // (pinned staging is sized by what the callers actually produce:
                                                               // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
     bool preparing[kLanes] = {}; // a submitter is allocating a set for this lane (lock dropped)
@@ -203,11 +210,18 @@ struct spf_pool {
     {
         using namespace spf_pool_impl;
         in[0] = in[1] = in[2] = 0;
+        const size_t glev = glwe_bytes() * prm.cbs_radix_count;
         switch (op) {
         case OP_KEYSWITCH: in[0] = lwe1_bytes(); out = lwe0_bytes(); break;
         case OP_CBS: in[0] = lwe0_bytes(); out = ggsw_bytes(); break;
         case OP_GATE_CBS: in[0] = lwe1_bytes(); out = ggsw_bytes(); break;
-        default: in[0] = ggsw_bytes(); in[1] = glwe_bytes(); in[2] = glwe_bytes(); out = glwe_bytes(); break;
+        case OP_SAMPLE_EXTRACT: in[0] = glwe_bytes(); out = lwe1_bytes(); break;
+        case OP_NOT: case OP_MUL_XN: in[0] = glwe_bytes(); out = glwe_bytes(); break;
+        case OP_GLWE_ADD: in[0] = in[1] = glwe_bytes(); out = glwe_bytes(); break;
+        case OP_MULTIPLY_GGSW_GLWE: in[0] = ggsw_bytes(); in[1] = glwe_bytes(); out = glwe_bytes(); break;
+        case OP_GLEV_CMUX: in[0] = ggsw_bytes(); in[1] = in[2] = glev; out = glev; break;
+        case OP_SCHEME_SWITCH: in[0] = glev; out = ggsw_bytes(); break;
+        default: in[0] = ggsw_bytes(); in[1] = glwe_bytes(); in[2] = glwe_bytes(); out = glwe_bytes(); break; // OP_CMUX
         }
     }
     size_t batch_cap(int op) const
@@ -254,7 +268,7 @@ struct spf_pool {
             if (!grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
             s.cap_mid = cap * lwe0_bytes();
         }
-        if (op != spf_pool_impl::OP_CMUX && s.scr_cap < cap) {
+        if ((op == spf_pool_impl::OP_KEYSWITCH || op == spf_pool_impl::OP_CBS || op == spf_pool_impl::OP_GATE_CBS) && s.scr_cap < cap) {
             if (scratch_reserve(ctx, s.scr, cap, true, true) != SPF_OK) return false; // (both: the set serves any kind later)
             s.scr_cap = cap;
         }
@@ -296,7 +310,7 @@ struct spf_pool {
         }
     }
 
-    spf_status submit(int op, const void* a, const void* b_in, const void* c, void* out, uint64_t* ticket)
+    spf_status submit(int op, const void* a, const void* b_in, const void* c, void* out, uint64_t* ticket, uint64_t param = 0)
     {
         using namespace spf_pool_impl;
         if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
@@ -330,6 +344,10 @@ struct spf_pool {
         std::shared_ptr<Batch> b;
         for (;;) {
             b = filling[lane];
+            if (b && b->param != param) { // (SampleExtract index / MulXN amount: the kernels take one value per launch)
+                close_batch(lane);
+                continue;
+            }
             if (b) break; // (a batch leaves `filling` the moment it is closed: what is there has room)
             // open a batch on a free staging set
             int set = -1;
@@ -366,7 +384,7 @@ struct spf_pool {
                 cv_set.notify_all();
                 return SPF_ERR_HIP;
             }
-            b->op = op; b->set = set; b->cap = cap; b->lane = lane;
+            b->op = op; b->set = set; b->cap = cap; b->lane = lane; b->param = param;
             filling[lane] = b;
             break;
         }
@@ -577,6 +595,28 @@ struct spf_pool {
         case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
             st = pool_keyswitch(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_mid, scr);
             if (st == SPF_OK) st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)s.d_out, scr, b.per_wg);
+            break;
+        case OP_SAMPLE_EXTRACT:
+            st = spf_sample_extract_l1_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (size_t)b.param, (uint64_t*)s.d_out);
+            break;
+        case OP_NOT:
+            st = spf_glwe_not_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out);
+            break;
+        case OP_GLWE_ADD:
+            st = spf_glwe_xor_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (const uint64_t*)s.d_in[1], (uint64_t*)s.d_out);
+            break;
+        case OP_MUL_XN:
+            st = spf_glwe_mul_xn_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (size_t)b.param, (uint64_t*)s.d_out);
+            break;
+        case OP_MULTIPLY_GGSW_GLWE:
+            st = spf_multiply_glwe_ggsw_dev(ctx, sk, B, (const uint64_t*)s.d_in[1], (const double*)s.d_in[0], (uint64_t*)s.d_out);
+            break;
+        case OP_GLEV_CMUX:
+            st = spf_glev_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],
+                                   (uint64_t*)s.d_out);
+            break;
+        case OP_SCHEME_SWITCH:
+            st = spf_scheme_switch_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out);
             break;
         default:
             st = spf_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],

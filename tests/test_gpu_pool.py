@@ -335,3 +335,60 @@ def test_pool_under_native_load_every_caller_gets_its_own_output(rig):
     assert ops == n and launches < n / 16, (n, ops, launches)
     assert np.array_equal(got, exp.reshape(T, -1).view(np.float64))
     print(f"pool soak: {T} callers, {el.value:.1f} s, {n} operations in {launches} launches")
+
+
+def test_pool_every_exec_op_kind_against_the_oracle(rig):
+    """The remaining `FheOp` kinds of `CircuitProcessor::exec_op` (circuit_processor/mod.rs:341-540) through the pool, one
+    ciphertext per call from many threads: SampleExtract (two different indices: two batches), Not, GlweAdd, MulXN,
+    MultiplyGgswGlwe, GlevCMux, SchemeSwitch — each output against the oracle."""
+    ks, eng = rig
+    P = ks.params
+    EP = eng.params
+    n = 12
+    r = np.random.default_rng(91)
+    ggsw = ((r.standard_normal((n, EP.cbs_ggsw_complex)) + 1j * r.standard_normal((n, EP.cbs_ggsw_complex))) * 2.0 ** 58)
+    a = random_glwe(92, n, P.glwe_len)
+    b = random_glwe(93, n, P.glwe_len)
+    ga = random_glwe(94, n * P.cbs_count, P.glwe_len).reshape(n, P.cbs_count, P.glwe_len)
+    gb = random_glwe(95, n * P.cbs_count, P.glwe_len).reshape(n, P.cbs_count, P.glwe_len)
+    ssk = O.gen_ssk_fft(O.Rng(0x7A11 + 1), ks.glwe_sk, P)   # any key: parity needs the SAME key on both sides
+    eng.load_scheme_switch_key(ssk)
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=2000)
+    out_se = np.zeros((n, P.N * P.k + 1), dtype=np.uint64)
+    out_not = np.zeros((n, P.glwe_len), dtype=np.uint64)
+    out_add = np.zeros_like(out_not)
+    out_xn = np.zeros_like(out_not)
+    out_mul = np.zeros_like(out_not)
+    out_gc = np.zeros((n, P.cbs_count * P.glwe_len), dtype=np.uint64)
+    out_ss = np.zeros((n, EP.cbs_ggsw_complex), dtype=np.complex128)
+
+    def task(i):
+        pool.sample_extract_l1(out_se[i], a[i], 0 if i % 2 else 1234)
+        pool.glwe_not(out_not[i], a[i])
+        pool.glwe_add(out_add[i], a[i], b[i])
+        pool.mul_xn(out_xn[i], a[i], 4096 + 77)          # taken mod 2N
+        pool.multiply_glwe_ggsw(out_mul[i], a[i], ggsw[i])
+        pool.glev_cmux(out_gc[i], ggsw[i], ga[i], gb[i])
+        pool.scheme_switch(out_ss[i], ga[i])
+        return i
+
+    try:
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            assert sorted(ex.map(task, range(n))) == list(range(n))
+        ops, launches = pool.stats()
+        assert ops == 7 * n and launches < ops            # coalesced
+        with pytest.raises(spf_amd.SpfError):
+            pool.sample_extract_l1(out_se[0], a[0], P.N)  # index out of range: refused at submit
+    finally:
+        pool.close()
+    for i in range(n):
+        assert np.array_equal(out_se[i], O.sample_extract(a[i], 0 if i % 2 else 1234, P.N, P.k)), i
+        assert np.array_equal(out_not[i], O.glwe_not(a[i], P.N, P.k)), i
+        assert np.array_equal(out_add[i], O.glwe_xor(a[i], b[i], P.N, P.k)), i
+        assert np.array_equal(out_xn[i], O.glwe_mul_xn(a[i], 77, P.N, P.k)), i
+        fft = O.glwe_ggsw_mad(np.zeros(P.glwe_len // 2, dtype=np.complex128), a[i], ggsw[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)
+        assert np.array_equal(out_mul[i], np.concatenate([O.poly_ifft(fft[:P.N // 2]), O.poly_ifft(fft[P.N // 2:])])), i
+        for j in range(P.cbs_count):
+            exp = O.cmux(ga[i, j], gb[i, j], ggsw[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)
+            assert np.array_equal(out_gc[i].reshape(P.cbs_count, P.glwe_len)[j], exp), (i, j)
+        assert np.array_equal(out_ss[i].view(np.float64), O.scheme_switch_fft(ga[i], ssk, P).view(np.float64)), i
