@@ -35,6 +35,15 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// The three-ciphertexts-per-workgroup blind rotation for 2 x #CU < B <= 3 x #CU (r05, the 512 -> 513 step of the launch time:
+// 6.95 -> 9.76 ms).  Built, bit-equal (same output checksums at B = 513 / 520 / 600 / 700 / 768, both instantiations), and no faster
+// than four per workgroup — 9.90-9.97 ms against 9.74-9.82 (plain PBS 10.61 against 10.28): two of the four SIMDs still carry two
+// waves, and the step of a workgroup is the step of its slowest SIMD.  Off; -DSPF_TRIO_SHAPE=1 re-runs the row
+// (profiles/r05_kernels_summary.md).  The alternative "512 on the two-per-workgroup shape + the rest on the eight-wave shape" runs
+// back to back (both shapes take a whole CU's LDS): 6.95 + 3.72 ms.
+#ifndef SPF_TRIO_SHAPE
+#define SPF_TRIO_SHAPE 0
+#endif
 constexpr size_t kMaxGridRows = 32768; // rows per launch of the one-grid-row-per-ciphertext kernels
 
 struct DevBuf {
@@ -253,8 +262,9 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     const size_t n_cu = (size_t)c->n_cu;
     const bool quad = B <= n_cu && per_wg_hint <= 1;
     const bool pair2 = !quad && B <= 2 * n_cu && per_wg_hint <= 2;
-    const size_t per_wg = quad ? 1 : (pair2 ? 2 : 4);
-    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(pair2 ? 256 : 512);
+    const bool trio = !quad && !pair2 && B <= 3 * n_cu && per_wg_hint <= 3 && SPF_TRIO_SHAPE; // three per workgroup: fills the chip up to 3 x #CU
+    const size_t per_wg = quad ? 1 : (pair2 ? 2 : (trio ? 3 : 4));
+    dim3 grid((unsigned)((B + per_wg - 1) / per_wg)), block(pair2 ? 256 : (trio ? 384 : 512));
     TimedScope ts(c, s, T_PBS);
     {
         spf_status st = ts.begin();
@@ -277,6 +287,10 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     else if (quad) SPF_LAUNCH("blind_rotate8_kernel<2,16,even>", (blind_rotate8_kernel<2, 16, 0>), kBlindRotate8Lds);
     else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14>", (blind_rotate2p2_kernel<2, 16, 14, 1>), kBlindRotate2p2Lds);
     else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14,even>", (blind_rotate2p2_kernel<2, 16, 14, 0>), kBlindRotate2p2Lds);
+#if SPF_TRIO_SHAPE
+    else if (trio && log_v == 0) SPF_LAUNCH("blind_rotate2p3_kernel<2,16,14>", (blind_rotate2p3_kernel<2, 16, 14, 1>), kBlindRotate2p3Lds);
+    else if (trio) SPF_LAUNCH("blind_rotate2p3_kernel<2,16,14,even>", (blind_rotate2p3_kernel<2, 16, 14, 0>), kBlindRotate2p3Lds);
+#endif
     else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16,14>", (blind_rotate2p_kernel<2, 16, 14, 1>), kBlindRotate2pLds);
     else SPF_LAUNCH("blind_rotate2p_kernel<2,16,14,even>", (blind_rotate2p_kernel<2, 16, 14, 0>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
@@ -487,6 +501,12 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
+#if SPF_TRIO_SHAPE
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, 14, 1>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p3Lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, 14, 0>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p3Lds));
+#endif
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate8_kernel<2, 16, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate8Lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate8_kernel<2, 16, 0>),

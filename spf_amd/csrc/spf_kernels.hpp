@@ -70,6 +70,15 @@ __device__ __forceinline__ void lds_dma_piece(const void* sbase, uint32_t voff, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(saved_m0) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
+// the same for the waves whose (wave-uniform) flag is set, as ONE opaque group: a C++ branch on the wave index around a piece makes
+// hipcc restructure the step loop (1 060 B of scratch per lane in the three-ciphertext shape, 28.7 ms instead of 9)
+__device__ __forceinline__ void lds_dma_piece_if(uint32_t flag, const void* sbase, uint32_t voff, uint32_t lds)
+{
+    uint32_t saved_m0, tmp;
+    asm volatile("v_readfirstlane_b32 %1, %2\n\ts_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 .Ldmaskip%=\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0\n.Ldmaskip%=:"
+                 : "=&s"(saved_m0), "=&s"(tmp) : "v"(flag), "v"(voff), "s"(sbase), "s"(lds) : "memory", "scc");
+}
 __device__ __forceinline__ uint32_t lds_address(const void* p)
 {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
@@ -206,12 +215,21 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
     const uint32_t total_chunks = 2 * a.n;
     const uint32_t dma_voff = (uint32_t)tid * 16u;                   // this lane's bytes inside an 8 KiB piece row
     const uint32_t dma_dst = lds_address(bskring) + wv * 1024;        // this wave's 1 KiB of each piece row
+    constexpr int kPieces = 2 * kBskSlotBytes / 1024, NW = 2 * CTS;   // 1 KiB pieces of a chunk; waves of the workgroup
     auto ring_dma = [&](uint32_t chunk) {
         const char* src = reinterpret_cast<const char*>(a.bsk) +
                           (size_t)__builtin_amdgcn_readfirstlane(chunk) * (2 * kBskSlotBytes); // uniform
+        if constexpr (kPieces % NW == 0) {
 #pragma unroll
-        for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
-            lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
+            for (int k = 0; k < 2 * kBskSlotBytes / (NT * 16); k++)
+                lds_dma_piece(src + k * NT * 16, dma_voff, dma_dst + k * NT * 16);
+        } else {
+            // (three ciphertexts per workgroup: 64 pieces over six waves — wave v takes pieces v, v + 6, ...)
+            const uint32_t lane16 = (uint32_t)lane * 16u, ring0 = lds_address(bskring);
+#pragma unroll
+            for (int k = 0; k < kPieces / NW; k++) lds_dma_piece(src + (k * NW + wv) * 1024, lane16, ring0 + (k * NW + wv) * 1024);
+            lds_dma_piece_if(wv < kPieces % NW ? 1u : 0u, src + ((kPieces / NW) * NW + wv) * 1024, lane16, ring0 + ((kPieces / NW) * NW + wv) * 1024);
+        }
     };
     ring_dma(0);
 
@@ -522,10 +540,19 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
                 for (int k = 0; k < 8; k++) // the slot just read
                     lds_dma_piece(src + (wv ^ 1) * 8192 + k * 1024, lane16, ring0 + (wv ^ 1) * 8192 + k * 1024);
+                constexpr int kRest = (2 * kBskSlotBytes - 2 * CTS * 8192) / 1024; // (fewer waves than slots: the rest of the ring)
+                if constexpr (kRest % NW == 0) {
 #pragma unroll
-                for (int k = 0; k < (2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024); k++) // (fewer waves than slots: the rest of the ring)
-                    lds_dma_piece(src + 2 * CTS * 8192 + (wv * ((2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024)) + k) * 1024, lane16,
-                                  ring0 + 2 * CTS * 8192 + (wv * ((2 * kBskSlotBytes - 2 * CTS * 8192) / (2 * CTS * 1024)) + k) * 1024);
+                    for (int k = 0; k < kRest / NW; k++)
+                        lds_dma_piece(src + 2 * CTS * 8192 + (wv * (kRest / NW) + k) * 1024, lane16,
+                                      ring0 + 2 * CTS * 8192 + (wv * (kRest / NW) + k) * 1024);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kRest / NW; k++)
+                        lds_dma_piece(src + 2 * CTS * 8192 + (k * NW + wv) * 1024, lane16, ring0 + 2 * CTS * 8192 + (k * NW + wv) * 1024);
+                    lds_dma_piece_if(wv < kRest % NW ? 1u : 0u, src + 2 * CTS * 8192 + ((kRest / NW) * NW + wv) * 1024, lane16,
+                                     ring0 + 2 * CTS * 8192 + ((kRest / NW) * NW + wv) * 1024);
+                }
             }
         } else {
             if constexpr (w == 0) {
@@ -622,6 +649,17 @@ __global__ __launch_bounds__(256, 1) void blind_rotate2p2_kernel(BlindRotateArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 2, MIX>(a, smem);
     else blind_rotate2p_body<L, LOGB, OPT, 0, 2, MIX>(a, smem);
+}
+
+// THREE ciphertexts per workgroup (six waves: two SIMDs carry two waves, two carry one; one workgroup per CU): for batches
+// between two and three ciphertexts per CU, where the four-ciphertext shape would leave a third of the CUs idle.  Same words.
+constexpr int kBlindRotate2p3Lds = kTableBytes + 3 * kWaveBufBytes + 2 * kBskSlotBytes;
+template <int L, int LOGB, int OPT, int MIX = 1>
+__global__ __launch_bounds__(384, 1) void blind_rotate2p3_kernel(BlindRotateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 3, MIX>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0, 3, MIX>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
