@@ -25,6 +25,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime reads this when it initialises (torch.cuda.is_available() below does that, before the library — whose loader
+# sets the same default — is opened): streams that share a hardware queue run their kernels one after the other, and the pool
+# keeps several batches resident on the GPU, each on its own stream (profiles/r05_pool.md).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 FLOP_PER_PBS = 263.5e6          # 637 x 413 696 f64 flop
 FP64_PEAK_TFLOPS = 78.6         # MI355X dense FP64 (vector == matrix): 256 CU x 128 flop/clk x 2.4 GHz

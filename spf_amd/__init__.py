@@ -6,7 +6,13 @@ mirror of ``parasol_runtime::Evaluation`` (parasol_runtime/src/crypto/evaluation
 There is no CPU fallback: importing works anywhere, but creating an ``Engine`` without the
 compiled library or without a GPU raises.
 """
-from .params import Params, DEFAULT_128  # noqa: F401
+import os as _os
+
+# read by the HIP runtime when it initialises; the library's loader sets the same default, but a process may touch the GPU (torch)
+# between importing this package and opening the library (spf_amd/csrc/spf_hip.hip, spf_ask_for_hw_queues)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from .params import Params, DEFAULT_128  # noqa: F401,E402
 from ._ffi import (Engine, Group, Pool, SpfError, ciphertext_from_bincode, ciphertext_to_bincode, ciphertext_words,  # noqa: F401
                    generate_lut, lib_path, load_library)
 from .evaluation import Evaluation, ComputeKey  # noqa: F401

@@ -203,10 +203,12 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
                     accb[e] += v; // out.b += trivial(b_k) ...
                 }
             }
+#ifndef SPF_ABL_NO_PARK // (timing-only ablation: wrong results — what does the parked half's traffic cost?  profiles/r05_kernels_summary.md)
             if (p == 1 && owns_output) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) park[(size_t)e * 64] = accb[e];
             }
+#endif
             wave_lds_fence(); // gathered: the region may be overwritten (next staging / the exchange image)
         }
 
@@ -283,8 +285,13 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             }
             if (m == 2) {
                 // the parked body half comes back under the last multiply-accumulate and the inverse cross exchange
+#ifndef SPF_ABL_NO_PARK
 #pragma unroll
                 for (int e = 0; e < 16; e++) accb[e] = park[(size_t)e * 64];
+#else
+#pragma unroll
+                for (int e = 0; e < 16; e++) accb[e] = (uint64_t)st[e] * 0x9E3779B97F4A7C15ull; // (something the compiler cannot fold)
+#endif
             }
             // ... - sum_j <digit_j(a), glev row L-1-j>, digits in order, both output polynomials (fft_ops.rs:489-494)
 #pragma unroll
