@@ -7,6 +7,7 @@
 #include "../../include/spf_hip.h"
 #include "spf_kernels.hpp"
 #include "spf_cbs_tail.hpp"
+#include "spf_generic.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -103,6 +104,12 @@ struct spf_ctx {
     std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
     bool timing = false;
     std::vector<TimedLaunch> timed[T_COUNT];
+    // any other parameter set (spf_generic.hpp): N a power of two in 8 .. 1024, any k and radix.  One workgroup per ciphertext,
+    // the oracle's transform for those sizes; the blind rotation, the CMUX family, sample extract, the linear operations and the
+    // keyswitch (its VALU form) are served, the circuit-bootstrap tail and gate graphs are not.
+    bool generic = false;
+    uint32_t log_n = 11;
+    c64* d_gen_tables = nullptr; // [N/2] twist, then [N/4] transform twiddles
 };
 
 namespace {
@@ -239,6 +246,14 @@ struct TimedScope {
     }
 };
 
+GenericShape generic_shape(const spf_ctx* c)
+{
+    GenericShape g{};
+    g.N = c->prm.polynomial_degree; g.logN = c->log_n; g.k = c->prm.glwe_size;
+    g.twist = c->d_gen_tables; g.w = c->d_gen_tables + g.N / 2;
+    return g;
+}
+
 spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_lwe,
                                const uint64_t* d_lut, size_t lut_stride, uint32_t log_chi,
                                uint32_t log_v, uint64_t body_rotate, uint64_t* d_out,
@@ -248,7 +263,22 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     if (B == 0) return SPF_OK;
     if (B > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
     // modulus switch needs log_modulus - log_v >= 1 and shifts below 64
-    if (log_v >= 12 || log_chi >= 52) return fail(c, SPF_ERR_INVALID_ARGUMENT, "log_v / log_chi out of range");
+    if (log_v >= c->log_n + 1 || log_chi >= 52) return fail(c, SPF_ERR_INVALID_ARGUMENT, "log_v / log_chi out of range");
+    if (c->generic) {
+        GenericPbsArgs ga{};
+        ga.g = generic_shape(c);
+        ga.lwe_in = d_lwe; ga.lut = d_lut; ga.lut_stride = lut_stride; ga.bsk = c->d_bsk; ga.out = d_out; ga.out_stride = out_stride;
+        ga.n = c->prm.lwe_dimension; ga.B = (uint32_t)B; ga.radix_log = c->prm.pbs_radix_log; ga.count = c->prm.pbs_radix_count;
+        ga.log_chi = log_chi; ga.log_v = log_v; ga.sample_extract = extract ? 1u : 0u; ga.body_rotate = body_rotate;
+        c->last_pbs_kernel = "generic_pbs_kernel";
+        TimedScope tsg(c, s, T_PBS);
+        spf_status stg = tsg.begin();
+        if (stg != SPF_OK) return stg;
+        hipLaunchKernelGGL(generic_pbs_kernel, dim3((unsigned)B), dim3(kGenericThreads),
+                           generic_lds_bytes(ga.g.N, ga.g.k, true), s, ga);
+        HIPCHK(c, hipGetLastError());
+        return tsg.end();
+    }
     BlindRotateArgs a{};
     a.lwe_in = d_lwe; a.lut = d_lut; a.lut_stride = lut_stride; a.bsk = SPF_BSK_PRESCALED ? c->d_bsk_scaled : c->d_bsk;
     a.tables = c->d_tables; a.out = d_out; a.out_stride = out_stride;
@@ -345,7 +375,7 @@ bool ks_mfma_ok(const spf_params& p)
 // (re)build the byte-plane image of the keyswitch key; called whenever the key becomes ready
 spf_status build_ks_planes(spf_ctx* c)
 {
-    if (!ks_mfma_ok(c->prm)) return SPF_OK;
+    if (c->generic || !ks_mfma_ok(c->prm)) return SPF_OK;
     const uint32_t n_in = c->prm.glwe_size * c->prm.polynomial_degree, w = c->prm.lwe_dimension + 1;
     const size_t K = (size_t)n_in * c->prm.ks_radix_count;
     const size_t npad = ((size_t)w * 8 + KSG_TILE - 1) / KSG_TILE * KSG_TILE;
@@ -401,6 +431,27 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
     return ts.end();
 }
 
+// the parameter sets of the generic kernels (spf_generic.hpp)
+bool params_generic(const spf_params& p, std::string& why)
+{
+    const uint32_t N = p.polynomial_degree;
+    if (N < 16 || N > 1024 || (N & (N - 1))) {
+        why = "polynomial_degree must be 2048 (specialised kernels) or a power of two in 16 .. 1024 (generic kernels)";
+        return false;
+    }
+    if (p.glwe_size == 0 || p.glwe_size > 8) { why = "glwe_size must be in 1 .. 8"; return false; }
+    auto radix_ok = [](uint32_t lg, uint32_t cnt) { return lg >= 1 && cnt >= 1 && lg * cnt < 64; };
+    if (!radix_ok(p.pbs_radix_log, p.pbs_radix_count) || !radix_ok(p.cbs_radix_log, p.cbs_radix_count)) {
+        why = "a radix decomposition needs 1 <= radix_log * count < 64";
+        return false;
+    }
+    if (generic_lds_bytes(N, p.glwe_size, true) > 160 * 1024) { why = "(k+1) polynomials of this degree do not fit the generic kernels' LDS"; return false; }
+    if (p.lwe_dimension == 0 || p.lwe_dimension > 4096) { why = "lwe_dimension out of range"; return false; }
+    if (p.ks_radix_log == 0 || p.ks_radix_log * p.ks_radix_count > 32) { why = "ks_radix must satisfy 0 < l*logB <= 32"; return false; }
+    if (p.cbs_radix_count >= 8) { why = "cbs_radix.count must be in 1..7"; return false; }
+    return true;
+}
+
 bool params_supported(const spf_params& p, std::string& why)
 {
     if (p.polynomial_degree != kN) { why = "kernels are built for polynomial_degree 2048"; return false; }
@@ -439,8 +490,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
 {
     if (!params || !out) return fail(nullptr, SPF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    std::string why;
-    if (!params_supported(*params, why)) return fail(nullptr, SPF_ERR_UNSUPPORTED, why);
+    std::string why, why_generic;
+    const bool specialised = params_supported(*params, why);
+    if (!specialised && !params_generic(*params, why_generic))
+        return fail(nullptr, SPF_ERR_UNSUPPORTED, params->polynomial_degree == kN ? why : why_generic);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, SPF_ERR_HIP, "no HIP device visible: the HIP path is the only path, there is no CPU fallback");
@@ -449,6 +502,8 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     if (!c) return fail(nullptr, SPF_ERR_HIP, "out of host memory");
     c->prm = *params;
     c->device = device_id;
+    c->generic = !specialised;
+    c->log_n = ceil_log2(params->polynomial_degree);
     auto bail = [&](spf_status s) { g_create_error = c->err; spf_destroy(c); return s; };
 #define CK(expr)                                                                                  \
     do {                                                                                          \
@@ -490,6 +545,21 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
         }
         CK(hipMalloc((void**)&c->d_cbs_lut, lut.size() * 8));
         CK(hipMemcpy(c->d_cbs_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice));
+    }
+    if (c->generic) {
+        // twist e^{+2 pi i j / (2N)} and transform twiddles e^{+2 pi i j / (N/2)}: the oracle's definitions for N != 2048
+        const uint32_t N = params->polynomial_degree, h = N / 2;
+        std::vector<c64> gt(h + h / 2);
+        for (uint32_t j = 0; j < h; j++) gt[j] = root_of_unity(j, 2 * (uint64_t)N);
+        for (uint32_t j = 0; j < h / 2; j++) gt[h + j] = root_of_unity(j, h);
+        CK(hipMalloc((void**)&c->d_gen_tables, gt.size() * sizeof(c64)));
+        CK(hipMemcpy(c->d_gen_tables, gt.data(), gt.size() * sizeof(c64), hipMemcpyHostToDevice));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_pbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)generic_lds_bytes(N, params->glwe_size, true)));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_cmux_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)generic_lds_bytes(N, params->glwe_size, false)));
+        *out = c;
+        return SPF_OK;
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            kKsLdsBytes));
@@ -535,7 +605,7 @@ void spf_destroy(spf_ctx* c)
         for (auto& t : v) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (void* p : {(void*)c->d_tables, (void*)c->d_bsk, (void*)c->d_bsk_scaled, (void*)c->d_ksk, (void*)c->d_cbs_lut,
                     c->in.p, c->out.p, c->mid.p, c->aux.p, (void*)c->d_ksk_planes, c->scr.ks_dig.p,
-                    c->scr.ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->scr.cbs_glwe.p, c->scr.cbs_glev.p})
+                    c->scr.ks_rowsum.p, (void*)c->d_ak, (void*)c->d_ssk, c->scr.cbs_glwe.p, c->scr.cbs_glev.p, (void*)c->d_gen_tables})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->d_ggsw_const) (void)hipFree(c->d_ggsw_const);
@@ -550,6 +620,7 @@ void spf_destroy(spf_ctx* c)
 // outside [2^-900, 2^1000)), where scaling first could round differently from scaling last, makes the key unusable instead.
 static spf_status finish_bootstrap_key(spf_ctx* c)
 {
+    if (c->generic) return SPF_OK; // (the generic kernels read the caller's spectra as they are)
 #if SPF_BSK_PRESCALED
     c->bsk_ready = false;
     const size_t n_complex = (size_t)c->prm.lwe_dimension * ggsw_fft_complex(c->prm, c->prm.pbs_radix_count);
@@ -748,6 +819,7 @@ spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx* c, void* stream, size_t B, con
 static spf_status tail_supported(spf_ctx* c)
 {
     const spf_params& p = c->prm;
+    if (c->generic) return fail(c, SPF_ERR_UNSUPPORTED, "the circuit-bootstrap tail (trace, scheme switch) is built for DEFAULT_128 only");
     if (p.cbs_radix_log != 4 || p.cbs_radix_count != 4 || p.tr_radix_log != 7 || p.tr_radix_count != 6 ||
         p.ss_radix_log != 3 || p.ss_radix_count != 15)
         return fail(c, SPF_ERR_UNSUPPORTED, "circuit-bootstrap tail is built for cbs 4x4, tr 6x7, ss 15x3 bits");
@@ -877,6 +949,16 @@ spf_status spf_sample_extract_l1_dev(spf_ctx* c, void* stream, size_t B, const u
     if (B == 0) return SPF_OK;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->generic) {
+        const uint32_t N = c->prm.polynomial_degree, k = c->prm.glwe_size;
+        for (size_t at = 0; at < B; at += kMaxGridRows) {
+            const size_t nb = std::min(B - at, kMaxGridRows);
+            hipLaunchKernelGGL(generic_sample_extract_kernel, dim3((k * N + 1 + 255) / 256, (unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                               d_glwe + at * glwe_words(c->prm), d_out + at * lwe1_words(c->prm), (uint32_t)nb, N, k, (uint32_t)idx);
+        }
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     // one grid row per ciphertext; grid.y is limited to 65535, larger batches go in slices
     for (size_t at = 0; at < B; at += kMaxGridRows) {
         const size_t nb = std::min(B - at, kMaxGridRows);
@@ -896,6 +978,16 @@ static spf_status glwe_linear_dev(spf_ctx* c, void* stream, size_t B, uint32_t o
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    if (c->generic) {
+        const uint32_t N = c->prm.polynomial_degree, k = c->prm.glwe_size;
+        for (size_t at = 0; at < B; at += kMaxGridRows) {
+            const size_t nb = std::min(B - at, kMaxGridRows), off = at * glwe_words(c->prm);
+            hipLaunchKernelGGL(generic_linear_kernel, dim3(((k + 1) * N + 255) / 256, (unsigned)nb), dim3(256), 0, s, d_a + off,
+                               d_b ? d_b + off : nullptr, d_out + off, N, c->log_n, k, op == GLWE_NOT ? 0u : (op == GLWE_XOR ? 1u : 2u), n);
+        }
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     for (size_t at = 0; at < B; at += kMaxGridRows) {
         const size_t nb = std::min(B - at, kMaxGridRows), off = at * 2 * kN;
         dim3 grid(2 * kN / 256, (unsigned)nb), block(256);
@@ -921,7 +1013,7 @@ spf_status spf_glwe_xor_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* 
 
 spf_status spf_glwe_mul_xn_dev(spf_ctx* c, void* stream, size_t B, const uint64_t* d_in, size_t n, uint64_t* d_out)
 {
-    return glwe_linear_dev(c, stream, B, GLWE_MUL_XN, d_in, nullptr, (uint32_t)(n % (2 * (size_t)kN)), d_out);
+    return glwe_linear_dev(c, stream, B, GLWE_MUL_XN, d_in, nullptr, c ? (uint32_t)(n % (2 * (size_t)c->prm.polynomial_degree)) : 0u, d_out);
 }
 
 // At most one gate per CU: the four-waves-per-gate latency shape (a level of a gate graph); beyond
@@ -1016,6 +1108,19 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 static spf_status launch_cmux(spf_ctx* c, hipStream_t s, size_t units, uint32_t per_ggsw, const double* d_sel,
                               const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out)
 {
+    if (c->generic) {
+        if (units == 0) return SPF_OK;
+        if (units > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
+        GenericCmuxArgs ga{};
+        ga.g = generic_shape(c);
+        ga.ggsw = reinterpret_cast<const c64*>(d_sel); ga.d0 = d_a ? d_a : d_b; ga.d1 = d_b; ga.out = d_out;
+        ga.units = (uint32_t)units; ga.per_ggsw = per_ggsw; ga.d0_zero = d_a ? 0u : 1u;
+        ga.radix_log = c->prm.cbs_radix_log; ga.count = c->prm.cbs_radix_count;
+        c->last_cmux_kernel = "generic_cmux_kernel";
+        hipLaunchKernelGGL(generic_cmux_kernel, dim3((unsigned)units), dim3(kGenericThreads), generic_lds_bytes(ga.g.N, ga.g.k, false), s, ga);
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
         return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
     if (units == 0) return SPF_OK;
@@ -1047,6 +1152,7 @@ spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel,
 spf_status spf_cmux_scattered_dev(spf_ctx* c, void* stream, size_t units, const void* const* d_ptrs)
 {
     if (!c || (units && !d_ptrs)) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->generic) return fail(c, SPF_ERR_UNSUPPORTED, "the scattered CMUX form (gate graphs) is built for DEFAULT_128 only");
     if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
         return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
     if (units == 0) return SPF_OK;
@@ -1249,7 +1355,7 @@ static spf_status glwe_linear_host(spf_ctx* c, size_t B, uint32_t op, const uint
     }
     spf_status s = glwe_linear_dev(c, c->stream, B, op, (const uint64_t*)c->in.p,
                                    op == GLWE_XOR ? (const uint64_t*)c->mid.p : nullptr,
-                                   (uint32_t)(n % (2 * (size_t)kN)), (uint64_t*)c->out.p);
+                                   (uint32_t)(n % (2 * (size_t)c->prm.polynomial_degree)), (uint64_t*)c->out.p);
     if (s != SPF_OK) return s;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipMemcpyAsync(out, c->out.p, B * gw, hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,173 @@
+"""The generic kernel family (spf_amd/csrc/spf_generic.hpp): any power-of-two N in 16 .. 1024, any k, any radix.
+
+The reference's functions are generic (`generalized_programmable_bootstrap`, programmable_bootstrapping.rs:342-410; `cmux`,
+fft_ops.rs:149-181) and its own functional tests run at small parameters — TEST_GLWE_DEF_1 = (N 128, k 2), TEST_LWE_DEF_1 =
+n 128, TEST_RADIX = 3 x 4 bits (sunscreen_tfhe/src/high_level.rs:9-58).  Here those tests are REPLAYED on the HIP path
+(encrypt with the oracle's keygen, compute on the GPU through the C ABI, decrypt, compare with the plaintext expectation —
+`can_cmux_fft`, `can_fft_external_product_glwe_ggsw` fft_ops.rs:537-619; `bootstrap_helper` programmable_bootstrapping.rs:708-779)
+and every output is also compared word for word with the oracle.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+import spf_amd
+from tests.util import random_glwe, random_lwe_batch, to_engine_params
+
+pytestmark = pytest.mark.gpu
+
+# high_level.rs:9-58
+TEST1 = O.DEFAULT_128.replace(lwe_n=128, lwe_std=1e-16, N=128, k=2, glwe_std=1e-16, pbs_radix_log=4, pbs_count=3,
+                              cbs_radix_log=4, cbs_count=3, ks_radix_log=4, ks_count=3)
+# TEST_GLWE_DEF_2 / TEST_LWE_DEF_2
+TEST2 = O.DEFAULT_128.replace(lwe_n=20, lwe_std=1e-16, N=256, k=3, glwe_std=1e-16, pbs_radix_log=4, pbs_count=3,
+                              cbs_radix_log=8, cbs_count=2, ks_radix_log=4, ks_count=3)
+# GLWE_1_1024_128 (sunscreen_tfhe/src/params.rs:248-255) with a short LWE side
+P1024 = O.DEFAULT_128.replace(lwe_n=12, N=1024, k=1, glwe_std=7.2e-8, pbs_radix_log=8, pbs_count=3, cbs_radix_log=4, cbs_count=4)
+SMALL16 = O.DEFAULT_128.replace(lwe_n=5, lwe_std=0.0, N=16, k=1, glwe_std=0.0, pbs_radix_log=6, pbs_count=2, cbs_radix_log=5,
+                                cbs_count=3, ks_radix_log=2, ks_count=6)
+
+
+def _ggsw(rng, sk, bit, P):
+    return O.encrypt_ggsw_fft(rng, sk, bit, P.N, P.k, P.cbs_radix_log, P.cbs_count, P.glwe_std)
+
+
+def test_reference_can_cmux_fft_replayed_on_the_gpu():
+    """fft_ops.rs:577-619 at TEST_GLWE_DEF_1 / TEST_RADIX: cmux(a, b, sel) decrypts to b when sel = 1, else a."""
+    P = TEST1
+    eng = spf_amd.Engine(to_engine_params(P))
+    rng = O.Rng(0xC0DE1)
+    sk = O.gen_binary_key(rng, P.k * P.N)
+    r = np.random.default_rng(5)
+    B = 24
+    sels = r.integers(0, 2, B)
+    a_pt = r.integers(0, 2, (B, P.N)).astype(np.uint64)
+    b_pt = r.integers(0, 2, (B, P.N)).astype(np.uint64)
+    enc = lambda pt: O.encrypt_glwe(rng, sk, np.array([O.encode(int(v), 1) for v in pt], dtype=np.uint64), P.N, P.k, P.glwe_std)  # noqa: E731
+    a = np.stack([enc(x) for x in a_pt])
+    b = np.stack([enc(x) for x in b_pt])
+    g = np.stack([_ggsw(rng, sk, int(s), P) for s in sels])
+    got = eng.cmux(g, a, b)
+    assert eng.last_cmux_kernel() == "generic_cmux_kernel"
+    for i in range(B):
+        assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+        dec = np.array([O.decode(int(t), 1) for t in O.decrypt_glwe_raw(got[i], sk, P.N, P.k)], dtype=np.uint64)
+        assert np.array_equal(dec, b_pt[i] if sels[i] else a_pt[i]), i
+
+
+def test_reference_can_fft_external_product_replayed_on_the_gpu():
+    """fft_ops.rs:537-575: glwe [*] ggsw decrypts to the GLWE's plaintext when the GGSW encrypts 1, to zero when 0; and
+    glev_cmux = cmux over each constituent GLWE."""
+    P = TEST1
+    eng = spf_amd.Engine(to_engine_params(P))
+    rng = O.Rng(0xC0DE2)
+    sk = O.gen_binary_key(rng, P.k * P.N)
+    r = np.random.default_rng(6)
+    B = 16
+    sels = r.integers(0, 2, B)
+    pt = r.integers(0, 2, (B, P.N)).astype(np.uint64)
+    x = np.stack([O.encrypt_glwe(rng, sk, np.array([O.encode(int(v), 1) for v in p], dtype=np.uint64), P.N, P.k, P.glwe_std) for p in pt])
+    g = np.stack([_ggsw(rng, sk, int(s), P) for s in sels])
+    got = eng.multiply_glwe_ggsw(x, g)
+    for i in range(B):
+        fft = O.glwe_ggsw_mad(np.zeros(P.glwe_len // 2, dtype=np.complex128), x[i], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)
+        h = P.N // 2
+        exp = np.concatenate([O.poly_ifft(fft[q * h:(q + 1) * h]) for q in range(P.k + 1)])
+        assert np.array_equal(got[i], exp), i
+        dec = np.array([O.decode(int(t), 1) for t in O.decrypt_glwe_raw(got[i], sk, P.N, P.k)], dtype=np.uint64)
+        assert np.array_equal(dec, pt[i] if sels[i] else np.zeros(P.N, dtype=np.uint64)), i
+    # glev_cmux (fft_ops.rs:203-220)
+    ga = random_glwe(7, 3 * P.cbs_count, P.glwe_len).reshape(3, P.cbs_count, P.glwe_len)
+    gb = random_glwe(8, 3 * P.cbs_count, P.glwe_len).reshape(3, P.cbs_count, P.glwe_len)
+    gg = eng.glev_cmux(g[:3], ga, gb).reshape(3, P.cbs_count, P.glwe_len)
+    for i in range(3):
+        for j in range(P.cbs_count):
+            assert np.array_equal(gg[i, j], O.cmux(ga[i, j], gb[i, j], g[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), (i, j)
+
+
+@pytest.mark.parametrize("P", [TEST1, TEST2, P1024, SMALL16], ids=["N128k2", "N256k3", "N1024k1", "N16k1"])
+def test_generic_bootstrap_family_against_the_oracle(P):
+    """generalized PBS (shared and per-ciphertext LUTs, several (log_chi, log_v, rotation)), univariate PBS, the circuit
+    bootstrap's PBS, keyswitch, sample extract and the linear operations at other parameter sets: every word against the
+    oracle."""
+    ks = O.gen_keyset(0x5EED0007, P)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    B = 5
+    lwe = random_lwe_batch(0x6E00 + P.N, B, P.lwe_n)
+    lut = random_glwe(0x6E10 + P.N, 1, P.glwe_len)[0]
+    luts = random_glwe(0x6E20 + P.N, B, P.glwe_len)
+    got = eng.generalized_pbs(lwe, lut, 0, 0, 0)
+    assert eng.last_blind_rotate_kernel() == "generic_pbs_kernel"
+    for i in range(B):
+        assert np.array_equal(got[i], O.generalized_pbs(lwe[i], lut, ks.bsk_fft, P, 0, 0)), i
+    got = eng.generalized_pbs(lwe, luts, 1, 2, 1 << 61)
+    for i in range(B):
+        rot = lwe[i].copy()
+        rot[-1] = np.uint64((int(rot[-1]) + (1 << 61)) & ((1 << 64) - 1))
+        assert np.array_equal(got[i], O.generalized_pbs(rot, luts[i], ks.bsk_fft, P, 1, 2)), i
+    u = eng.pbs_univariate(lwe, lut)
+    for i in range(B):
+        assert np.array_equal(u[i], O.pbs_univariate(lwe[i], lut, ks.bsk_fft, P)), i
+    c = eng.circuit_bootstrap_pbs(lwe)
+    for i in range(B):
+        assert np.array_equal(c[i], O.cbs_pbs(lwe[i], ks.bsk_fft, P)), i
+    lwe1 = random_lwe_batch(0x6E30 + P.N, B, P.k * P.N)
+    sw = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+    for i in range(B):
+        assert np.array_equal(sw[i], O.keyswitch_lwe(lwe1[i], ks.ksk, P.k * P.N, P.lwe_n, P.ks_radix_log, P.ks_count)), i
+    gate = eng.gate_bootstrap(lwe1)
+    for i in range(B):
+        assert np.array_equal(gate[i], O.cbs_pbs(sw[i], ks.bsk_fft, P)), i
+    a = random_glwe(0x6E40 + P.N, B, P.glwe_len)
+    b = random_glwe(0x6E50 + P.N, B, P.glwe_len)
+    for idx in (0, 1, P.N // 2, P.N - 1):
+        se = eng.sample_extract_l1(a, idx)
+        for i in range(B):
+            assert np.array_equal(se[i], O.sample_extract(a[i], idx, P.N, P.k)), (idx, i)
+    n1, x = eng.glwe_not(a), eng.glwe_xor(a, b)
+    for amount in (0, 1, P.N - 1, P.N, P.N + 3, 2 * P.N + 5):
+        m = eng.glwe_mul_xn(a, amount)
+        for i in range(B):
+            assert np.array_equal(m[i], O.glwe_mul_xn(a[i], amount, P.N, P.k)), (amount, i)
+    for i in range(B):
+        assert np.array_equal(n1[i], O.glwe_not(a[i], P.N, P.k))
+        assert np.array_equal(x[i], O.glwe_xor(a[i], b[i], P.N, P.k))
+
+
+def test_reference_bootstrap_helper_shape_replayed_at_small_parameters():
+    """programmable_bootstrapping.rs:708-779 (`can_bootstrap`, `can_bootstrap_with_map`) at TEST_LWE_DEF_1 / TEST_GLWE_DEF_1:
+    every message of the plaintext space, encrypted with a padding bit, bootstrapped through `generate_lut`'s table, decrypts to
+    map(msg)."""
+    P = TEST1.replace(pbs_radix_log=8, pbs_count=2)
+    EP = to_engine_params(P)
+    ks = O.gen_keyset(0x5EED0008, P, with_ksk=False)
+    eng = spf_amd.Engine(EP)
+    eng.load_bootstrap_key(ks.bsk_fft)
+    bits = 2
+    for fmap in (lambda v: v, lambda v: (v + 3) % 4):
+        lut = spf_amd.generate_lut([fmap], bits, EP)
+        assert np.array_equal(lut, O.trivial_lut_glwe(O.generate_lut(P.N, [fmap], bits), P))
+        msgs = list(range(1 << bits))
+        rng = O.Rng(77)
+        cts = np.stack([O.encrypt_lwe(rng, ks.lwe_sk, m << (64 - bits - 1), P.lwe_std) for m in msgs])
+        out = eng.pbs_univariate(cts, lut)
+        for m, ct_in, ct_out in zip(msgs, cts, out):
+            assert np.array_equal(ct_out, O.pbs_univariate(ct_in, lut, ks.bsk_fft, P))
+            dec = O.decode(O.decrypt_lwe_raw(ct_out, ks.glwe_sk), bits)
+            assert dec == fmap(m), (m, dec)
+
+
+def test_generic_contexts_say_what_they_do_not_do():
+    P = to_engine_params(TEST1)
+    eng = spf_amd.Engine(P)
+    with pytest.raises(spf_amd.SpfError) as e:
+        eng.mod_switch_trace_and_rotate(random_glwe(1, 1, TEST1.glwe_len))
+    assert e.value.status == 4 and "DEFAULT_128" in str(e.value)
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.FheCircuit(eng)
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.Engine(P.replace(polynomial_degree=96))        # not a power of two
+    with pytest.raises(spf_amd.SpfError):
+        spf_amd.Engine(spf_amd.DEFAULT_128.replace(pbs_radix_log=4, pbs_radix_count=3))   # N = 2048 needs the DAG-I kernels' radix
