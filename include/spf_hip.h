@@ -23,8 +23,8 @@
  *   - "_batch" entry points take HOST pointers (what a Rust shim holding `&[u64]` passes) and
  *     stage through device memory; "_dev" entry points take DEVICE pointers plus a hipStream_t
  *     (passed as void*) and are asynchronous on that stream.
- *   - a context is bound to one GPU; one process per GPU.  Calls on one context are
- *     serialised internally (thread-safe); use one context per stream for concurrency.
+ *   - a context is bound to one GPU.  Calls on one context are serialised internally (thread-safe); use one context per
+ *     stream for concurrency.  A device group (spf_group_*) holds one context per GPU of the node for ONE host process.
  */
 #ifndef SPF_HIP_H
 #define SPF_HIP_H
@@ -63,7 +63,10 @@ typedef struct spf_params {
     uint32_t ss_radix_count;    /* ss_radix.count           = 15   */
 } spf_params;
 
-/* DEFAULT_128 (parasol_runtime/src/params.rs:107-134) */
+/* DEFAULT_128 (parasol_runtime/src/params.rs:107-134): the parameter set the tuned kernels are built for (lwe_dimension and the
+ * keyswitch radix are free).  Any other set with polynomial_degree a power of two in 16 .. 1024, glwe_size <= 8 and radices with
+ * radix_log * count < 64 is served by a generic, untuned kernel family with the same results as the reference's generic functions
+ * (every entry point except the gate graphs); polynomial_degree 2048 with another glwe_size or pbs radix is SPF_ERR_UNSUPPORTED. */
 void spf_default_params(spf_params *out);
 
 typedef struct spf_ctx spf_ctx;

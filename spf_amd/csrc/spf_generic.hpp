@@ -77,16 +77,15 @@ __device__ inline uint64_t generic_next_digit(uint64_t& s, uint32_t radix_log)
     return digit - (carry << radix_log);
 }
 
-// glwe_ggsw_mad (fft_ops.rs:23-56 -> :67-98 -> :107-124) into accf (cleared here); `coef(p, i)` yields coefficient i of
-// polynomial p of the GLWE being multiplied.  ggsw: [row<k+1][level<count][poly<k+1][bin<N/2].
+// decomposed_polynomial_glev_mad (fft_ops.rs:67-98 -> :107-124): accf += <decomp(poly), glev>, GLEV entries in reverse;
+// `coef(i)` yields coefficient i of the polynomial.  glev: [level<count][poly<k+1][bin<N/2].
 template <class COEF>
-__device__ inline void generic_glwe_ggsw_mad(const GenericShape& g, c64* accf, c64* buf, uint64_t* state, const c64* ggsw,
-                                             uint32_t radix_log, uint32_t count, COEF coef)
+__device__ inline void generic_glev_mad(const GenericShape& g, c64* accf, c64* buf, uint64_t* state, const c64* glev,
+                                        uint32_t radix_log, uint32_t count, COEF coef)
 {
     const uint32_t tid = threadIdx.x, N = g.N, h = N / 2, k = g.k;
-    for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) accf[i] = {0.0, 0.0};
-    for (uint32_t p = 0; p <= k; p++) {
-        for (uint32_t i = tid; i < N; i += kGenericThreads) state[i] = generic_radix_round(coef(p, i), radix_log, count);
+    {
+        for (uint32_t i = tid; i < N; i += kGenericThreads) state[i] = generic_radix_round(coef(i), radix_log, count);
         __syncthreads();
         for (uint32_t j = 0; j < count; j++) {
             // next digit of every coefficient (each state word has ONE owner: thread i mod 256 for i and for i + N/2 alike)
@@ -100,7 +99,7 @@ __device__ inline void generic_glwe_ggsw_mad(const GenericShape& g, c64* accf, c
             __syncthreads();
             generic_fft(buf, h, g.logN - 1, +1, g.w);
             // GLEV entries are consumed in reverse (fft_ops.rs:92)
-            const c64* row = ggsw + ((size_t)p * count + (count - 1 - j)) * (size_t)(k + 1) * h;
+            const c64* row = glev + (size_t)(count - 1 - j) * (size_t)(k + 1) * h;
             for (uint32_t q = 0; q <= k; q++)
                 for (uint32_t t = tid; t < h; t += kGenericThreads) {
                     const c64 a = row[(size_t)q * h + t], b = buf[t], c = accf[q * h + t];
@@ -113,6 +112,31 @@ __device__ inline void generic_glwe_ggsw_mad(const GenericShape& g, c64* accf, c
             __syncthreads();
         }
     }
+}
+
+// glwe_ggsw_mad (fft_ops.rs:23-56) into accf (cleared here); `coef(p, i)` yields coefficient i of polynomial p of the GLWE being
+// multiplied.  ggsw: [row<k+1][level<count][poly<k+1][bin<N/2].
+template <class COEF>
+__device__ inline void generic_glwe_ggsw_mad(const GenericShape& g, c64* accf, c64* buf, uint64_t* state, const c64* ggsw,
+                                             uint32_t radix_log, uint32_t count, COEF coef)
+{
+    const uint32_t tid = threadIdx.x, h = g.N / 2, k = g.k;
+    for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) accf[i] = {0.0, 0.0};
+    __syncthreads();
+    for (uint32_t p = 0; p <= k; p++)
+        generic_glev_mad(g, accf, buf, state, ggsw + (size_t)p * count * (size_t)(k + 1) * h, radix_log, count,
+                         [&](uint32_t i) { return coef(p, i); });
+}
+
+// PolynomialRef::fft of a full-range torus polynomial (entities/polynomial.rs:257-274) into spec[N/2]; `coef(i)` its words
+template <class COEF>
+__device__ inline void generic_poly_fft(const GenericShape& g, c64* spec, COEF coef)
+{
+    const uint32_t tid = threadIdx.x, h = g.N / 2;
+    for (uint32_t t = tid; t < h; t += kGenericThreads)
+        spec[t] = cmul_nf({(double)(int64_t)coef(t), (double)(int64_t)coef(t + h)}, g.twist[t]);
+    __syncthreads();
+    generic_fft(spec, h, g.logN - 1, +1, g.w);
 }
 
 // PolynomialFftRef::ifft of spectrum q of accf (entities/polynomial_fft.rs:82-99): `sink(i, torus word)` for i < N
@@ -265,6 +289,108 @@ __global__ void generic_linear_kernel(const uint64_t* a, const uint64_t* b, uint
             const uint64_t v = x[p * N + (idx & (N - 1))];
             o[i] = ((idx >> logN) & 1) ? (uint64_t)0 - v : v;
         }
+    }
+}
+
+struct GenericTraceArgs {
+    GenericShape g;
+    const uint64_t* glwe_in; // B x (k+1) N: lo-noise GLWE out of the bootstrap
+    uint64_t* glev_out;      // B x cbs_count x (k+1) N
+    const c64* ak;           // [log2 N][row<k][level<tr_count][poly<k+1][N/2]
+    uint32_t units, cbs_count, cbs_radix_log, tr_radix_log, tr_count;
+};
+__host__ __device__ inline size_t generic_trace_lds_bytes(uint32_t N, uint32_t k)
+{
+    return generic_lds_bytes(N, k, true) + (size_t)(k + 1) * N * 8; // + the automorphed copy
+}
+
+// mod_switch_trace_and_rotate for one (ciphertext, gadget level) (circuit_bootstrapping.rs:260-298): un-rotate, X^-level,
+// shift-round by log2 N, then the trace (automorphisms/mod.rs:53-85) = log2 N rounds of automorphism + FFT-domain GLWE
+// keyswitch (fft_ops.rs:457-495)
+__global__ __launch_bounds__(kGenericThreads) void generic_trace_kernel(GenericTraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GenericShape& g = a.g;
+    const uint32_t tid = threadIdx.x, N = g.N, h = N / 2, k = g.k, len = (k + 1) * N;
+    c64* accf = reinterpret_cast<c64*>(smem);
+    c64* buf = accf + (size_t)(k + 1) * h;
+    uint64_t* state = reinterpret_cast<uint64_t*>(buf + h);
+    uint64_t* X = state + N;
+    uint64_t* G = X + len;
+    const uint32_t unit = blockIdx.x, ct = unit / a.cbs_count, lvl = unit % a.cbs_count;
+    const uint64_t* in = a.glwe_in + (size_t)ct * len;
+    for (uint32_t i = tid; i < len; i += kGenericThreads) {
+        const uint32_t p = i / N, c = i % N, idx = c + lvl; // X^-lvl: out[c] = +-in[c + lvl]
+        const uint32_t src = idx & (N - 1);
+        uint64_t v = in[p * N + src];
+        if (p == k && src <= lvl) v += (uint64_t)1 << (64 - (a.cbs_radix_log * (src + 1) + 1)); // body coefficients 0..lvl un-rotated
+        v = ((idx >> g.logN) & 1) ? (uint64_t)0 - v : v;
+        X[i] = (v >> g.logN) + ((v >> (g.logN - 1)) & 1); // glwe_mod_switch_and_expand_pow_2
+    }
+    __syncthreads();
+    const size_t glev_len = (size_t)a.tr_count * (k + 1) * h, ksk_len = (size_t)k * glev_len;
+    for (uint32_t it = 1; it <= g.logN; it++) {
+        const uint32_t kk = (N >> (it - 1)) + 1;
+        // polynomial_pow_k (ops/polynomial/mod.rs:62-84): p_k[(i kk) mod N] = +-p[i], minus when (i kk) / N is odd
+        for (uint32_t i = tid; i < len; i += kGenericThreads) {
+            const uint32_t p = i / N, c = i % N, prod = c * kk;
+            const uint64_t v = X[i];
+            G[p * N + (prod & (N - 1))] = ((prod >> g.logN) & 1) ? (uint64_t)0 - v : v;
+        }
+        for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) accf[i] = {0.0, 0.0};
+        __syncthreads();
+        const c64* ksk = a.ak + (size_t)(it - 1) * ksk_len;
+        for (uint32_t r = 0; r < k; r++)
+            generic_glev_mad(g, accf, buf, state, ksk + (size_t)r * glev_len, a.tr_radix_log, a.tr_count,
+                             [&](uint32_t i) { return G[r * N + i]; });
+        // out += trivial(b_k) - ks
+        for (uint32_t q = 0; q <= k; q++)
+            generic_poly_ifft(g, accf + (size_t)q * h, buf, [&](uint32_t i, uint64_t t) {
+                X[q * N + i] += (q == k ? G[k * N + i] : (uint64_t)0) - t;
+            });
+    }
+    uint64_t* out = a.glev_out + (size_t)unit * len;
+    for (uint32_t i = tid; i < len; i += kGenericThreads) out[i] = X[i];
+}
+
+struct GenericSchemeSwitchArgs {
+    GenericShape g;
+    const uint64_t* glev;  // B x cbs_count x (k+1) N
+    c64* ggsw_out;         // B x [row<k+1][level<cbs_count][poly<k+1][N/2]
+    const c64* ssk;        // [pair][level<ss_count][poly<k+1][N/2], pairs upper-triangular (entities/scheme_switch_key.rs)
+    uint32_t units, cbs_count, ss_radix_log, ss_count;
+};
+
+// scheme_switch_fft for one (ciphertext, gadget level): the k+1 rows of that level (fft_ops.rs:225-279, 403-442)
+__global__ __launch_bounds__(kGenericThreads) void generic_scheme_switch_kernel(GenericSchemeSwitchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GenericShape& g = a.g;
+    const uint32_t tid = threadIdx.x, N = g.N, h = N / 2, k = g.k, len = (k + 1) * N;
+    c64* y = reinterpret_cast<c64*>(smem);
+    c64* buf = y + (size_t)(k + 1) * h;
+    uint64_t* state = reinterpret_cast<uint64_t*>(buf + h);
+    const uint32_t unit = blockIdx.x, ct = unit / a.cbs_count, lvl = unit % a.cbs_count;
+    const uint64_t* x = a.glev + (size_t)unit * len;
+    const size_t glwe_fft_len = (size_t)(k + 1) * h, ss_glev_len = (size_t)a.ss_count * glwe_fft_len;
+    c64* out_ct = a.ggsw_out + (size_t)ct * (k + 1) * a.cbs_count * glwe_fft_len;
+    for (uint32_t j = 0; j <= k; j++) {
+        c64* dst = out_ct + ((size_t)j * a.cbs_count + lvl) * glwe_fft_len;
+        if (j == k) {
+            for (uint32_t p = 0; p <= k; p++) generic_poly_fft(g, y + (size_t)p * h, [&](uint32_t i) { return x[p * N + i]; });
+        } else {
+            for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) y[i] = {0.0, 0.0};
+            __syncthreads();
+            generic_poly_fft(g, y + (size_t)j * h, [&](uint32_t i) { return x[k * N + i]; }); // y.a[j] = FFT(x.b)
+            for (uint32_t r = 0; r < k; r++) {
+                const uint32_t row = j <= r ? j : r, col = j <= r ? r : j; // get_linear_index of the upper triangle
+                const size_t pair = (size_t)(k * (k + 1) / 2) - (size_t)(k - row) * ((k - row) + 1) / 2 + col - row;
+                generic_glev_mad(g, y, buf, state, a.ssk + pair * ss_glev_len, a.ss_radix_log, a.ss_count,
+                                 [&](uint32_t i) { return x[r * N + i]; });
+            }
+        }
+        for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) dst[i] = y[i];
+        __syncthreads();
     }
 }
 

@@ -105,8 +105,8 @@ struct spf_ctx {
     bool timing = false;
     std::vector<TimedLaunch> timed[T_COUNT];
     // any other parameter set (spf_generic.hpp): N a power of two in 8 .. 1024, any k and radix.  One workgroup per ciphertext,
-    // the oracle's transform for those sizes; the blind rotation, the CMUX family, sample extract, the linear operations and the
-    // keyswitch (its VALU form) are served, the circuit-bootstrap tail and gate graphs are not.
+    // the oracle's transform for those sizes; every batch and device-pointer entry point is served (keyswitch in its VALU form);
+    // gate graphs are not.
     bool generic = false;
     uint32_t log_n = 11;
     c64* d_gen_tables = nullptr; // [N/2] twist, then [N/4] transform twiddles
@@ -445,7 +445,11 @@ bool params_generic(const spf_params& p, std::string& why)
         why = "a radix decomposition needs 1 <= radix_log * count < 64";
         return false;
     }
-    if (generic_lds_bytes(N, p.glwe_size, true) > 160 * 1024) { why = "(k+1) polynomials of this degree do not fit the generic kernels' LDS"; return false; }
+    if (generic_trace_lds_bytes(N, p.glwe_size) > 160 * 1024) { why = "(k+1) polynomials of this degree do not fit the generic kernels' LDS"; return false; }
+    if (!radix_ok(p.tr_radix_log, p.tr_radix_count) || !radix_ok(p.ss_radix_log, p.ss_radix_count)) {
+        why = "a radix decomposition needs 1 <= radix_log * count < 64";
+        return false;
+    }
     if (p.lwe_dimension == 0 || p.lwe_dimension > 4096) { why = "lwe_dimension out of range"; return false; }
     if (p.ks_radix_log == 0 || p.ks_radix_log * p.ks_radix_count > 32) { why = "ks_radix must satisfy 0 < l*logB <= 32"; return false; }
     if (p.cbs_radix_count >= 8) { why = "cbs_radix.count must be in 1..7"; return false; }
@@ -557,6 +561,10 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_pbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)generic_lds_bytes(N, params->glwe_size, true)));
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_cmux_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)generic_lds_bytes(N, params->glwe_size, false)));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)generic_trace_lds_bytes(N, params->glwe_size)));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_scheme_switch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)generic_lds_bytes(N, params->glwe_size, false)));
         *out = c;
         return SPF_OK;
@@ -819,7 +827,7 @@ spf_status spf_circuit_bootstrap_pbs_dev(spf_ctx* c, void* stream, size_t B, con
 static spf_status tail_supported(spf_ctx* c)
 {
     const spf_params& p = c->prm;
-    if (c->generic) return fail(c, SPF_ERR_UNSUPPORTED, "the circuit-bootstrap tail (trace, scheme switch) is built for DEFAULT_128 only");
+    if (c->generic) return SPF_OK; // (generic_trace_kernel / generic_scheme_switch_kernel take any radix)
     if (p.cbs_radix_log != 4 || p.cbs_radix_count != 4 || p.tr_radix_log != 7 || p.tr_radix_count != 6 ||
         p.ss_radix_log != 3 || p.ss_radix_count != 15)
         return fail(c, SPF_ERR_UNSUPPORTED, "circuit-bootstrap tail is built for cbs 4x4, tr 6x7, ss 15x3 bits");
@@ -829,6 +837,16 @@ static spf_status tail_supported(spf_ctx* c)
 static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_glwe, uint64_t* d_glev)
 {
     if (!c->ak_ready) return fail(c, SPF_ERR_NO_KEY, "automorphism key not loaded");
+    if (c->generic) {
+        GenericTraceArgs ga{};
+        ga.g = generic_shape(c);
+        ga.glwe_in = d_glwe; ga.glev_out = d_glev; ga.ak = c->d_ak;
+        ga.units = (uint32_t)(B * c->prm.cbs_radix_count); ga.cbs_count = c->prm.cbs_radix_count; ga.cbs_radix_log = c->prm.cbs_radix_log;
+        ga.tr_radix_log = c->prm.tr_radix_log; ga.tr_count = c->prm.tr_radix_count;
+        hipLaunchKernelGGL(generic_trace_kernel, dim3(ga.units), dim3(kGenericThreads), generic_trace_lds_bytes(ga.g.N, ga.g.k), s, ga);
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     TraceArgs a{};
     a.glwe_in = d_glwe; a.glev_out = d_glev; a.ak = c->d_ak; a.tables = c->d_tables;
     a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;
@@ -878,6 +896,16 @@ static spf_status launch_trace(spf_ctx* c, hipStream_t s, size_t B, const uint64
 static spf_status launch_scheme_switch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t* d_glev, double* d_ggsw)
 {
     if (!c->ssk_ready) return fail(c, SPF_ERR_NO_KEY, "scheme-switch key not loaded");
+    if (c->generic) {
+        GenericSchemeSwitchArgs ga{};
+        ga.g = generic_shape(c);
+        ga.glev = d_glev; ga.ggsw_out = reinterpret_cast<c64*>(d_ggsw); ga.ssk = c->d_ssk;
+        ga.units = (uint32_t)(B * c->prm.cbs_radix_count); ga.cbs_count = c->prm.cbs_radix_count;
+        ga.ss_radix_log = c->prm.ss_radix_log; ga.ss_count = c->prm.ss_radix_count;
+        hipLaunchKernelGGL(generic_scheme_switch_kernel, dim3(ga.units), dim3(kGenericThreads), generic_lds_bytes(ga.g.N, ga.g.k, false), s, ga);
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     SchemeSwitchArgs a{};
     a.glev = d_glev; a.ggsw_out = reinterpret_cast<c64*>(d_ggsw); a.ssk = c->d_ssk; a.tables = c->d_tables;
     a.units = (uint32_t)(B * c->prm.cbs_radix_count); a.cbs_count = c->prm.cbs_radix_count;

@@ -159,14 +159,56 @@ def test_reference_bootstrap_helper_shape_replayed_at_small_parameters():
             assert dec == fmap(m), (m, dec)
 
 
+def _eng_params(P):
+    return to_engine_params(P).replace(tr_radix_log=P.tr_radix_log, tr_radix_count=P.tr_count,
+                                       ss_radix_log=P.ss_radix_log, ss_radix_count=P.ss_count)
+
+
+@pytest.mark.parametrize("P", [TEST1.replace(lwe_n=6, tr_radix_log=7, tr_count=6, ss_radix_log=3, ss_count=15),
+                               TEST2.replace(lwe_n=4, tr_radix_log=5, tr_count=7, ss_radix_log=4, ss_count=8),
+                               SMALL16.replace(tr_radix_log=6, tr_count=5, ss_radix_log=5, ss_count=6)],
+                         ids=["N128k2", "N256k3", "N16k1"])
+def test_generic_circuit_bootstrap_tail_against_the_oracle(P):
+    """mod_switch_trace_and_rotate, scheme_switch_fft and the whole `Evaluation::circuit_bootstrap` at k = 2 / 3 / 1 (the upper-
+    triangular scheme-switch key pairs of k > 1 included): every word against the oracle."""
+    ks = O.gen_keyset(0x5EED0009, P)
+    r = O.Rng(0x7A12)
+    ak = O.gen_auto_key_fft(r, ks.glwe_sk, P)
+    ssk = O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng = spf_amd.Engine(_eng_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    B = 3
+    glwe = random_glwe(0x7B00 + P.N, B, P.glwe_len)
+    got = eng.mod_switch_trace_and_rotate(glwe)
+    for i in range(B):
+        assert np.array_equal(got[i], O.mod_switch_trace_and_rotate(glwe[i], ak, P)), i
+    glev = random_glwe(0x7B10 + P.N, B * P.cbs_count, P.glwe_len).reshape(B, P.cbs_count, P.glwe_len)
+    gg = eng.scheme_switch(glev)
+    for i in range(B):
+        assert np.array_equal(gg[i].view(np.float64), O.scheme_switch_fft(glev[i], ssk, P).view(np.float64)), i
+    lwe = random_lwe_batch(0x7B20 + P.N, B, P.lwe_n)
+    cb = eng.circuit_bootstrap(lwe)
+    lwe1 = random_lwe_batch(0x7B30 + P.N, B, P.k * P.N)
+    kcb = eng.keyswitch_circuit_bootstrap(lwe1)
+    for i in range(B):
+        assert np.array_equal(cb[i].view(np.float64), O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P).view(np.float64)), i
+        l0 = O.keyswitch_lwe(lwe1[i], ks.ksk, P.k * P.N, P.lwe_n, P.ks_radix_log, P.ks_count)
+        assert np.array_equal(kcb[i].view(np.float64), O.circuit_bootstrap(l0, ks.bsk_fft, ak, ssk, P).view(np.float64)), i
+    for bit in (0, 1):
+        triv = np.zeros(P.lwe_n + 1, dtype=np.uint64)
+        triv[-1] = np.uint64(bit << 63)
+        assert np.array_equal(eng.l1ggsw_constant(bit).view(np.float64), O.circuit_bootstrap(triv, ks.bsk_fft, ak, ssk, P).view(np.float64))
+
+
 def test_generic_contexts_say_what_they_do_not_do():
     P = to_engine_params(TEST1)
     eng = spf_amd.Engine(P)
     with pytest.raises(spf_amd.SpfError) as e:
-        eng.mod_switch_trace_and_rotate(random_glwe(1, 1, TEST1.glwe_len))
-    assert e.value.status == 4 and "DEFAULT_128" in str(e.value)
-    with pytest.raises(spf_amd.SpfError):
         spf_amd.FheCircuit(eng)
+    assert e.value.status == 4 and "DEFAULT_128" in str(e.value)
     with pytest.raises(spf_amd.SpfError):
         spf_amd.Engine(P.replace(polynomial_degree=96))        # not a power of two
     with pytest.raises(spf_amd.SpfError):
