@@ -1,4 +1,4 @@
-// spf_generic.hpp — the path for ANY power-of-two polynomial degree 8 <= N <= 2048, any GLWE size k and any gadget radix
+// spf_generic.hpp — the path for ANY power-of-two polynomial degree 16 <= N <= 2048, any GLWE size k and any gadget radix
 // (VERDICT r04 "missing #3").
 //
 // The specialised kernels of spf_kernels.hpp are built for the one parameter set `parasol_runtime` ships (N = 2048, k = 1,
@@ -12,17 +12,18 @@
 //              forward direction; root(j, m) is read as root(j * (N/2)/m, N/2): the same bits, by construction of the table);
 //   MAD        the AVX-512 order, four FMAs (simd/x86_64/avx512.rs:54-57);
 //   inverse    (y * (1/(N/2))) * conj(root(j, 2N)) non-fused, round half away, mod 2^64 by fma, saturating cast.
-// For N = 2048 the oracle's transform is DAG-I (the specialised kernels'), which this family does not implement: a context
-// with N = 2048 and an unsupported radix or k is refused rather than computed with a different rounding.
+// For N = 2048 the canonical transform is DAG-I (the tuned kernels'): `generic_fft1024_dag1` is its array form, so a context with
+// N = 2048 and another radix (the reference's `can_generalized_bootstrap` runs 3 x 4 bits at N = 2048) computes the same bits the
+// tuned kernels and the checker define.
 #pragma once
 #include "spf_device.hpp"
 
 namespace spf {
 
 struct GenericShape {
-    uint32_t N, logN, k;      // polynomial degree (power of two, 8 .. 1024 here), its log2, GLWE size
+    uint32_t N, logN, k;      // polynomial degree (power of two), its log2, GLWE size
     const c64* twist;         // [N/2]  e^{+2 pi i j / (2N)}
-    const c64* w;             // [N/4]  e^{+2 pi i j / (N/2)}   (N/2 >= 8)
+    const c64* w;             // N < 2048: [N/4] e^{+2 pi i j / (N/2)};  N = 2048: the tuned kernels' table image (DAG-I: T1, T2, WC)
 };
 
 constexpr int kGenericThreads = 256;
@@ -31,7 +32,89 @@ constexpr int kGenericThreads = 256;
 // and (blind rotation only) the accumulator (k+1) x N u64
 __host__ __device__ inline size_t generic_lds_bytes(uint32_t N, uint32_t k, bool with_acc)
 {
-    return (size_t)(k + 1) * (N / 2) * 16 + (size_t)(N / 2) * 16 + (size_t)N * 8 + (with_acc ? (size_t)(k + 1) * N * 8 : 0);
+    // (the digit state doubles as the second image of DAG-I's passes at N = 2048: N u64 = 1024 c64 — same bytes)
+    return (size_t)(k + 1) * (N / 2) * 16 + (size_t)(N / 2) * 16 + (size_t)N * 16 + (with_acc ? (size_t)(k + 1) * N * 8 : 0);
+}
+
+__device__ inline void generic_fft(c64* a, uint32_t len, uint32_t loglen, int dir, const c64* w_tab);
+
+// DAG-I's 1024-point transform on a[1024] in LDS with tmp[1024] as the second image, array form of the tuned
+// kernels' register code: the same butterflies (`radix8`), twiddle products and tables, so the same bits.  128 threads each
+// carry one radix-8 of one of the two 512-point transforms per pass.
+__device__ inline void generic_fft1024_dag1(c64* a, c64* tmp, int dir, const c64* tab)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = tid >> 6, l = tid & 63; // (tid < 128: sub-transform s, task l)
+    auto fft512_passes = [&](auto DIRC) {
+        constexpr int DIR = decltype(DIRC)::value;
+        // entry: sub-transform s has its 512 inputs at a[s * 512 + n'] (time order n' = 64 n1 + n0)
+        c64 v[8];
+        if (tid < 128) {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) v[n1] = a[s * 512 + 64 * n1 + l];
+            radix8<DIR>(v);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul_tw<DIR>(v[k1], tab[kT1Off + (k1 - 1) * 64 + l]); // W512^{n0 k1}, n0 = l
+#pragma unroll
+            for (int k1 = 0; k1 < 8; k1++) tmp[s * 512 + l * 8 + k1] = v[k1];                            // y[n0][k1]
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const uint32_t k1 = l >> 3, b = l & 7;
+#pragma unroll
+            for (int aa = 0; aa < 8; aa++) v[aa] = tmp[s * 512 + (8 * aa + b) * 8 + k1];
+            radix8<DIR>(v);
+#pragma unroll
+            for (int c = 1; c < 8; c++) v[c] = cmul_tw<DIR>(v[c], tab[kT2Off + (c - 1) * 8 + b]);          // W64^{b c}
+#pragma unroll
+            for (int c = 0; c < 8; c++) a[s * 512 + k1 * 64 + b * 8 + c] = v[c];                          // g[k1][b][c]
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const uint32_t k1 = l >> 3, c = l & 7;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v[b] = a[s * 512 + k1 * 64 + b * 8 + c];
+            radix8<DIR>(v);
+#pragma unroll
+            for (int d = 0; d < 8; d++) tmp[s * 512 + k1 + 8 * c + 64 * d] = v[d];                        // X[k1 + 8c + 64d]
+        }
+        __syncthreads();
+        // exit: sub-transform s has its 512 outputs at tmp[s * 512 + k']
+    };
+    if (dir > 0) {
+        // split by parity: E <- a[2n'], O <- a[2n'+1]
+        for (uint32_t i = tid; i < 1024; i += kGenericThreads) tmp[(i & 1) * 512 + (i >> 1)] = a[i];
+        __syncthreads();
+        for (uint32_t i = tid; i < 1024; i += kGenericThreads) a[i] = tmp[i];
+        __syncthreads();
+        fft512_passes(std::integral_constant<int, +1>{});
+        for (uint32_t k = tid; k < 512; k += kGenericThreads) {
+            const c64 t = cmul_tw<+1>(tmp[512 + k], tab[kWCOff + k]);
+            const c64 E = tmp[k];
+            a[k] = cadd(E, t);
+            a[k + 512] = csub(E, t);
+        }
+        __syncthreads();
+    } else {
+        for (uint32_t k = tid; k < 512; k += kGenericThreads) {
+            const c64 x0 = a[k], x1 = a[k + 512];
+            tmp[k] = cadd(x0, x1);
+            tmp[512 + k] = cmul_tw<-1>(csub(x0, x1), tab[kWCOff + k]);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 1024; i += kGenericThreads) a[i] = tmp[i];
+        __syncthreads();
+        fft512_passes(std::integral_constant<int, -1>{});
+        for (uint32_t i = tid; i < 1024; i += kGenericThreads) a[i] = tmp[(i & 1) * 512 + (i >> 1)];
+        __syncthreads();
+    }
+}
+
+// the transform of a context: the checker's radix-2 DIT for N < 2048, DAG-I for N = 2048
+__device__ inline void generic_transform(const GenericShape& g, c64* a, c64* tmp, int dir)
+{
+    if (g.N == 2048) generic_fft1024_dag1(a, tmp, dir, g.w);
+    else generic_fft(a, g.N / 2, g.logN - 1, dir, g.w);
 }
 
 // in-place radix-2 DIT of a[len] (LDS), every thread of the block takes part; dir > 0: forward (conjugated twiddles)
@@ -97,7 +180,7 @@ __device__ inline void generic_glev_mad(const GenericShape& g, c64* accf, c64* b
                 buf[t] = cmul_nf({re, im}, g.twist[t]);
             }
             __syncthreads();
-            generic_fft(buf, h, g.logN - 1, +1, g.w);
+            generic_transform(g, buf, reinterpret_cast<c64*>(state + N), +1);
             // GLEV entries are consumed in reverse (fft_ops.rs:92)
             const c64* row = glev + (size_t)(count - 1 - j) * (size_t)(k + 1) * h;
             for (uint32_t q = 0; q <= k; q++)
@@ -130,23 +213,23 @@ __device__ inline void generic_glwe_ggsw_mad(const GenericShape& g, c64* accf, c
 
 // PolynomialRef::fft of a full-range torus polynomial (entities/polynomial.rs:257-274) into spec[N/2]; `coef(i)` its words
 template <class COEF>
-__device__ inline void generic_poly_fft(const GenericShape& g, c64* spec, COEF coef)
+__device__ inline void generic_poly_fft(const GenericShape& g, c64* spec, c64* tmp, COEF coef)
 {
     const uint32_t tid = threadIdx.x, h = g.N / 2;
     for (uint32_t t = tid; t < h; t += kGenericThreads)
         spec[t] = cmul_nf({(double)(int64_t)coef(t), (double)(int64_t)coef(t + h)}, g.twist[t]);
     __syncthreads();
-    generic_fft(spec, h, g.logN - 1, +1, g.w);
+    generic_transform(g, spec, tmp, +1);
 }
 
 // PolynomialFftRef::ifft of spectrum q of accf (entities/polynomial_fft.rs:82-99): `sink(i, torus word)` for i < N
 template <class SINK>
-__device__ inline void generic_poly_ifft(const GenericShape& g, const c64* spec, c64* buf, SINK sink)
+__device__ inline void generic_poly_ifft(const GenericShape& g, const c64* spec, c64* buf, c64* tmp, SINK sink)
 {
     const uint32_t tid = threadIdx.x, h = g.N / 2;
     for (uint32_t t = tid; t < h; t += kGenericThreads) buf[t] = spec[t];
     __syncthreads();
-    generic_fft(buf, h, g.logN - 1, -1, g.w);
+    generic_transform(g, buf, tmp, -1);
     const double n_inv = 1.0 / (double)h;
     for (uint32_t t = tid; t < h; t += kGenericThreads) {
         const c64 y = buf[t], tw = g.twist[t];
@@ -188,7 +271,8 @@ __global__ __launch_bounds__(kGenericThreads) void generic_pbs_kernel(GenericPbs
     c64* accf = reinterpret_cast<c64*>(smem);
     c64* buf = accf + (size_t)(k + 1) * h;
     uint64_t* state = reinterpret_cast<uint64_t*>(buf + h);
-    uint64_t* acc = state + N;
+    c64* tmp = reinterpret_cast<c64*>(state + N);
+    uint64_t* acc = state + 2 * N;
     const uint32_t ct = blockIdx.x;
     const uint64_t* lwe = a.lwe_in + (size_t)ct * (a.n + 1);
     const uint64_t* lut = a.lut + (size_t)ct * a.lut_stride;
@@ -214,7 +298,7 @@ __global__ __launch_bounds__(kGenericThreads) void generic_pbs_kernel(GenericPbs
             return rot - acc[p * N + i];
         });
         for (uint32_t q = 0; q <= k; q++)
-            generic_poly_ifft(g, accf + (size_t)q * h, buf, [&](uint32_t i, uint64_t t) { acc[q * N + i] += t; });
+            generic_poly_ifft(g, accf + (size_t)q * h, buf, tmp, [&](uint32_t i, uint64_t t) { acc[q * N + i] += t; });
     }
     if (!a.sample_extract) {
         uint64_t* out = a.out + (size_t)ct * a.out_stride;
@@ -256,7 +340,7 @@ __global__ __launch_bounds__(kGenericThreads) void generic_cmux_kernel(GenericCm
     generic_glwe_ggsw_mad(g, accf, buf, state, ggsw, a.radix_log, a.count,
                           [&](uint32_t p, uint32_t i) { return zero ? d1[p * N + i] : d1[p * N + i] - d0[p * N + i]; });
     for (uint32_t q = 0; q <= k; q++)
-        generic_poly_ifft(g, accf + (size_t)q * h, buf, [&](uint32_t i, uint64_t t) { out[q * N + i] = zero ? t : t + d0[q * N + i]; });
+        generic_poly_ifft(g, accf + (size_t)q * h, buf, reinterpret_cast<c64*>(state + N), [&](uint32_t i, uint64_t t) { out[q * N + i] = zero ? t : t + d0[q * N + i]; });
     (void)tid;
 }
 
@@ -315,7 +399,8 @@ __global__ __launch_bounds__(kGenericThreads) void generic_trace_kernel(GenericT
     c64* accf = reinterpret_cast<c64*>(smem);
     c64* buf = accf + (size_t)(k + 1) * h;
     uint64_t* state = reinterpret_cast<uint64_t*>(buf + h);
-    uint64_t* X = state + N;
+    c64* tmp = reinterpret_cast<c64*>(state + N);
+    uint64_t* X = state + 2 * N;
     uint64_t* G = X + len;
     const uint32_t unit = blockIdx.x, ct = unit / a.cbs_count, lvl = unit % a.cbs_count;
     const uint64_t* in = a.glwe_in + (size_t)ct * len;
@@ -345,7 +430,7 @@ __global__ __launch_bounds__(kGenericThreads) void generic_trace_kernel(GenericT
                              [&](uint32_t i) { return G[r * N + i]; });
         // out += trivial(b_k) - ks
         for (uint32_t q = 0; q <= k; q++)
-            generic_poly_ifft(g, accf + (size_t)q * h, buf, [&](uint32_t i, uint64_t t) {
+            generic_poly_ifft(g, accf + (size_t)q * h, buf, tmp, [&](uint32_t i, uint64_t t) {
                 X[q * N + i] += (q == k ? G[k * N + i] : (uint64_t)0) - t;
             });
     }
@@ -377,11 +462,11 @@ __global__ __launch_bounds__(kGenericThreads) void generic_scheme_switch_kernel(
     for (uint32_t j = 0; j <= k; j++) {
         c64* dst = out_ct + ((size_t)j * a.cbs_count + lvl) * glwe_fft_len;
         if (j == k) {
-            for (uint32_t p = 0; p <= k; p++) generic_poly_fft(g, y + (size_t)p * h, [&](uint32_t i) { return x[p * N + i]; });
+            for (uint32_t p = 0; p <= k; p++) generic_poly_fft(g, y + (size_t)p * h, reinterpret_cast<c64*>(state + N), [&](uint32_t i) { return x[p * N + i]; });
         } else {
             for (uint32_t i = tid; i < (k + 1) * h; i += kGenericThreads) y[i] = {0.0, 0.0};
             __syncthreads();
-            generic_poly_fft(g, y + (size_t)j * h, [&](uint32_t i) { return x[k * N + i]; }); // y.a[j] = FFT(x.b)
+            generic_poly_fft(g, y + (size_t)j * h, reinterpret_cast<c64*>(state + N), [&](uint32_t i) { return x[k * N + i]; }); // y.a[j] = FFT(x.b)
             for (uint32_t r = 0; r < k; r++) {
                 const uint32_t row = j <= r ? j : r, col = j <= r ? r : j; // get_linear_index of the upper triangle
                 const size_t pair = (size_t)(k * (k + 1) / 2) - (size_t)(k - row) * ((k - row) + 1) / 2 + col - row;

@@ -104,7 +104,7 @@ struct spf_ctx {
     std::vector<hipEvent_t> slice_ev;  // one "slice k is computed" event per slice in flight
     bool timing = false;
     std::vector<TimedLaunch> timed[T_COUNT];
-    // any other parameter set (spf_generic.hpp): N a power of two in 8 .. 1024, any k and radix.  One workgroup per ciphertext,
+    // any other parameter set (spf_generic.hpp): N a power of two in 16 .. 2048, any k and radix that fit the LDS.  One workgroup per ciphertext,
     // the oracle's transform for those sizes; every batch and device-pointer entry point is served (keyswitch in its VALU form);
     // gate graphs are not.
     bool generic = false;
@@ -250,7 +250,8 @@ GenericShape generic_shape(const spf_ctx* c)
 {
     GenericShape g{};
     g.N = c->prm.polynomial_degree; g.logN = c->log_n; g.k = c->prm.glwe_size;
-    g.twist = c->d_gen_tables; g.w = c->d_gen_tables + g.N / 2;
+    g.twist = c->d_gen_tables;
+    g.w = g.N == (uint32_t)kN ? c->d_tables : c->d_gen_tables + g.N / 2; // N = 2048: DAG-I reads the tuned kernels' table image
     return g;
 }
 
@@ -435,8 +436,8 @@ spf_status launch_keyswitch(spf_ctx* c, hipStream_t s, size_t B, const uint64_t*
 bool params_generic(const spf_params& p, std::string& why)
 {
     const uint32_t N = p.polynomial_degree;
-    if (N < 16 || N > 1024 || (N & (N - 1))) {
-        why = "polynomial_degree must be 2048 (specialised kernels) or a power of two in 16 .. 1024 (generic kernels)";
+    if (N < 16 || N > 2048 || (N & (N - 1))) {
+        why = "polynomial_degree must be a power of two in 16 .. 2048";
         return false;
     }
     if (p.glwe_size == 0 || p.glwe_size > 8) { why = "glwe_size must be in 1 .. 8"; return false; }
@@ -497,7 +498,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     std::string why, why_generic;
     const bool specialised = params_supported(*params, why);
     if (!specialised && !params_generic(*params, why_generic))
-        return fail(nullptr, SPF_ERR_UNSUPPORTED, params->polynomial_degree == kN ? why : why_generic);
+        return fail(nullptr, SPF_ERR_UNSUPPORTED, why_generic);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, SPF_ERR_HIP, "no HIP device visible: the HIP path is the only path, there is no CPU fallback");

@@ -44,15 +44,19 @@ def test_unsupported_params_rejected(lib):
     import ctypes as C
     p = _ffi._CParams()
     lib.spf_default_params(p)
-    p.polynomial_degree = 4096           # neither the specialised kernels (2048) nor the generic ones (16 .. 1024)
+    p.polynomial_degree = 4096           # beyond the tuned kernels (2048) and the generic ones (16 .. 2048)
     h = C.c_void_p()
     st = lib.spf_create(p, 0, h)
     assert st == 4 and not h.value
     assert b"2048" in lib.spf_last_error(None)
     lib.spf_default_params(p)
-    p.pbs_radix_log, p.pbs_radix_count = 4, 3   # N = 2048 with another radix: DAG-I kernels are built for 2 x 16 only
+    p.glwe_size = 3                      # (k+1) polynomials of degree 2048 do not fit the generic kernels' LDS
     st = lib.spf_create(p, 0, h)
-    assert st == 4 and not h.value and b"2 x 16" in lib.spf_last_error(None)
+    assert st == 4 and not h.value and b"LDS" in lib.spf_last_error(None)
+    lib.spf_default_params(p)
+    p.pbs_radix_log, p.pbs_radix_count = 16, 4   # l * log B must stay below 64
+    st = lib.spf_create(p, 0, h)
+    assert st == 4 and not h.value
 
 
 def test_no_gpu_means_loud_failure():

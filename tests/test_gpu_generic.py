@@ -212,4 +212,35 @@ def test_generic_contexts_say_what_they_do_not_do():
     with pytest.raises(spf_amd.SpfError):
         spf_amd.Engine(P.replace(polynomial_degree=96))        # not a power of two
     with pytest.raises(spf_amd.SpfError):
-        spf_amd.Engine(spf_amd.DEFAULT_128.replace(pbs_radix_log=4, pbs_radix_count=3))   # N = 2048 needs the DAG-I kernels' radix
+        spf_amd.Engine(spf_amd.DEFAULT_128.replace(glwe_size=3))   # does not fit the generic kernels' LDS
+
+
+def test_n2048_with_another_radix_runs_dag1_in_the_generic_family():
+    """`can_generalized_bootstrap` (programmable_bootstrapping.rs:925-990) runs TEST_RADIX = 3 x 4 bits at N = 2048: outside the
+    tuned kernels (2 x 16).  The generic family carries DAG-I in array form, so the words are the ones the tuned kernels and the
+    oracle define: PBS, CMUX, trace, scheme switch and the whole circuit bootstrap against the oracle, and the SAME batch through
+    a tuned context where the parameters allow (CMUX at cbs 4 x 4 is radix-independent of the PBS)."""
+    P = O.DEFAULT_128.replace(lwe_n=3, pbs_radix_log=4, pbs_count=3, tr_radix_log=6, tr_count=7, ss_radix_log=5, ss_count=9)
+    ks = O.gen_keyset(0x5EED000A, P)
+    r = O.Rng(0x7A13)
+    ak = O.gen_auto_key_fft(r, ks.glwe_sk, P)
+    ssk = O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng = spf_amd.Engine(_eng_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    B = 3
+    lwe = random_lwe_batch(0x7C00, B, P.lwe_n)
+    lut = random_glwe(0x7C01, 1, P.glwe_len)[0]
+    got = eng.generalized_pbs(lwe, lut, 0, 1, 0)
+    assert eng.last_blind_rotate_kernel() == "generic_pbs_kernel"
+    for i in range(B):
+        assert np.array_equal(got[i], O.generalized_pbs(lwe[i], lut, ks.bsk_fft, P, 0, 1)), i
+    cb = eng.circuit_bootstrap(lwe[:2])
+    for i in range(2):
+        assert np.array_equal(cb[i].view(np.float64), O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P).view(np.float64)), i
+    # the generic CMUX against the tuned one: same selector, same operands, same words
+    tuned = spf_amd.Engine(spf_amd.DEFAULT_128.replace(lwe_dimension=3))
+    a, b = random_glwe(0x7C02, 2, P.glwe_len), random_glwe(0x7C03, 2, P.glwe_len)
+    assert np.array_equal(eng.cmux(cb, a, b), tuned.cmux(cb, a, b))
+    assert eng.last_cmux_kernel() == "generic_cmux_kernel" and tuned.last_cmux_kernel().startswith("cmux")
