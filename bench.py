@@ -41,6 +41,23 @@ TRACE_FLOP_PER_CT = 4 * 11 * (8 * 51200 + 12 * 8192 + 6 * 6144 + 2 * 8192)
 SCHEME_SWITCH_FLOP_PER_CT = 4 * (19 * 51200 + 30 * 8192 + 17 * 6144 + 2 * 8192)
 
 
+class _stdout_to_stderr:
+    """librccl prints a version banner on stdout when a communicator is created; this script's stdout is ONE JSON line.  Routes the
+    process's file descriptor 1 to stderr for the duration (C-level prints included)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _host_cpus():
     """CPUs this process can actually run on at once: (min(affinity mask, cgroup CFS quota), CPUs visible, quota in CPUs or
     None).  The GPU box shows 256 CPUs and grants 16 through cpu.max: threads beyond the quota only take turns."""
@@ -387,6 +404,7 @@ def main() -> int:
         mul32 = leg("mul32_gate_pool", lambda: _bench_mul32_pool(eng, P, rank, world))
     cmux = leg("cmux", _cmux) if args.with_cmux else None
     evpool = leg("evaluation_pool", lambda: _bench_evaluation_pool(eng, P, dev, torch)) if (extras and rank == 0) else None
+    devgroup = leg("device_group", lambda: _bench_device_group(P, local_dev, lwe0, blobs, torch)) if (extras and rank == 0 and world == 1) else None
     leg("restore", restore_headline_output)
 
     # one collective for all legs: MAX of the per-rank seconds (inf where a rank failed)
@@ -537,6 +555,8 @@ def main() -> int:
             line["circuit_bootstrap"] = cbs
         if evpool:
             line["evaluation_pool"] = evpool
+        if devgroup:
+            line["device_group"] = devgroup
         if add32:
             line["add32"] = add32
         if mul8:
@@ -597,7 +617,8 @@ def _single_process_main(args) -> int:
         for which in (0, 1, 2, 3):
             members[0].key_blob_commit(which)
     t_rep0 = time.perf_counter()
-    grp.replicate_keys()
+    with _stdout_to_stderr():
+        grp.replicate_keys()
     t_rep = time.perf_counter() - t_rep0
     rep = grp.replication_stats()
 
@@ -777,6 +798,52 @@ def _live_counters(kernel_name, B, kernel_ms, n_cu, budget_s=150.0):
         out["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]
         out["SQ_LDS_BANK_CONFLICT"] = c["SQ_LDS_BANK_CONFLICT"]
     return out
+
+
+def _bench_device_group(P, device, lwe0, blobs, torch, batch=2048):
+    """The multi-GPU boundary on the box at hand (include/spf_hip.h `spf_group_*`): ONE host process, a group of two
+    members on this one GPU — keys uploaded once from the host and replicated INSIDE the library (a one-rank RCCL communicator +
+    in-place broadcast, device-to-device copy for the second member), one host batch cut into two contiguous ranges, each on its
+    member's thread and stream, results reassembled.  A rehearsal of the mechanism, not a scaling measurement: both members
+    share this GPU's CUs.  Reports the replication record and the host-pointer group call against the single context."""
+    import spf_amd
+    keys_host = [b.cpu().numpy() for b in blobs]
+    grp = spf_amd.Group(P, devices=[device, device])
+    try:
+        t0 = time.perf_counter()
+        with _stdout_to_stderr():
+            grp.load_bootstrap_key(keys_host[0].view(np.complex128))
+            grp.load_keyswitch_key(keys_host[1].view(np.uint64))
+            grp.load_automorphism_key(keys_host[2].view(np.complex128))
+            grp.load_scheme_switch_key(keys_host[3].view(np.complex128))
+        t_load = time.perf_counter() - t0
+        rep = grp.replication_stats()
+        B = min(batch, lwe0.shape[0])
+        lwe_h = lwe0[:B].cpu().numpy().view(np.uint64)
+        out_g = np.zeros((B, P.glwe_words), dtype=np.uint64)
+        grp.circuit_bootstrap_pbs(lwe_h, out=out_g)
+        t0 = time.perf_counter()
+        grp.circuit_bootstrap_pbs(lwe_h, out=out_g)
+        t_g = time.perf_counter() - t0
+        one = grp.member(0)
+        out_1 = np.zeros_like(out_g)
+        one.circuit_bootstrap_pbs(lwe_h, out=out_1)
+        t0 = time.perf_counter()
+        one.circuit_bootstrap_pbs(lwe_h, out=out_1)
+        t_1 = time.perf_counter() - t0
+        # a member drained and re-admitted: the split follows the rotation, the words do not change
+        grp.set_member_enabled(1, False)
+        out_d = np.zeros_like(out_g)
+        grp.circuit_bootstrap_pbs(lwe_h[:64], out=out_d[:64])
+        grp.set_member_enabled(1, True)
+        return {"members": 2, "devices": [device, device], "transport": rep["transport"], "rccl_world_size": rep["rccl_world_size"],
+                "key_bytes_replicated_per_member": rep["bytes_per_member"], "replication_wire_s": round(rep["wire_seconds"], 4),
+                "rccl_comm_init_s": round(rep["comm_init_seconds"], 3), "load_and_replicate_s": round(t_load, 3),
+                "batch": B, "group_ms_per_batch": round(t_g * 1e3, 3), "single_context_ms_per_batch": round(t_1 * 1e3, 3),
+                "same_words_as_single_context": bool(np.array_equal(out_g, out_1) and np.array_equal(out_d[:64], out_1[:64])),
+                "note": "two members on ONE GPU share its CUs: a rehearsal of replication / split / reassembly, not a scaling figure"}
+    finally:
+        grp.close()
 
 
 def _bench_evaluation_pool(eng, P, dev, torch, thread_counts=(64, 256, 1024), seconds=2.5):

@@ -202,3 +202,88 @@ def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
         for i in check:
             assert np.array_equal(outs[i], vals[i]), f"graph case {case} (seed {SEED + 2}): node {i} of {len(val_nodes)}"
         g.close()
+
+
+def test_random_parameter_sets_through_the_generic_family():
+    """Random parameter sets outside the tuned kernels (N = 16 .. 1024, k = 1 .. 3, random radices and LWE dimension) and the
+    N = 2048 sets with another PBS radix: a random entry point of the generic family per case — generalized / univariate /
+    circuit-bootstrap PBS, CMUX, keyswitch, trace, scheme switch, whole circuit bootstrap — every checked word against the oracle."""
+    rng = np.random.default_rng(SEED + 3)
+    for case in range(max(4, CASES // 2)):
+        if rng.random() < 0.2:
+            N, k = 2048, 1
+        else:
+            N, k = int(rng.choice((16, 32, 64, 128, 256, 512, 1024))), int(rng.integers(1, 4))
+        if (k + 1) * N > 4096:      # keeps the oracle fast and the polynomials inside one CU's LDS
+            k = 1
+
+        def radix(max_bits=40):
+            lg = int(rng.integers(1, 17))
+            return lg, int(rng.integers(1, max(2, min(8, max_bits // lg) + 1)))
+        pl, pc = radix()
+        if N == 2048 and (pl, pc) == (16, 2):
+            pl, pc = 8, 3
+        cl, cc = radix(24)
+        cc = min(cc, 7)
+        tl, tc = radix()
+        sl, sc = radix()
+        kl = int(rng.integers(1, 9))
+        kc = int(rng.integers(1, max(2, 32 // kl + 1)))
+        n = int(rng.integers(1, 9))
+        P = O.DEFAULT_128.replace(lwe_n=n, N=N, k=k, pbs_radix_log=pl, pbs_count=pc, cbs_radix_log=cl, cbs_count=cc,
+                                  ks_radix_log=kl, ks_count=kc, tr_radix_log=tl, tr_count=tc, ss_radix_log=sl, ss_count=sc)
+        tag = f"case {case} (seed {SEED + 3}): N={N} k={k} n={n} pbs={pc}x{pl} cbs={cc}x{cl} ks={kc}x{kl} tr={tc}x{tl} ss={sc}x{sl}"
+        ks = O.gen_keyset(int(rng.integers(1 << 30)), P)
+        r = O.Rng(int(rng.integers(1 << 30)))
+        ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+        EP = to_engine_params(P).replace(tr_radix_log=tl, tr_radix_count=tc, ss_radix_log=sl, ss_radix_count=sc)
+        eng = spf_amd.Engine(EP)
+        eng.load_bootstrap_key(ks.bsk_fft)
+        eng.load_keyswitch_key(ks.ksk)
+        eng.load_automorphism_key(ak)
+        eng.load_scheme_switch_key(ssk)
+        B = int(rng.integers(1, 7))
+        kind = int(rng.integers(0, 7))
+        lwe = rng.integers(0, 1 << 64, size=(B, n + 1), dtype=np.uint64)
+        if kind == 0:
+            lut = random_glwe(int(rng.integers(1 << 30)), B, P.glwe_len)
+            log_chi, log_v = int(rng.integers(0, 4)), int(rng.integers(0, min(4, N.bit_length() - 1)))
+            got = eng.generalized_pbs(lwe, lut, log_chi, log_v, 0)
+            for i in range(B):
+                assert np.array_equal(got[i], O.generalized_pbs(lwe[i], lut[i], ks.bsk_fft, P, log_chi, log_v)), (tag, kind, i)
+        elif kind == 1:
+            lut = random_glwe(int(rng.integers(1 << 30)), 1, P.glwe_len)[0]
+            got = eng.pbs_univariate(lwe, lut)
+            for i in range(B):
+                assert np.array_equal(got[i], O.pbs_univariate(lwe[i], lut, ks.bsk_fft, P)), (tag, kind, i)
+        elif kind == 2:
+            got = eng.circuit_bootstrap_pbs(lwe)
+            for i in range(B):
+                assert np.array_equal(got[i], O.cbs_pbs(lwe[i], ks.bsk_fft, P)), (tag, kind, i)
+        elif kind == 3:
+            n_c = (k + 1) * cc * (k + 1) * (N // 2)
+            g = ((rng.standard_normal((B, n_c)) + 1j * rng.standard_normal((B, n_c))) * 2.0 ** 55).astype(np.complex128)
+            a = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            b = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            got = eng.cmux(g, a, b)
+            for i in range(B):
+                assert np.array_equal(got[i], O.cmux(a[i], b[i], g[i], N, k, cl, cc)), (tag, kind, i)
+        elif kind == 4:
+            lwe1 = rng.integers(0, 1 << 64, size=(B, k * N + 1), dtype=np.uint64)
+            got = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+            for i in range(B):
+                assert np.array_equal(got[i], O.keyswitch_lwe(lwe1[i], ks.ksk, k * N, n, kl, kc)), (tag, kind, i)
+        elif kind == 5:
+            glwe = rng.integers(0, 1 << 64, size=(B, P.glwe_len), dtype=np.uint64)
+            got = eng.mod_switch_trace_and_rotate(glwe)
+            glev = rng.integers(0, 1 << 64, size=(B, cc, P.glwe_len), dtype=np.uint64)
+            gg = eng.scheme_switch(glev)
+            for i in range(B):
+                assert np.array_equal(got[i], O.mod_switch_trace_and_rotate(glwe[i], ak, P)), (tag, kind, i)
+                assert np.array_equal(gg[i].view(np.float64), O.scheme_switch_fft(glev[i], ssk, P).view(np.float64)), (tag, kind, i)
+        else:
+            got = eng.circuit_bootstrap(lwe[:2])
+            for i in range(min(B, 2)):
+                exp = O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P)
+                assert np.array_equal(got[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), (tag, kind, i)
+        eng.close()
