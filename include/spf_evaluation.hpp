@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace spf {
 
@@ -33,23 +34,27 @@ struct ComputeKey {
     size_t ss_key_complex = 0;
 };
 
+// One `Evaluation` per process, shared by every worker thread, as in the reference — and it owns EVERY listed GPU: a device
+// group (spf_group_*) with the keys replicated inside the library; a batch is cut over the devices, B = 1 lands on the first one.
 class Evaluation {
   public:
-    // Evaluation::new (evaluation.rs:161-197)
-    Evaluation(const ComputeKey& key, const spf_params& params, int device = 0) : params_(params)
+    // Evaluation::new (evaluation.rs:161-197) over the listed devices (a device may repeat: that many contexts on it)
+    Evaluation(const ComputeKey& key, const spf_params& params, const std::vector<int>& devices) : params_(params)
     {
-        check(spf_create(&params, device, &ctx_), nullptr);
-        try { // a throw from here on would skip the destructor: release the context (keys in HBM, stream) first
-            check(spf_load_bootstrap_key(ctx_, key.bs_key, key.bs_key_complex), ctx_);
-            if (key.ks_key) check(spf_load_keyswitch_key(ctx_, key.ks_key, key.ks_key_words), ctx_);
-            if (key.auto_key) check(spf_load_automorphism_key(ctx_, key.auto_key, key.auto_key_complex), ctx_);
-            if (key.ss_key) check(spf_load_scheme_switch_key(ctx_, key.ss_key, key.ss_key_complex), ctx_);
+        check_create(spf_group_create(&params, devices.data(), (int)devices.size(), &grp_));
+        ctx_ = spf_group_ctx(grp_, 0);
+        try { // a throw from here on would skip the destructor: release the group (keys in HBM, streams, threads) first
+            check(spf_group_load_bootstrap_key(grp_, key.bs_key, key.bs_key_complex));
+            if (key.ks_key) check(spf_group_load_keyswitch_key(grp_, key.ks_key, key.ks_key_words));
+            if (key.auto_key) check(spf_group_load_automorphism_key(grp_, key.auto_key, key.auto_key_complex));
+            if (key.ss_key) check(spf_group_load_scheme_switch_key(grp_, key.ss_key, key.ss_key_complex));
         } catch (...) {
-            spf_destroy(ctx_);
-            ctx_ = nullptr;
+            spf_group_destroy(grp_);
+            grp_ = nullptr;
             throw;
         }
     }
+    Evaluation(const ComputeKey& key, const spf_params& params, int device = 0) : Evaluation(key, params, std::vector<int>{device}) {}
     // Evaluation::with_default_params (evaluation.rs:200-204)
     static Evaluation with_default_params(const ComputeKey& key, int device = 0)
     {
@@ -57,15 +62,17 @@ class Evaluation {
         spf_default_params(&p);
         return Evaluation(key, p, device);
     }
-    Evaluation(Evaluation&& o) noexcept : ctx_(o.ctx_), params_(o.params_) { o.ctx_ = nullptr; }
+    Evaluation(Evaluation&& o) noexcept : grp_(o.grp_), ctx_(o.ctx_), params_(o.params_) { o.grp_ = nullptr; o.ctx_ = nullptr; }
     Evaluation(const Evaluation&) = delete;
     Evaluation& operator=(const Evaluation&) = delete;
-    ~Evaluation() { spf_destroy(ctx_); }
+    ~Evaluation() { spf_group_destroy(grp_); }
+    int devices() const { return spf_group_size(grp_); }
+    spf_group* group() const { return grp_; }
 
     // Evaluation::l1ggsw_zero / l1ggsw_one (:254-262): the circuit bootstraps of the trivial L0 LWE of 0 / 1 that
     // Evaluation::new precomputes (:161-197); here made on the GPU at first use and cached in HBM per key set
-    void l1ggsw_zero(double* ggsw_fft_out) const { check(spf_l1ggsw_constant(ctx_, 0, ggsw_fft_out), ctx_); }
-    void l1ggsw_one(double* ggsw_fft_out) const { check(spf_l1ggsw_constant(ctx_, 1, ggsw_fft_out), ctx_); }
+    void l1ggsw_zero(double* ggsw_fft_out) const { check(spf_group_l1ggsw_constant(grp_, 0, ggsw_fft_out)); }
+    void l1ggsw_one(double* ggsw_fft_out) const { check(spf_group_l1ggsw_constant(grp_, 1, ggsw_fft_out)); }
 
     const spf_params& params() const { return params_; }
     spf_ctx* raw() const { return ctx_; }
@@ -73,84 +80,93 @@ class Evaluation {
     // KeylessEvaluation::not(&mut L1GlweCiphertext, &L1GlweCiphertext) (:48); `not`/`xor` are C++ tokens
     void not_(uint64_t* output, const uint64_t* input, size_t B = 1)
     {
-        check(spf_glwe_not_batch(ctx_, B, input, output), ctx_);
+        check(spf_group_glwe_not_batch(grp_, B, input, output));
     }
     // KeylessEvaluation::xor(&mut L1GlweCiphertext, a, b) (:53)
     void xor_(uint64_t* output, const uint64_t* a, const uint64_t* b, size_t B = 1)
     {
-        check(spf_glwe_xor_batch(ctx_, B, a, b, output), ctx_);
+        check(spf_group_glwe_xor_batch(grp_, B, a, b, output));
     }
     // KeylessEvaluation::mul_xn(&mut L1GlweCiphertext, &L1GlweCiphertext, n) (:58)
     void mul_xn(uint64_t* output, const uint64_t* input, size_t n, size_t B = 1)
     {
-        check(spf_glwe_mul_xn_batch(ctx_, B, input, n, output), ctx_);
+        check(spf_group_glwe_mul_xn_batch(grp_, B, input, n, output));
     }
     // KeylessEvaluation::sample_extract_l1(&mut L1LweCiphertext, &L1GlweCiphertext, idx) (:126)
     void sample_extract_l1(uint64_t* output, const uint64_t* input, size_t idx, size_t B = 1)
     {
-        check(spf_sample_extract_l1_batch(ctx_, B, input, idx, output), ctx_);
+        check(spf_group_sample_extract_l1_batch(grp_, B, input, idx, output));
     }
     // Evaluation::keyswitch_lwe_l1_lwe_l0(&mut L0LweCiphertext, &L1LweCiphertext) (:246)
     void keyswitch_lwe_l1_lwe_l0(uint64_t* output, const uint64_t* input, size_t B = 1)
     {
-        check(spf_keyswitch_lwe_l1_lwe_l0_batch(ctx_, B, input, output), ctx_);
+        check(spf_group_keyswitch_lwe_l1_lwe_l0_batch(grp_, B, input, output));
     }
     // Evaluation::circuit_bootstrap(&mut L1GgswCiphertext, &L0LweCiphertext) (:211)
     void circuit_bootstrap(double* output_ggsw_fft, const uint64_t* input_l0, size_t B = 1)
     {
-        check(spf_circuit_bootstrap_batch(ctx_, B, input_l0, output_ggsw_fft), ctx_);
+        check(spf_group_circuit_bootstrap_batch(grp_, B, input_l0, output_ggsw_fft));
     }
     // Evaluation::scheme_switch(&mut L1GgswCiphertext, &L1GlevCiphertext) (:231)
     void scheme_switch(double* output_ggsw_fft, const uint64_t* input_glev, size_t B = 1)
     {
-        check(spf_scheme_switch_batch(ctx_, B, input_glev, output_ggsw_fft), ctx_);
+        check(spf_group_scheme_switch_batch(grp_, B, input_glev, output_ggsw_fft));
     }
     // bootstrap stage of Evaluation::circuit_bootstrap (:211) = hi_noise_lwe_to_lo_noise_glwe
     void circuit_bootstrap_pbs(uint64_t* output_glwe, const uint64_t* input_l0, size_t B = 1)
     {
-        check(spf_circuit_bootstrap_pbs_batch(ctx_, B, input_l0, output_glwe), ctx_);
+        check(spf_group_circuit_bootstrap_pbs_batch(grp_, B, input_l0, output_glwe));
     }
     // sunscreen_tfhe::ops::bootstrapping::programmable_bootstrap_univariate
     void programmable_bootstrap_univariate(uint64_t* output_l1, const uint64_t* input_l0,
                                            const uint64_t* lut_glwe, size_t B = 1, size_t lut_stride = 0)
     {
-        check(spf_pbs_univariate_batch(ctx_, B, input_l0, lut_glwe, lut_stride, output_l1), ctx_);
+        check(spf_group_pbs_univariate_batch(grp_, B, input_l0, lut_glwe, lut_stride, output_l1));
     }
     // sunscreen_tfhe::ops::bootstrapping::generalized_programmable_bootstrap
     void generalized_programmable_bootstrap(uint64_t* output_glwe, const uint64_t* input_l0,
                                             const uint64_t* lut_glwe, uint32_t log_chi, uint32_t log_v,
                                             size_t B = 1, size_t lut_stride = 0)
     {
-        check(spf_generalized_pbs_batch(ctx_, B, input_l0, lut_glwe, lut_stride, log_chi, log_v, 0, output_glwe), ctx_);
+        check(spf_group_generalized_pbs_batch(grp_, B, input_l0, lut_glwe, lut_stride, log_chi, log_v, 0, output_glwe));
     }
     // KeylessEvaluation::cmux(&mut L1GlweCiphertext, &L1GgswCiphertext, a, b) (:68)
     void cmux(uint64_t* output, const double* sel_ggsw_fft, const uint64_t* a, const uint64_t* b, size_t B = 1)
     {
-        check(spf_cmux_batch(ctx_, B, sel_ggsw_fft, a, b, output), ctx_);
+        check(spf_group_cmux_batch(grp_, B, sel_ggsw_fft, a, b, output));
     }
     // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, fused on device
     void gate_bootstrap(uint64_t* output_glwe, const uint64_t* input_l1, size_t B = 1)
     {
-        check(spf_gate_bootstrap_batch(ctx_, B, input_l1, output_glwe), ctx_);
+        check(spf_group_gate_bootstrap_batch(grp_, B, input_l1, output_glwe));
     }
 
     // KeylessEvaluation::glev_cmux (:86), multiply_glwe_ggsw (:104)
     void glev_cmux(uint64_t* output, const double* sel_ggsw_fft, const uint64_t* a, const uint64_t* b, size_t B = 1)
     {
-        check(spf_glev_cmux_batch(ctx_, B, sel_ggsw_fft, a, b, output), ctx_);
+        check(spf_group_glev_cmux_batch(grp_, B, sel_ggsw_fft, a, b, output));
     }
     void multiply_glwe_ggsw(uint64_t* output, const uint64_t* glwe, const double* ggsw_fft, size_t B = 1)
     {
-        check(spf_multiply_glwe_ggsw_batch(ctx_, B, glwe, ggsw_fft, output), ctx_);
+        check(spf_group_multiply_glwe_ggsw_batch(grp_, B, glwe, ggsw_fft, output));
     }
 
   private:
     friend class FheCircuit;
+    void check(spf_status s) const
+    {
+        if (s != SPF_OK) throw Error(s, spf_group_last_error(grp_));
+    }
+    static void check_create(spf_status s)
+    {
+        if (s != SPF_OK) throw Error(s, spf_last_error(nullptr));
+    }
     static void check(spf_status s, const spf_ctx* c)
     {
         if (s != SPF_OK) throw Error(s, spf_last_error(c));
     }
-    spf_ctx* ctx_ = nullptr;
+    spf_group* grp_ = nullptr;
+    spf_ctx* ctx_ = nullptr; // member 0: gate graphs and the device-pointer forms address one device
     spf_params params_;
 };
 

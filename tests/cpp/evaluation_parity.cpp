@@ -128,6 +128,18 @@ int main()
         }
         expect(same(gout, gref), "FheCircuit: SE -> KS -> CBS -> CMux(sel, a, Not(b))");
 
+        // one Evaluation over a device group (two contexts on GPU 0: key replication inside the library, the batch cut in two)
+        {
+            spf::Evaluation ev2(key, p, std::vector<int>{0, 0});
+            const size_t B = 5;
+            std::vector<uint64_t> l1b(B * (k * N + 1)), g1(B * (k + 1) * N), g2(B * (k + 1) * N);
+            for (size_t i = 0; i < B; i++)
+                spfo_encrypt_lwe(&r, l1b.data() + i * (k * N + 1), glwe_sk.data(), k * N, spfo_encode(i & 1, 1), glwe_std);
+            ev.gate_bootstrap(g1.data(), l1b.data(), B);
+            ev2.gate_bootstrap(g2.data(), l1b.data(), B);
+            expect(ev2.devices() == 2 && same(g1, g2), "Evaluation over a device group [0, 0]: same words as one device");
+        }
+
         // malformed graph: wrong operand type must throw when the node is added (task.rs:26-31)
         bool threw = false;
         try { g.op(SPF_OP_CIRCUIT_BOOTSTRAP, {ia}); } catch (const spf::Error&) { threw = true; }

@@ -4,6 +4,7 @@
 # usage: bash tools/gpu_ab_libs.sh <tag> <lib.so> ...      (MODES="pbs pbsu" BATCH=4096 REPS=5 by default)
 set -o pipefail
 TAG=$1; shift
+mkdir -p gpurun_out
 LOG=gpurun_out/abl_$TAG.log
 : > $LOG
 for L in "$@"; do

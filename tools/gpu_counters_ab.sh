@@ -6,6 +6,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 2 --warmup 1 --batch 4096 --no-cpu-baseline --no-extras --no-live-counters ${BENCH_EXTRA:-}"
 export KFILTER=${KFILTER:-blind_rotate}
+mkdir -p gpurun_out
 LOG=gpurun_out/cnt_$TAG.log
 : > $LOG
 for V in "$@"; do

@@ -3,6 +3,7 @@
 # graph and one 32 x 32 multiplication graph.  usage: bash tools/gpu_lat_ab.sh <tag> <lib.so> ...
 set -o pipefail
 TAG=$1; shift
+mkdir -p gpurun_out
 LOG=gpurun_out/lat_$TAG.log
 : > $LOG
 for L in "$@"; do

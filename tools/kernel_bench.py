@@ -40,6 +40,7 @@ def key(which, scale):
         t.copy_(rnd_i64(nbytes // 8).view(torch.uint8))
     else:
         t.copy_((torch.randn(nbytes // 8, generator=g, device=dev, dtype=torch.float64) * scale).view(torch.uint8))
+    torch.cuda.synchronize()  # the blob was filled on torch's stream (spf_key_blob_commit also waits for the device since r05)
     eng.key_blob_commit(which)
 
 

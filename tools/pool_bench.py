@@ -24,6 +24,7 @@ for which in range(4):
         t.copy_(torch.randint(-(2 ** 63), 2 ** 63 - 1, (nbytes // 8,), generator=g, device=dev, dtype=torch.int64).view(torch.uint8))
     else:
         t.copy_((torch.randn(nbytes // 8, generator=g, device=dev, dtype=torch.float64) * 2.0 ** 67).view(torch.uint8))
+    torch.cuda.synchronize()  # the blob was filled on torch's stream (spf_key_blob_commit also waits for the device since r05)
     eng.key_blob_commit(which)
 threads = tuple(int(x) for x in sys.argv[1:]) or (64, 256, 1024)
 print(json.dumps(bench._bench_evaluation_pool(eng, P, dev, torch, thread_counts=threads)))

@@ -1,7 +1,7 @@
 import subprocess, sys, os, itertools
 which = sys.argv[1]           # EVEN or MIX
 base = sys.argv[2]            # current schedule string
-os.chdir('/root/repo')
+os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # the repository root, wherever the checkout lives
 variants = []
 for i in range(20):
     for ch in '-01':
