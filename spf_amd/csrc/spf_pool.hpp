@@ -439,15 +439,19 @@ struct spf_pool {
 
     // `mu` held.  The callers blocked in the pool right now (open tickets) stand for the population that keeps coming back.
     size_t population() const { return tickets.size(); }
-    // Caller groups in use.  Measured (tools/pool_bench.py, fraction of the device-resident rate at 64 / 256 / 1 024 callers):
-    // two groups 0.91 / 0.71 / 0.73, three 0.94 / 0.76 / 0.75, four 0.88 / 0.79 / 0.69, six 0.79 / 0.67 / 0.63 (r04, one group at
-    // a time: 0.83 / 0.72 / 0.72).  Four groups while the population fits the chip at two ciphertexts per CU; beyond that the
-    // bootstraps of the resident batches subscribe every CU (four per CU) and a fourth group only queues its keyswitch, trace and
-    // copy kernels behind them: three.
+    // Caller groups in use.  Measured (tools/pool_bench.py, fraction of the device-resident rate; profiles/r05_pool.md):
+    //   callers      32    64    128   256   384   512   768   1024  1536  2048
+    //   2 groups    0.88  0.91  0.77  0.71  0.81  0.67  0.77  0.73  0.88  0.53
+    //   3 groups    0.96  0.94  0.88  0.76  0.84  0.77  0.81  0.75  0.87  0.58
+    //   4 groups    0.93  0.88  0.89  0.79  0.85  0.79  0.82  0.69  0.85  0.65     (6: 0.79 / 0.67 / 0.63, 8: 0.68 / 0.68 / 0.60 at 64 / 256 / 1024)
+    // Four groups, except around the population that exactly fills the chip at four ciphertexts per CU (1 024 on 256 CUs): there
+    // the bootstraps of four resident batches subscribe every CU and each group's keyswitch, trace and copy kernels queue behind
+    // them — three groups leave the fourth quarter of the callers in their host phase.
     size_t groups_now() const
     {
         if (groups) return groups;
-        return population() > 2 * (size_t)ctx->n_cu ? 3 : 4;
+        const size_t pop = population(), n_cu = (size_t)ctx->n_cu;
+        return (2 * pop > 7 * n_cu && pop <= 6 * n_cu) ? 3 : 4;
     }
     // ciphertexts per workgroup the bootstrap of a batch should use at least: the shape the whole population would get in one
     // launch, so that the resident batches tile the CUs (one batch of a quarter of 1 024 callers takes 64 CUs, not 256)
