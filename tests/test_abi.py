@@ -67,6 +67,27 @@ def test_no_gpu_means_loud_failure():
         spf_amd.Engine()
 
 
+def test_group_entry_points_validate_before_touching_a_device(lib):
+    """spf_group_*: null / empty arguments are refused with a message, and without a GPU creation fails loudly (no fallback)."""
+    import ctypes as C
+    from tests.util import gpu_available
+    p = _ffi._CParams()
+    lib.spf_default_params(p)
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.spf_group_create(p, ids, 0, h) == 1 and not h.value          # no devices
+    assert lib.spf_group_create(p, None, 2, h) == 1 and not h.value         # null list
+    assert b"n_devices" in lib.spf_last_error(None)
+    assert lib.spf_group_size(None) == 0 and lib.spf_group_ctx(None, 0) is None
+    assert lib.spf_group_replicate_keys(None) == 1
+    assert lib.spf_group_gate_bootstrap_batch(None, 1, None, None) == 1
+    if not gpu_available():
+        st = lib.spf_group_create(p, ids, 2, h)
+        assert st == 2 and not h.value and b"no HIP device" in lib.spf_last_error(None)
+        with pytest.raises(spf_amd.SpfError):
+            spf_amd.Group(devices=[0, 0])
+
+
 def test_product_never_imports_oracle():
     # the oracle is test infrastructure: nothing under spf_amd/ may reference it
     for dirpath, _, files in os.walk(os.path.join(ROOT, "spf_amd")):
