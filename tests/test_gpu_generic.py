@@ -244,3 +244,45 @@ def test_n2048_with_another_radix_runs_dag1_in_the_generic_family():
     a, b = random_glwe(0x7C02, 2, P.glwe_len), random_glwe(0x7C03, 2, P.glwe_len)
     assert np.array_equal(eng.cmux(cb, a, b), tuned.cmux(cb, a, b))
     assert eng.last_cmux_kernel() == "generic_cmux_kernel" and tuned.last_cmux_kernel().startswith("cmux")
+
+
+def test_pool_and_group_over_a_generic_parameter_set():
+    """The host layers above the kernels are parameter-agnostic: the call-coalescing pool and a device group `[0, 0]` at
+    TEST_GLWE_DEF_1 / TEST_LWE_DEF_1 give the words of the single generic context."""
+    from concurrent.futures import ThreadPoolExecutor
+    P = TEST1.replace(lwe_n=5, tr_radix_log=7, tr_count=6, ss_radix_log=3, ss_count=15)
+    EP = _eng_params(P)
+    ks = O.gen_keyset(0x5EED000B, P)
+    r = O.Rng(0x7A14)
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng, grp = spf_amd.Engine(EP), spf_amd.Group(EP, devices=[0, 0])
+    for e in (eng, grp):
+        e.load_bootstrap_key(ks.bsk_fft)
+        e.load_keyswitch_key(ks.ksk)
+        e.load_automorphism_key(ak)
+        e.load_scheme_switch_key(ssk)
+    n = 9
+    lwe1 = random_lwe_batch(0x7D00, n, P.k * P.N)
+    a, b = random_glwe(0x7D01, n, P.glwe_len), random_glwe(0x7D02, n, P.glwe_len)
+    want_g = eng.keyswitch_circuit_bootstrap(lwe1)
+    want_m = eng.cmux(want_g, a, b)
+    assert np.array_equal(grp.keyswitch_circuit_bootstrap(lwe1).view(np.float64), want_g.view(np.float64))
+    assert np.array_equal(grp.cmux(want_g, a, b), want_m)
+    assert np.array_equal(grp.gate_bootstrap(lwe1), eng.gate_bootstrap(lwe1))
+    pool = spf_amd.Pool(eng, max_batch=16, max_wait_us=500)
+    ggsw = np.zeros((n, EP.cbs_ggsw_complex), dtype=np.complex128)
+    mux = np.zeros((n, P.glwe_len), dtype=np.uint64)
+
+    def task(i):
+        pool.keyswitch_circuit_bootstrap(ggsw[i], lwe1[i])
+        pool.cmux(mux[i], ggsw[i], a[i], b[i])
+        return i
+
+    try:
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            assert sorted(ex.map(task, range(n))) == list(range(n))
+    finally:
+        pool.close()
+        grp.close()
+    assert np.array_equal(ggsw.view(np.float64), want_g.view(np.float64))
+    assert np.array_equal(mux, want_m)
