@@ -65,7 +65,7 @@ enum Op {
     OP_SAMPLE_EXTRACT = 4, OP_NOT = 5, OP_GLWE_ADD = 6, OP_MUL_XN = 7, OP_MULTIPLY_GGSW_GLWE = 8, OP_GLEV_CMUX = 9, OP_SCHEME_SWITCH = 10,
     N_OPS = 11
 };
-constexpr int kMaxGroups = 8;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
+constexpr int kMaxGroups = 4;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
 constexpr int kSets = 2 * kMaxGroups; // per group one batch in flight / being collected and one filling
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
 
