@@ -32,8 +32,11 @@ def test_bench_line_has_the_contract_fields():
     # the kernel named is the one that ran: 512 ciphertexts (two per CU) take the two-ciphertext paired shape, not the
     # four-ciphertext throughput kernel
     assert roof["kernel"].startswith("blind_rotate2p2_kernel"), roof["kernel"]
-    for leg in ("gate", "cmux", "circuit_bootstrap", "add32", "pcie_inclusive"):
-        assert isinstance(d.get(leg), dict), leg
+    for leg in ("gate", "cmux", "circuit_bootstrap", "add32", "pcie_inclusive", "device_group", "evaluation_pool"):
+        assert isinstance(d.get(leg), dict), (leg, d.get("leg_errors"))
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]     # nothing else on stdout (librccl's banner goes to stderr)
+    grp = d["device_group"]
+    assert grp["members"] == 2 and grp["same_words_as_single_context"] is True and grp["key_bytes_replicated_per_member"] > 0
     assert d["pcie_inclusive"]["same_words_as_device_path"] is True
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     # traffic / busy fractions are this run's own rocprofv3 --pmc passes when the profiler is on the box, else the
@@ -44,7 +47,27 @@ def test_bench_line_has_the_contract_fields():
     else:
         assert "live_counters" in (d.get("leg_errors") or {}) or roof["traffic"] is None
     cpu = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "cpus_visible", "cfs_quota_cpus"):
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert cpu["cores"] <= cpu["cpus_visible"] and (cpu["cfs_quota_cpus"] is None or cpu["cores"] <= cpu["cfs_quota_cpus"] + 1)
     assert cpu["gpu_outputs_bit_equal_on_sample"] is True
+
+
+@pytest.mark.gpu
+def test_single_process_bench_line_over_a_device_group():
+    """`bench.py --gpus N --single-process`: the same line shape from ONE host process driving a device group (here two members
+    on the one GPU), keys replicated inside the library."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0",
+                        "--steps", "1", "--warmup", "1", "--batch", "256", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1, r.stdout[:500]
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "PBS/s" and d["value"] > 0
+    assert d["config"]["devices"] == [0, 0] and d["config"]["global_batch"] == 512
+    assert d["rccl"]["members"] == 2 and d["rccl"]["broadcast_bytes"] > 0 and d["rccl"]["world_size"] >= 1
+    assert d["pcie_inclusive"]["same_words_as_device_path"] is True
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key

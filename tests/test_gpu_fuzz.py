@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("SPF_FUZZ_CASES", "12"))
 SEED = int(os.environ.get("SPF_FUZZ_SEED", "20260401"))
 LWE_DIMS = (1, 3, 20)
+FULL_N = 637   # DEFAULT_128's LWE dimension: drawn now and then with a small batch (the oracle needs 64 ms per bootstrap)
 SIZES = (1, 2, 3, 7, 64, 100, 255, 256, 257, 300, 511, 512, 513, 600, 1023, 1024, 1025, 1031, 1100, 2047, 2050)
 
 
@@ -27,7 +28,7 @@ def engines():
     if not gpu_available():
         pytest.skip("needs a GPU")
     out = {}
-    for n in LWE_DIMS:
+    for n in LWE_DIMS + (FULL_N,):
         ks = keyset(0x5EED0001, n, with_ksk=False)
         eng = spf_amd.Engine(to_engine_params(ks.params))
         eng.load_bootstrap_key(ks.bsk_fft)
@@ -40,9 +41,11 @@ def test_random_bootstrap_calls_against_the_oracle(engines):
     log = []
     for case in range(CASES):
         n = int(rng.choice(LWE_DIMS))
+        B = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 1200))
+        if rng.random() < 0.04:   # a full-length blind rotation: 637 steps, every output against the oracle
+            n, B = FULL_N, int(rng.choice((1, 5, 33, 64)))
         ks, eng = engines[n]
         P = ks.params
-        B = int(rng.choice(SIZES)) if rng.random() < 0.8 else int(rng.integers(1, 1200))
         lwe = rng.integers(0, 1 << 64, size=(B, n + 1), dtype=np.uint64)
         if rng.random() < 0.3:   # identity steps, extreme words
             rows = rng.integers(0, B, size=max(1, B // 7))
