@@ -255,7 +255,7 @@ spf_status spf_multiply_glwe_ggsw_dev(spf_ctx *ctx, void *stream, size_t B, cons
  *     batch closes when it is full (max_batch, and the staging a batch may pin), when every caller of the group's previous
  *     batch is back, or when nobody has joined it for max_wait_us (stretched to an eighth of the last batch's GPU time, at most
  *     twenty such quiet times after its first member) — but not on the timer while the group's previous batch is still out.
- *     The groups' batches run on the GPU side by side, each on its own stream (DESIGN §4.8, profiles/r05_pool.md).
+ *     The groups' batches run on the GPU side by side, each on its own stream (DESIGN §4.6, profiles/r05_pool.md).
  *   Asynchronous use: a thread may hold many tickets; eight staging sets exist, so a caller that keeps more than eight batches
  *     uncollected waits in submit until a set is collected (or 200 ms old).
  *   spf_pool_wait returns the status of the batch the operation ran in (first-error-wins per batch, as
