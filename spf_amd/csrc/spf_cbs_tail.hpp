@@ -12,8 +12,15 @@
 #pragma once
 #include "spf_kernels.hpp"
 
-#ifndef SPF_TAIL_PAIR
-#define SPF_TAIL_PAIR fft512_pair1t // pass twiddles requested early, shared by the pair (r04: scheme switch 1.16 -> 1.12 ms, trace unchanged)
+// The transform pair of each tail kernel (all variants give the same words).  r05 A/B, ms per 4096, two runs each
+// (profiles/r05_kernels_summary.md): trace 4.52 / 4.57 / 4.61 / 4.72 and scheme switch 1.149 / 1.111 / 1.126 / 1.130 with
+// fft512_pair1 / pair1t / pair1ts / pair1ts2 — the trace kernel has no registers to hold a pass's twiddles across the pair
+// (44 B of scratch already), the scheme switch has.
+#ifndef SPF_TRACE_PAIR
+#define SPF_TRACE_PAIR fft512_pair1
+#endif
+#ifndef SPF_SS_PAIR
+#define SPF_SS_PAIR fft512_pair1t // pass twiddles requested early, shared by the pair (r04: 1.16 -> 1.12 ms)
 #endif
 
 namespace spf {
@@ -243,7 +250,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             if (m == 0) young_prio<0>(is_young);
             if (m == 2) young_prio<1>(is_young);
             if (m > 0) ring_dma(chunk);
-            SPF_TAIL_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
+            SPF_TRACE_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
             STAMPT(2);
             // radix-2 stage across the two waves, both digits in one exchange
             if constexpr (w == 0) {
@@ -387,7 +394,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             for (int k = 0; k < 8; k++) lds_dma_piece(src + k * 1024, lane16, dst + k * 1024);
         }
         STAMPT(7);
-        SPF_TAIL_PAIR<-1, XP>(WW[0], WW[1], mine, tab, lane);
+        SPF_TRACE_PAIR<-1, XP>(WW[0], WW[1], mine, tab, lane);
         STAMPT(8);
         {
             uint64_t t[16];
@@ -494,7 +501,7 @@ __device__ __forceinline__ void scheme_switch_body(const SchemeSwitchArgs& a, ch
     const c64* wc = tab + kWCOff + 256 * w + lane;
     // forward transform pair with the radix-2 stage across the two waves; leaves this wave's bins in VV
     auto forward_pair = [&](c64 (&VV)[2][8]) {
-        SPF_TAIL_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
+        SPF_SS_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
         if constexpr (w == 0) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
