@@ -312,18 +312,20 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
         a.stamps = d_stamps;
     }
 #endif
+#define SPF_STR2(x) #x
+#define SPF_STR(x) SPF_STR2(x)
 #define SPF_LAUNCH(NAME, KERNEL, LDS) do { c->last_pbs_kernel = NAME; hipLaunchKernelGGL(KERNEL, grid, block, LDS, s, a); } while (0)
     // log_v >= 1 makes every rotation amount even: the kernels then skip the hand-overs around the rotation gather (",even")
     if (quad && log_v == 0) SPF_LAUNCH("blind_rotate8_kernel<2,16>", (blind_rotate8_kernel<2, 16, 1>), kBlindRotate8Lds);
     else if (quad) SPF_LAUNCH("blind_rotate8_kernel<2,16,even>", (blind_rotate8_kernel<2, 16, 0>), kBlindRotate8Lds);
-    else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14>", (blind_rotate2p2_kernel<2, 16, 14, 1>), kBlindRotate2p2Lds);
-    else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16,14,even>", (blind_rotate2p2_kernel<2, 16, 14, 0>), kBlindRotate2p2Lds);
+    else if (pair2 && log_v == 0) SPF_LAUNCH("blind_rotate2p2_kernel<2,16," SPF_STR(SPF_BR2_OPT) ">", (blind_rotate2p2_kernel<2, 16, SPF_BR2_OPT, 1>), kBlindRotate2p2Lds);
+    else if (pair2) SPF_LAUNCH("blind_rotate2p2_kernel<2,16," SPF_STR(SPF_BR2_OPT) ",even>", (blind_rotate2p2_kernel<2, 16, SPF_BR2_OPT, 0>), kBlindRotate2p2Lds);
 #if SPF_TRIO_SHAPE
-    else if (trio && log_v == 0) SPF_LAUNCH("blind_rotate2p3_kernel<2,16,14>", (blind_rotate2p3_kernel<2, 16, 14, 1>), kBlindRotate2p3Lds);
-    else if (trio) SPF_LAUNCH("blind_rotate2p3_kernel<2,16,14,even>", (blind_rotate2p3_kernel<2, 16, 14, 0>), kBlindRotate2p3Lds);
+    else if (trio && log_v == 0) SPF_LAUNCH("blind_rotate2p3_kernel<2,16," SPF_STR(SPF_BR_OPT) ">", (blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 1>), kBlindRotate2p3Lds);
+    else if (trio) SPF_LAUNCH("blind_rotate2p3_kernel<2,16," SPF_STR(SPF_BR_OPT) ",even>", (blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 0>), kBlindRotate2p3Lds);
 #endif
-    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16,14>", (blind_rotate2p_kernel<2, 16, 14, 1>), kBlindRotate2pLds);
-    else SPF_LAUNCH("blind_rotate2p_kernel<2,16,14,even>", (blind_rotate2p_kernel<2, 16, 14, 0>), kBlindRotate2pLds);
+    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16," SPF_STR(SPF_BR_OPT) ">", (blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 1>), kBlindRotate2pLds);
+    else SPF_LAUNCH("blind_rotate2p_kernel<2,16," SPF_STR(SPF_BR_OPT) ",even>", (blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 0>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
     {
@@ -572,18 +574,18 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            kKsLdsBytes));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 14, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, 14, 0>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, SPF_BR2_OPT, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, 14, 0>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p2_kernel<2, 16, SPF_BR2_OPT, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p2Lds));
 #if SPF_TRIO_SHAPE
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, 14, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p3Lds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, 14, 0>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2p3Lds));
 #endif
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate8_kernel<2, 16, 1>),

@@ -133,8 +133,9 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 // OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
 // transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
-// two).  The library instantiates OPT = 14 only; the A/B numbers of the others and of
-// everything else tried on this kernel are in profiles/r02_experiments_blind_rotate.md and r03_experiments_blind_rotate.md.
+// two).  The library instantiates OPT = 6 (SPF_BR_OPT / SPF_BR2_OPT below; r03-r04 shipped 14: bit 3 was worth 0.3 ms on the
+// ten-barrier kernel and costs 0.25 ms on today's); the A/B numbers of the others are in profiles/r05_experiments_blind_rotate.md,
+// everything else tried on this kernel in profiles/r02_… and r03_experiments_blind_rotate.md.
 // Which transform pair each of the three pairs of a step uses (spf_device.hpp; all give the same words), per instantiation:
 // E = even rotations (circuit bootstrap), M = mixing (plain PBS); 0 / 1 = polynomial 0's / 1's forward pair, I = the inverse pair.
 // All share the pass twiddles between the two transforms and spread the stores through the butterflies (r04: 42.6 -> 39.9 ms
@@ -159,7 +160,10 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #define SPF_PAIR_MI fft512_pair1ts
 #endif
 #ifndef SPF_BR_OPT
-#define SPF_BR_OPT 14
+#define SPF_BR_OPT 6  // blind_rotate2p_kernel (four ciphertexts per workgroup): r05 A/B 38.73-38.79 ms per 4096 against 39.01 with 14, plain PBS 40.66-40.75 against 41.06-41.16
+#endif
+#ifndef SPF_BR2_OPT
+#define SPF_BR2_OPT 6  // blind_rotate2p2_kernel (two per workgroup): 6.87 ms per 512 against 6.96 with 14 (plain PBS 7.07 / 7.08)
 #endif
 #ifndef SPF_BSK_PRESCALED
 #define SPF_BSK_PRESCALED 1 // the device image of the bootstrap key carries the inverse transform's 1/1024 (scale_bootstrap_key_kernel)
@@ -635,8 +639,8 @@ template <int L, int LOGB, int OPT, int MIX = 1>
 __global__ __launch_bounds__(512, 2) void blind_rotate2p_kernel(BlindRotateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, SPF_BR_OPT, 1, 4, MIX>(a, smem);
-    else blind_rotate2p_body<L, LOGB, SPF_BR_OPT, 0, 4, MIX>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) blind_rotate2p_body<L, LOGB, OPT, 1, 4, MIX>(a, smem);
+    else blind_rotate2p_body<L, LOGB, OPT, 0, 4, MIX>(a, smem);
 }
 
 // The same schedule with TWO ciphertexts per workgroup (four waves, one per SIMD, one workgroup per CU): for batches

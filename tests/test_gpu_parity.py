@@ -119,8 +119,8 @@ def test_saturating_cast_quirk_is_reproduced():
 # gather hand-overs and their own ragged tail.  One launch per batch (device-pointer entry points).
 
 EDGE_BATCHES = [1030, 600, 400, 100]   # 2p ragged, 2p, 2p2, eight-wave latency shape
-_EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,14", 600: "blind_rotate2p_kernel<2,16,14",
-                400: "blind_rotate2p2_kernel<2,16,14"}
+_EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,6", 600: "blind_rotate2p_kernel<2,16,6",
+                400: "blind_rotate2p2_kernel<2,16,6"}
 
 
 def _edge_kernel(B, even):
