@@ -836,10 +836,26 @@ __device__ __forceinline__ void radix8_twr_spread(c64 (&X)[8], const c64 (&tw)[7
     for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
     sched_fence();
 }
+// XP = 0 tail of the pairs below: exchange 2 of B through the image as well, behind A's (A's exchange-2 reads are issued, a wave's
+// DS instructions execute in order, so B's stores cannot overtake them): eight stores and eight reads on the LDS pipe instead of
+// lane_transpose_hi3's 80 vector instructions — 16 v_permlane*_swap at 8.5 cycles of the SIMD each, 32 DPP moves at 4.5, 16 moves
+// (tools/microbench/valu_rates.hip): ~480 of a pair's ~5 600 vector cycles.  B's reads travel under A's last radix-8.
+template <int DIR, class ST, class LD>
+__device__ __forceinline__ void pair_tail_through_image(c64 (&A)[8], c64 (&B)[8], ST store, LD load, uint32_t rd2)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) store(B, k);
+    sched_fence();
+    load(B, rd2);
+    sched_fence();
+    radix8<DIR>(A);
+    sched_fence();
+    radix8<DIR>(B);
+}
 template <int DIR, int XP, bool EARLY, bool SPREAD, class MID = no_hook>
 __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
 {
-    static_assert(XP == 2, "exchange 2 of B in registers");
+    static_assert(XP == 2 || XP == 0, "exchange 2 of B in registers (2) or through the image behind A's (0)");
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
     const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
@@ -909,16 +925,20 @@ __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* bu
         radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
     }
     if constexpr (!EARLY || SPREAD) { load(A, rd2); sched_fence(); }
-    lane_transpose_hi3(B);
-    radix8<DIR>(A);
-    radix8<DIR>(B);
+    if constexpr (XP == 2) {
+        lane_transpose_hi3(B);
+        radix8<DIR>(A);
+        radix8<DIR>(B);
+    } else {
+        pair_tail_through_image<DIR>(A, B, store, load, rd2);
+    }
     sched_fence();
 }
 // fft512_pair1ts with each exchange's reads issued inside the other transform's pass, right behind the last spread store
 template <int DIR, int XP = 2, class MID = no_hook>
 __device__ __forceinline__ void fft512_pair1ts2(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
 {
-    static_assert(XP == 2, "exchange 2 of B in registers");
+    static_assert(XP == 2 || XP == 0, "exchange 2 of B in registers (2) or through the image behind A's (0)");
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
     const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
@@ -950,9 +970,13 @@ __device__ __forceinline__ void fft512_pair1ts2(c64 (&A)[8], c64 (&B)[8], char* 
     mid();
     // pass 2 of B: A's exchange-2 stores, then A's exchange-2 reads
     radix8_twr_spread2<DIR>(B, tw2, [&](int k) { store(A, k); }, [&]() { load(A, rd2); });
-    lane_transpose_hi3(B);
-    radix8<DIR>(A);
-    radix8<DIR>(B);
+    if constexpr (XP == 2) {
+        lane_transpose_hi3(B);
+        radix8<DIR>(A);
+        radix8<DIR>(B);
+    } else {
+        pair_tail_through_image<DIR>(A, B, store, load, rd2);
+    }
     sched_fence();
 }
 template <int DIR, int XP = 2, class MID = no_hook>
@@ -1098,6 +1122,64 @@ __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c
     }
     if constexpr (MANTISSA_FORM) torus_bits16_mantissa(tv, t);
     else torus_bits16(tv, t);
+}
+// a + (uint64_t)b as ONE v_mad_u64_u32 (b * 1 + a; 4.9 cycles of a SIMD): hipcc widens b to a register pair (a move) and adds
+// with v_lshl_add_u64, or emits a v_add_co / v_addc pair (9.8 cycles)
+__device__ __forceinline__ uint64_t add_u32_to_u64(uint64_t a, uint32_t b)
+{
+    uint64_t out, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=&v"(out), "=s"(carry) : "v"(b), "v"(a));
+    return out;
+}
+
+// NEGATED-ACCUMULATOR form of untwist_to_torus_bits + `acc += t` (blind_rotate2p_body with SPF_BR_NEG): the caller keeps
+// nacc = -acc (mod 2^64) and this does nacc -= t, i.e. nacc += (-t).  Same words as the plain form, fewer VALU cycles
+// (tools/microbench/valu_rates.hip, profiles/r05_valu_rates.md: a v_sub_co / v_subb pair costs 9.8 cycles of a SIMD, the
+// 64-bit add v_lshl_add_u64 4.8, a VOP2 32-bit operation 2.5, a VOP3 one 4.5):
+//   * the untwist product is formed NEGATED for free ((-m1) - m2 and m3 - m4 swapped: source modifiers, exact), so the
+//     integer of the negated value is what gets ADDED — no subtraction anywhere;
+//   * two's complement of the shifted magnitude bits as (r + s) ^ s with s = the sign spread over 64 bits (a 64-bit shift,
+//     a 64-bit add, two XORs) instead of (r ^ s) - s (…, a subtract pair);
+//   * the exponent window [1087, 1138] is checked on (high word << 1) — the sign leaves, one VOP2 shift instead of a VOP3
+//     bit-field extract — and the saturating-cast quirk by a running signed minimum of the results' high words (INT_MIN
+//     <=> some magnitude has the high word 0x80000000; VOP2) instead of one 64-bit compare per value.
+// The literal fall-back takes the original value (-tvn, exact) and is subtracted.
+template <bool PRESCALED>
+__device__ __forceinline__ void untwist_sub_from_negated(const c64 (&V)[8], const c64* twist_lds, uint64_t (&nacc)[16])
+{
+    double tvn[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) {
+        c64 xs = V[n1];
+        if constexpr (!PRESCALED) xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
+        const c64 tw = twist_lds[64 * n1];
+        // cmul_nf_conj negated: re = -(a.re b.re) - (a.im b.im), im = a.re b.im - a.im b.re
+        tvn[n1] = -(xs.re * tw.re) - xs.im * tw.im;
+        tvn[8 + n1] = xs.re * tw.im - xs.im * tw.re;
+    }
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    int32_t qmin = 0x7FFFFFFF;
+    uint64_t t[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint64_t b = (uint64_t)__double_as_longlong(tvn[e]);
+        const uint32_t hi = (uint32_t)(b >> 32);
+        const uint32_t k = hi << 1; // exponent field in bits 31..21, sign gone
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+        const uint64_t r = b << (((hi >> 20) + 13u) & 63u);
+        const int32_t rh = (int32_t)(uint32_t)(r >> 32);
+        qmin = rh < qmin ? rh : qmin;
+        const uint64_t sg = (uint64_t)((int64_t)b >> 63);
+        t[e] = (r + sg) ^ sg;
+    }
+    if (__all(kmin >= (1087u << 21) && kmax < (1139u << 21) && qmin != (int32_t)0x80000000)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) nacc[e] += t[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) nacc[e] -= f64_round_to_torus(-tvn[e]);
+    }
 }
 // the same with the twist factors held in registers (the latency kernels)
 __device__ __forceinline__ void untwist_to_torus_bits(const c64 (&V)[8], const c64 (&twist)[8], uint64_t (&t)[16])

@@ -177,10 +177,36 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #ifndef SPF_COMBINE_PRE
 #define SPF_COMBINE_PRE 0
 #endif
+// SPF_BR_NEG = 1: the wave keeps the NEGATED accumulator nacc = -acc (mod 2^64) in its registers and stages that.  Every 64-bit
+// subtraction of the step becomes an addition — the rotate-and-subtract `(+-acc[src]) - acc[me]` is `(+-nacc[src]) + nacc[me]`
+// with the gather's sign flipped, the rounding bit 2^31 and the +1 of the two's complement ride on ONE 32-bit addend
+// (v_mad_u64_u32), and the rounded top word is simply the high word of the sum; the torus conversion adds the integer of the
+// negated value (untwist_sub_from_negated).  hipcc emits a 9.8-cycle v_sub_co / v_subb pair for a 64-bit subtraction and a
+// 4.8-cycle v_lshl_add_u64 for an addition (tools/microbench/valu_rates.hip).  Same words: integer identities only.
+#ifndef SPF_BR_NEG
+#define SPF_BR_NEG 1
+#endif
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
     constexpr int XP = (OPT & 1) ? 1 : ((OPT & 2) ? 2 : 0);
+    // (A/B knobs: the exchange-2 choice of each of the three pairs of a step separately; default = the one OPT selects)
+#ifdef SPF_XP_F0
+    constexpr int XPF0 = SPF_XP_F0;
+#else
+    constexpr int XPF0 = XP;
+#endif
+#ifdef SPF_XP_F1
+    constexpr int XPF1 = SPF_XP_F1;
+#else
+    constexpr int XPF1 = XP;
+#endif
+#ifdef SPF_XP_I
+    constexpr int XPI = SPF_XP_I;
+#else
+    constexpr int XPI = XP;
+#endif
+    constexpr bool NEG = SPF_BR_NEG != 0;
 #ifdef SPF_STAMPS
     // per-phase wall cycles of this wave (diagnostic build; s_memtime drains lgkmcnt: ~5 % overhead)
     uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -248,7 +274,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             for (int e = 0; e < 16; e++) {
                 uint32_t idx = (uint32_t)coef2(e) + bt;
                 uint64_t v = lut[p * kN + (idx & (kN - 1))];
-                acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+                if constexpr (NEG) acc[p][e] = ((idx >> 11) & 1) ? v : (uint64_t)0 - v; // (NEG: acc[][] holds -accumulator throughout)
+                else acc[p][e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
             }
     }
     __syncthreads();
@@ -321,6 +348,8 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 // for e >= 8): region (parity) and the low address bits do not depend on e
                 const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
                 const char* region = tile + (t0 & 1) * 8192;
+                uint32_t T0 = (t0 + 2048u) << 20; // (NEG) bit 31 = complement of bit 11 of t0; opaque so that it is re-derived per polynomial
+                if constexpr (NEG) asm volatile("" : "+v"(T0));
                 uint64_t gin[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
@@ -335,9 +364,21 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
-                    const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
-                    const uint64_t rot = (gin[e] ^ sgn) - sgn;
-                                        dig[e] = gadget_round_top32(rot - acc[p][e]); // the rounded top word; its two digits are taken at the twist
+                    if constexpr (NEG) {
+                        // gin = nacc[src]; x = rot - acc[me] = (-+ nacc[src]) + nacc[me]: the sign mask m is the complement of bit 11 of t
+                        // (= bit 11 of t + 2048, brought to bit 31 once per polynomial: T0 + a literal per element);
+                        // x + 2^31 = (gin ^ m) + (nacc[me] + (2^31 + (m ? 1 : 0))), and the rounded top word is its high word.
+                        // The small pieces are pinned (opaque values, one v_mad_u64_u32): left to itself hipcc rebuilds the mask from a
+                        // bit-field extract, widens the 32-bit addend to a register pair and keeps all of it live across the transforms.
+                        const uint32_t m32 = (uint32_t)((int32_t)(T0 + (uint32_t)(((e >> 3) * 1024 + (e & 7) * 128) << 20)) >> 31);
+                        const uint64_t m = ((uint64_t)m32 << 32) | m32;
+                        uint32_t k32 = 0x80000000u - m32;
+                        dig[e] = (uint32_t)(((gin[e] ^ m) + add_u32_to_u64(acc[p][e], k32)) >> 32);
+                    } else {
+                        const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
+                        const uint64_t rot = (gin[e] ^ sgn) - sgn;
+                        dig[e] = gadget_round_top32(rot - acc[p][e]); // the rounded top word; its two digits are taken at the twist
+                    }
                 }
             }
             c64 VV[2][8];
@@ -372,11 +413,11 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             if (p == 0) SPF_PRIO_POINT(4); else SPF_PRIO_POINT(10);
             if (p == 1) ring_dma(chunk);
             if constexpr (MIX) {
-                if (p == 0) SPF_PAIR_M0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
-                else SPF_PAIR_M1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
+                if (p == 0) SPF_PAIR_M0<+1, XPF0>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
+                else SPF_PAIR_M1<+1, XPF1>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
             } else {
-                if (p == 0) SPF_PAIR_E0<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
-                else SPF_PAIR_E1<+1, XP>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
+                if (p == 0) SPF_PAIR_E0<+1, XPF0>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
+                else SPF_PAIR_E1<+1, XPF1>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
             }
             STAMP(3);
             if (p == 0) SPF_PRIO_POINT(5);
@@ -587,16 +628,20 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             SPF_PRIO_POINT(14);
             if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
-        if constexpr (MIX) SPF_PAIR_MI<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
-        else SPF_PAIR_EI<-1, XP>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+        if constexpr (MIX) SPF_PAIR_MI<-1, XPI>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+        else SPF_PAIR_EI<-1, XPI>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
         STAMP(9);
         SPF_PRIO_POINT(15);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            uint64_t t[16];
-            untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(WW[q], twist, t);
+            if constexpr (NEG) {
+                untwist_sub_from_negated<SPF_BSK_PRESCALED>(WW[q], twist, acc[q]);
+            } else {
+                uint64_t t[16];
+                untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(WW[q], twist, t);
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[q][e] += t[e];
+                for (int e = 0; e < 16; e++) acc[q][e] += t[e];
+            }
             if (q == 0) SPF_PRIO_POINT(16);
         }
         STAMP(10);
@@ -612,6 +657,12 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 
     if (!owns_output) return;
     uint64_t* out = a.out + (size_t)ct * a.out_stride;
+    if constexpr (NEG) {
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[p][e] = (uint64_t)0 - acc[p][e];
+    }
     if (!a.sample_extract) {
 #pragma unroll
         for (int p = 0; p < 2; p++)
