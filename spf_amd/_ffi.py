@@ -481,6 +481,10 @@ class Engine:
     def cmux_dev(self, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out):
         self._ck(self._lib.spf_cmux_dev(self._h, stream, B, d_sel_ggsw_fft, d_a, d_b, d_out))
 
+    def cmux_scattered_dev(self, stream, units, d_ptrs):
+        """`units` CMUXes over scattered operands: d_ptrs = device array of 4 pointers per unit {selector, a (0 = zero), b, out}"""
+        self._ck(self._lib.spf_cmux_scattered_dev(self._h, stream, units, d_ptrs))
+
     def glwe_not_dev(self, stream, B, d_in, d_out):
         self._ck(self._lib.spf_glwe_not_dev(self._h, stream, B, d_in, d_out))
 
