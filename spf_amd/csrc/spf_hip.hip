@@ -1091,7 +1091,7 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
 #ifdef SPF_STAMPS
         // diagnostic build: per-phase cycles of the first few streaming-shape launches (median over waves)
         static int reported_s = 0;
-        if (reported_s < 2 && a.B >= 1024) {
+        if (reported_s < 2 && a.B >= 512) {
             const size_t waves = (size_t)((a.B + 1) / 2) * 4;
             uint64_t* d_st = nullptr;
             (void)hipMalloc(&d_st, waves * 16 * 8);
@@ -1103,13 +1103,14 @@ static void launch_cmux_args(spf_ctx* c, hipStream_t s, const CmuxArgs& a)
             std::vector<uint64_t> h(waves * 16);
             (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
             (void)hipFree(d_st);
-            static const char* nm[12] = {"entry: table copy, operand loads, decomposition", "barrier (table in place)", "digit + twist x8",
+            static const char* nm[16] = {"entry: operand words in, decomposition", "barrier (table in place)", "digit + twist x8",
                 "hand-over (cross data consumed) x7", "forward transform x8", "cross write + hand-over x8", "cross read + combine x8",
                 "wait for the round's selector rows x8", "MAD + next rows requested x8", "inverse cross exchange (3 hand-overs)",
-                "inverse transform pair", "untwist + d0 + store issue"};
+                "inverse transform pair", "untwist + d0 + store issue", "entry: kernel arguments + pointer table", "entry: 64 operand loads issued",
+                "(unused)", "(unused)"};
             fprintf(stderr, "[cmux stamps] B=%u (cycles per gate, median over %zu waves)\n", a.B, waves);
             double tot = 0;
-            for (int i = 0; i < 12; i++) {
+            for (int i = 0; i < 16; i++) {
                 std::vector<uint64_t> v;
                 for (size_t wv = 0; wv < waves; wv++) v.push_back(h[wv * 16 + i]);
                 std::sort(v.begin(), v.end());

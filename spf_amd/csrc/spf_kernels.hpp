@@ -84,6 +84,24 @@ __device__ __forceinline__ uint32_t lds_address(const void* p)
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
+// The 32 640-byte twiddle image global -> LDS by LDS-DMA (NT threads, 16 bytes each per piece; the last piece is partial and
+// runs under the lanes' own execution mask).  Asynchronous and without a register round trip: a kernel a workgroup runs ONCE
+// issues it before anything else, so it travels under the pointer and operand loads (cmux_kernel: the copy as global loads +
+// ds_write queued behind the 64 operand loads of a lane was 6.3 k of a gate's 70 k cycles).  Completion counts on vmcnt.
+template <int NT>
+__device__ __forceinline__ void table_image_dma(const c64* tables, char* smem, int tid, int wv)
+{
+    const char* src = reinterpret_cast<const char*>(tables);
+    const uint32_t voff = (uint32_t)tid * 16u;
+    const uint32_t dst = lds_address(smem) + (uint32_t)wv * 1024u;
+    constexpr int kRow = NT * 16, kFull = kTableBytes / kRow, kRest = kTableBytes - kFull * kRow;
+#pragma unroll
+    for (int k = 0; k < kFull; k++) lds_dma_piece(src + k * kRow, voff, dst + k * kRow);
+    if constexpr (kRest > 0) {
+        if (tid * 16 < kRest) lds_dma_piece(src + kFull * kRow, voff, dst + kFull * kRow);
+    }
+}
+
 // Hand-over as a bare workgroup barrier (LDS queue drained first).  Not __syncthreads(): its fence would also drain vmcnt, i.e. wait for the key
 // loads in flight.  (The flat-polled words of pair_barrier wait on vmcnt too.)
 __device__ __forceinline__ void pair_barrier_w()
@@ -1068,7 +1086,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 {
     static_assert(L * LOGB <= 32, "packed digits need L*LOGB <= 32");
 #ifdef SPF_STAMPS
-    uint64_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t st_prev = __builtin_amdgcn_s_memtime();
 #define STAMPS_(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
 #else
@@ -1086,6 +1104,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     // hand-over between the two waves of a gate: every wave of the workgroup runs the same sequence, so a bare
     // s_barrier does it (r01's flat-polled word per pair: 0.366 vs 0.355 ms per 4096 gates)
     auto cmux_sync = [&]() { pair_barrier_w(); };
+    table_image_dma<128 * G>(a.tables, smem, tid, wv); // first: it needs nothing but the kernel arguments
     const uint32_t ct_raw = blockIdx.x * G + cslot;
     const bool owns_output = ct_raw < a.B;
     const uint32_t ct = owns_output ? ct_raw : a.B - 1;
@@ -1109,10 +1128,18 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
     const gu64_cptr gd0 = global_view(d0), gd1 = global_view(d1);
     const gu64_ptr gout = global_view(out_ct);
     auto coef2 = [&](int e) -> int { return (e >> 3) * 1024 + (e & 7) * 128 + 2 * lane + w; };
+#ifdef SPF_STAMPS
+    asm volatile("" :: "v"(gd0), "v"(gd1), "v"(gout)); // (diagnostic: the pointers are in)
+    STAMPS_(12);
+#endif
 
     // All 64 operand words are requested before anything else happens (left to itself hipcc keeps about fourteen loads
     // in flight and decomposes one value per round trip: 19 us of the 62 us a gate spent in this kernel), the twiddle
-    // image is copied while they fly, and the decomposition starts when they are in.
+    // image is on its way by LDS-DMA since the top, and the decomposition starts when the words are in.
+    // (r05, measured and not kept: the words as 16-byte loads of coefficient PAIRS, each wave decomposing both parities of
+    // half a polynomial and handing the other parity's digits to its partner through the tile — half the loads, every line
+    // touched once; the issue of the loads went from 6.2 k to 4.8 k cycles, the hand-over and the longer decomposition cost
+    // more: 46.0 -> 48.0 ms per four 32 x 32 multiplications, batches unchanged.)
     uint64_t x1[2][16], x0[2][16];
 #pragma unroll
     for (int p = 0; p < 2; p++)
@@ -1123,12 +1150,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             x0[p][e] = gd0[c]; // d0 aliases d1 when it is the zero ciphertext: no branch around the load
         }
     sched_fence();
-    {
-        const double2* src = reinterpret_cast<const double2*>(a.tables);
-        double2* dst = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < kTableEntries; i += 128 * G) dst[i] = src[i];
-    }
-    sched_fence();
+    STAMPS_(13);
     uint32_t dig[2][16];
 #pragma unroll
     for (int p = 0; p < 2; p++)
@@ -1148,6 +1170,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
             dig[p][e] = packed;
         }
     STAMPS_(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my pieces of the twiddle image have landed (LDS-DMA counts on vmcnt)
     __syncthreads(); // twiddle image ready
     STAMPS_(1);
 
@@ -1330,7 +1353,7 @@ __device__ __forceinline__ void cmux_body(const CmuxArgs& a, char* smem)
 #ifdef SPF_STAMPS
     if (a.stamps && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) a.stamps[((size_t)blockIdx.x * (2 * G) + wv) * 16 + i] = st_acc[i];
+        for (int i = 0; i < 16; i++) a.stamps[((size_t)blockIdx.x * (2 * G) + wv) * 16 + i] = st_acc[i];
     }
 #endif
 #undef STAMPS_
