@@ -783,6 +783,7 @@ template <int L, int LOGB, int W, int J, int MIX>
 __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, char* smem)
 {
     static_assert(L == 2 && L * LOGB <= 32, "two digits, one per wave of a pair");
+    constexpr bool NEG = SPF_BR_NEG != 0; // negated accumulator, as in blind_rotate2p_body (3.72 -> 3.6x ms: the j = 0 wave's integer work is on the step's critical path)
     c64* tab = reinterpret_cast<c64*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -816,7 +817,8 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
         for (int e = 0; e < 16; e++) {
             uint32_t idx = (uint32_t)coef2(e) + bt;
             uint64_t v = lut[h * kN + (idx & (kN - 1))];
-            acc[e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
+            if constexpr (NEG) acc[e] = ((idx >> 11) & 1) ? v : (uint64_t)0 - v; // (NEG: acc[] holds -accumulator throughout)
+            else acc[e] = ((idx >> 11) & 1) ? (uint64_t)0 - v : v;
         }
     }
     __syncthreads(); // twiddle image in place
@@ -869,6 +871,8 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
             STAMP8(1);
             const uint32_t t0 = (uint32_t)(2 * lane + w) + 2 * kN - at;
             const char* src = spectra((int)(t0 & 1), h);
+            uint32_t T0 = (t0 + 2048u) << 20; // (NEG) bit 31 = complement of bit 11 of t0
+            if constexpr (NEG) asm volatile("" : "+v"(T0));
             uint64_t gin[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -883,9 +887,18 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const uint32_t t = t0 + (e >> 3) * 1024 + (e & 7) * 128;
-                const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
-                const uint64_t rot = (gin[e] ^ sgn) - sgn;
-                dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[e]);
+                if constexpr (NEG) {
+                    // x + 2^31 = (gin ^ m) + (nacc[me] + (2^31 + (m ? 1 : 0))), m = complement of bit 11 of t (see blind_rotate2p_body)
+                    const uint32_t m32 = (uint32_t)((int32_t)(T0 + (uint32_t)(((e >> 3) * 1024 + (e & 7) * 128) << 20)) >> 31);
+                    const uint64_t m = ((uint64_t)m32 << 32) | m32;
+                    const uint32_t k32 = 0x80000000u - m32;
+                    const uint32_t s = (uint32_t)(((gin[e] ^ m) + add_u32_to_u64(acc[e], k32)) >> 32); // the rounded top word
+                    dig[e] = (s & 0xFFFFu) | ((s + 0x8000u) & 0xFFFF0000u); // digit 0 | digit 1 = (s >> 16) + carry of digit 0, as packed fields
+                } else {
+                    const uint64_t sgn = (uint64_t)((int64_t)((uint64_t)t << 52) >> 63); // bit 11 of t, spread
+                    const uint64_t rot = (gin[e] ^ sgn) - sgn;
+                    dig[e] = gadget_digits_packed<L, LOGB>(rot - acc[e]);
+                }
             }
             static_assert(LOGB == 16, "digit 1 of the real and of the imaginary element share a 32-bit word");
             uint32_t pk[8];
@@ -995,10 +1008,14 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
             fft512_single<-1, 7>(U, mine, tab, lane); // its exchanges follow the inbox reads in this wave's own LDS queue
             STAMP8(10);
             if constexpr (!LAST) SPF_KEY_PIECE(3);
-            uint64_t t[16];
-            untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(U, twist_lds, t);
+            if constexpr (NEG) {
+                untwist_sub_from_negated<SPF_BSK_PRESCALED>(U, twist_lds, acc);
+            } else {
+                uint64_t t[16];
+                untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(U, twist_lds, t);
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] += t[e];
+                for (int e = 0; e < 16; e++) acc[e] += t[e];
+            }
             STAMP8(11);
         } else {
             if constexpr (!LAST) { SPF_KEY_PIECE(2); SPF_KEY_PIECE(3); }
@@ -1015,6 +1032,10 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
 #undef STAMP8
 #undef SPF_KEY_PIECE
     if constexpr (J == 0) {
+        if constexpr (NEG) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = (uint64_t)0 - acc[e];
+        }
         uint64_t* out = a.out + (size_t)ct * a.out_stride;
         if (!a.sample_extract) {
 #pragma unroll
