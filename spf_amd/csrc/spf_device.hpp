@@ -317,6 +317,9 @@ __device__ __forceinline__ void swap_lane8(double& a, double& b)
 }
 __device__ __forceinline__ void lane_transpose_hi3(c64 (&V)[8])
 {
+#if defined(SPF_ABL) && SPF_ABL == 3 // (timing-only ablation: see spf_kernels.hpp)
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; r++) { // register bit 2 <-> lane bit 5
         swap_halves32(V[r].re, V[r + 4].re);

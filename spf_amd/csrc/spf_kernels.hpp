@@ -204,6 +204,12 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #ifndef SPF_BR_NEG
 #define SPF_BR_NEG 1
 #endif
+// SPF_ABL = n: TIMING-ONLY ablations of blind_rotate2p_body (wrong results; never in the library): what does the step cost without
+// 1 the torus conversion, 2 the rotation gather + decomposition, 3 the register-side exchange, 4 the multiply-accumulate and its
+// key reads, 5 the forward pairs, 6 the inverse pair.  profiles/r05_valu_rates.md, "what the step is made of".
+#ifndef SPF_ABL
+#define SPF_ABL 0
+#endif
 template <int L, int LOGB, int OPT, int W, int CTS = 4, int MIX = 1>
 __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, char* smem)
 {
@@ -361,6 +367,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             STAMP(0);
             if (p == 0) SPF_PRIO_POINT(2); else SPF_PRIO_POINT(9);
             uint32_t dig[16];
+#if SPF_ABL == 2 // (timing-only ablation, wrong results: no rotation gather, no subtraction, no rounding)
+#pragma unroll
+            for (int e = 0; e < 16; e++) dig[e] = (uint32_t)(acc[p][e] >> 32) ^ at;
+#else
             {
                 // source coefficient of element e: (c_e - at) mod 2N with c_e = c_0 + 128 m (m = e & 7, +1024
                 // for e >= 8): region (parity) and the low address bits do not depend on e
@@ -399,6 +409,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     }
                 }
             }
+#endif
             c64 VV[2][8];
 #if SPF_TWIST_PRE
             {
@@ -430,6 +441,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             // (r03c: polynomial 0: the older waves lead through the forward transforms; polynomial 1: the younger)
             if (p == 0) SPF_PRIO_POINT(4); else SPF_PRIO_POINT(10);
             if (p == 1) ring_dma(chunk);
+#if SPF_ABL != 5 // (5: timing-only, the forward transform pairs are not executed)
             if constexpr (MIX) {
                 if (p == 0) SPF_PAIR_M0<+1, XPF0>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
                 else SPF_PAIR_M1<+1, XPF1>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
@@ -437,6 +449,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                 if (p == 0) SPF_PAIR_E0<+1, XPF0>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(17); });
                 else SPF_PAIR_E1<+1, XPF1>(VV[0], VV[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(18); });
             }
+#endif
             STAMP(3);
             if (p == 0) SPF_PRIO_POINT(5);
             // radix-2 stage across the two waves, both digits in one exchange: wave 0 finishes bins with
@@ -509,6 +522,18 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
 #endif
             STAMP(5);
+#if SPF_ABL == 4 // (timing-only: no key reads from the ring, no multiply-accumulate)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) { // (scaled into the magnitude window of the conversion's short path)
+                        const bool first = p == 0 && j == 0;
+                        prod[q][r].re = __builtin_fma(VV[j][r].re, 0x1p58, first ? 0.0 : prod[q][r].re);
+                        prod[q][r].im = __builtin_fma(VV[j][r].im, 0x1p58, first ? 0.0 : prod[q][r].im);
+                    }
+#else
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const c64* row = reinterpret_cast<const c64*>(bskring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
@@ -544,6 +569,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     }
                 }
             }
+#endif
             STAMP(6);
             if (p == 0) SPF_PRIO_POINT(7);
             __syncthreads(); // every wave is done with the ring and with its partner's cross data
@@ -646,12 +672,18 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             SPF_PRIO_POINT(14);
             if (chunk < total_chunks) ring_dma(chunk); // rows of the next step's polynomial 0
         }
+#if SPF_ABL != 6 // (6: timing-only, the inverse transform pair is not executed)
         if constexpr (MIX) SPF_PAIR_MI<-1, XPI>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
         else SPF_PAIR_EI<-1, XPI>(WW[0], WW[1], mine, tab, lane, [&]() { SPF_PRIO_POINT(19); });
+#endif
         STAMP(9);
         SPF_PRIO_POINT(15);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
+#if SPF_ABL == 1 // (timing-only: no untwist, no conversion to the torus)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[q][e] += (uint64_t)__double_as_longlong(e < 8 ? WW[q][e].re : WW[q][e - 8].im);
+#else
             if constexpr (NEG) {
                 untwist_sub_from_negated<SPF_BSK_PRESCALED>(WW[q], twist, acc[q]);
             } else {
@@ -660,6 +692,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[q][e] += t[e];
             }
+#endif
             if (q == 0) SPF_PRIO_POINT(16);
         }
         STAMP(10);
