@@ -1,7 +1,7 @@
 // NOT in the library.  r05 experiment (verdict r04 item 6a): the CMUX-tree gate's latency shape over eight waves instead of four.
 // Bit-equal with cmux4_kernel on first run (checksums of tools/kernel_bench.py cmux at B = 1 / 4 / 64 / 256), and SLOWER:
 //   B = 1 / 4 / 64 / 256:  cmux4 14.7 / 14.9 / 15.4 / 23.7 us per launch, cmux8 16.9 / 17.1 / 17.8 / 29.0 us.
-// Why (stamps, profiles/r05_kernels_summary.md): a wave that has its SIMD to itself already issues a transform pair at the SIMD's
+// Why (stamps, profiles/r05_experiments_other_kernels.md): a wave that has its SIMD to itself already issues a transform pair at the SIMD's
 // f64 rate (5.0 k cycles a pair alone; cmux4's "decompose + 2 x (pair, cross)" is 12.3 k), and SIMD siblings share that rate: the
 // pair plus the wait for the sibling's pair at the cross barrier is 10.2 k here.  What the split saves (2 k) is spent on twice the
 // waves to start (entry + table barrier 12.6 k against 7.0 k), 140 B of scratch at 256 registers, and two more barriers.
@@ -9,7 +9,7 @@
 // ------------------------------------------------------------------------------------------
 // cmux8_kernel: cmux4_kernel's gate over EIGHT waves — wave (w, h, jj): sample parity w x polynomial h x digit pair jj
 // (digits 2jj, 2jj + 1); waves (w, h, 0) and (w, h, 1) are SIMD siblings (wave number 4 jj + 2 h + w).  cmux4's stamps
-// (profiles/r05_kernels_summary.md) put 12.3 k of a gate's 35 k cycles into "decompose + 2 x (transform pair, cross)" of a
+// (profiles/r05_experiments_other_kernels.md) put 12.3 k of a gate's 35 k cycles into "decompose + 2 x (transform pair, cross)" of a
 // wave that has its SIMD to itself: here every wave runs ONE `fft512_pair_pipelined`, the sibling the other beside it.
 //   * both waves of a pair load and decompose polynomial h themselves (no hand-over: the loads are the same lines, and a
 //     hand-over is a barrier);

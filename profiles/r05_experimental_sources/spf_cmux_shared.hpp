@@ -1,6 +1,6 @@
 // spf_cmux_shared.hpp — r05 experiment, NOT part of the library (compiled by nothing): `cmux_shared_kernel`, the CMUX of a gate-graph
 // level whose gates share selectors, as it was built into spf_kernels.hpp / spf_hip.hip / spf_graph.hpp and measured
-// (profiles/r05_kernels_summary.md, "Shared-selector CMUX"): bit-equal to cmux_kernel and to the oracle, no faster on the
+// (profiles/r05_experiments_other_kernels.md, "Shared-selector CMUX"): bit-equal to cmux_kernel and to the oracle, no faster on the
 // 32 x 32 multiplier's levels.  Kept as the record of what was measured.
 //
 // ---- device side (was in spf_kernels.hpp, between cmux_kernel and cmux4_kernel) ----

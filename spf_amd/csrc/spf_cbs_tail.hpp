@@ -13,7 +13,7 @@
 #include "spf_kernels.hpp"
 
 // The transform pair of each tail kernel (all variants give the same words).  r05 A/B, ms per 4096, two runs each
-// (profiles/r05_kernels_summary.md): trace 4.52 / 4.57 / 4.61 / 4.72 and scheme switch 1.149 / 1.111 / 1.126 / 1.130 with
+// (profiles/r05_experiments_other_kernels.md): trace 4.52 / 4.57 / 4.61 / 4.72 and scheme switch 1.149 / 1.111 / 1.126 / 1.130 with
 // fft512_pair1 / pair1t / pair1ts / pair1ts2 — the trace kernel has no registers to hold a pass's twiddles across the pair
 // (44 B of scratch already), the scheme switch has.
 #ifndef SPF_TRACE_PAIR
@@ -210,7 +210,7 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
                     accb[e] += v; // out.b += trivial(b_k) ...
                 }
             }
-#ifndef SPF_ABL_NO_PARK // (timing-only ablation: wrong results — what does the parked half's traffic cost?  profiles/r05_kernels_summary.md)
+#ifndef SPF_ABL_NO_PARK // (timing-only ablation: wrong results — what does the parked half's traffic cost?  profiles/r05_experiments_other_kernels.md)
             if (p == 1 && owns_output) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) park[(size_t)e * 64] = accb[e];

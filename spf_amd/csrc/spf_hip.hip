@@ -40,7 +40,7 @@ thread_local std::string g_create_error;
 // 6.95 -> 9.76 ms).  Built, bit-equal (same output checksums at B = 513 / 520 / 600 / 700 / 768, both instantiations), and no faster
 // than four per workgroup — 9.90-9.97 ms against 9.74-9.82 (plain PBS 10.61 against 10.28): two of the four SIMDs still carry two
 // waves, and the step of a workgroup is the step of its slowest SIMD.  Off; -DSPF_TRIO_SHAPE=1 re-runs the row
-// (profiles/r05_kernels_summary.md).  The alternative "512 on the two-per-workgroup shape + the rest on the eight-wave shape" runs
+// (profiles/r05_experiments_other_kernels.md).  The alternative "512 on the two-per-workgroup shape + the rest on the eight-wave shape" runs
 // back to back (both shapes take a whole CU's LDS): 6.95 + 3.72 ms.
 #ifndef SPF_TRIO_SHAPE
 #define SPF_TRIO_SHAPE 0
