@@ -139,8 +139,10 @@ __device__ __forceinline__ void young_prio(uint32_t flag) {
 // polynomial, right where r03c's long stretch runs, so its younger waves arrived 4 600 cycles early at hand-over 1; its own
 // schedule (r04, twelve timed: profiles/r04_experiments_blind_rotate.md) lets them lead through the FIRST HALF of each of
 // the three transform pairs and nowhere else: 46.4 -> 44.9 ms per 4096.
+// (r05, after the negated accumulator had shortened the integer phases: every single-position change re-timed, tools/sweep_prio.py +
+// tools/gpu_sweep_prio.sh — position 5 -> '0' 38.44-38.53 ms against 38.72-38.79, three runs of nine launches; the mixing schedule stays)
 #ifndef SPF_PRIO_SCHED_EVEN
-#define SPF_PRIO_SCHED_EVEN "----0-----10--1-----"
+#define SPF_PRIO_SCHED_EVEN "----00----10--1-----"
 #endif
 #ifndef SPF_PRIO_SCHED_MIX
 #define SPF_PRIO_SCHED_MIX "----1-----1---10-00-"
