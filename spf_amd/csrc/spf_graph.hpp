@@ -20,6 +20,26 @@
 #include <tuple>
 #include <vector>
 
+// host memory the copy engines can reach directly (hipHostMalloc): a copy to or from pageable memory is staged by the runtime
+// through its own pinned bounce buffer, synchronously, ~20 us per call — 33 of them were 0.68 of a 32-bit addition's 5.5 ms
+struct spf_pinned_buf {
+    uint8_t* p = nullptr;
+    size_t n = 0;
+    uint8_t* data() const { return p; }
+    bool resize(size_t bytes)
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        if (!bytes) return true;
+        if (hipHostMalloc((void**)&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        std::memset(p, 0, bytes);
+        n = bytes;
+        return true;
+    }
+    void free_buf() { (void)resize(0); }
+};
+
 struct spf_graph {
     struct Node {
         int32_t op;        // spf_graph_op, or -1 input, -2 trivial constant
@@ -48,7 +68,25 @@ struct spf_graph {
     std::vector<std::pair<uint32_t, void*>> outputs;
     bool planned = false;
     std::vector<Group> groups;
-    std::vector<uint8_t> h_inputs;
+    spf_pinned_buf h_inputs;
+    // outputs leave in ONE device-to-host copy: gathered on the device (one gather_rows launch per value size) into d_out_stage,
+    // copied into pinned h_out_stage, handed to the callers' buffers from there
+    struct OutClass { size_t words = 0, count = 0, ptr_index = 0, stage_off = 0; std::vector<size_t> which; };
+    std::vector<OutClass> out_classes;
+    spf_pinned_buf h_out_stage;
+    char* d_out_stage = nullptr;
+    void** d_out_ptrs = nullptr;
+    size_t out_bytes = 0, outputs_planned = (size_t)-1;
+    void release_outputs()
+    {
+        if (d_out_stage) (void)hipFree(d_out_stage);
+        if (d_out_ptrs) (void)hipFree(d_out_ptrs);
+        d_out_stage = nullptr;
+        d_out_ptrs = nullptr;
+        h_out_stage.free_buf();
+        out_classes.clear();
+        outputs_planned = (size_t)-1;
+    }
     size_t inputs_bytes = 0, arena_bytes = 0, stage_bytes = 0;
     char* d_arena = nullptr;
     char* d_stage[2] = {nullptr, nullptr};
@@ -81,6 +119,7 @@ struct spf_graph {
     void release()
     {
         drop_exec();
+        release_outputs();
         runs_since_plan = 0;
         if (d_arena) (void)hipFree(d_arena);
         if (d_stage[0]) (void)hipFree(d_stage[0]);
@@ -298,7 +337,7 @@ inline spf_status plan(spf_graph* g)
             if (is_cmux_family(gr.op)) hist[gr.members.size() * (gr.op == SPF_OP_GLEV_CMUX ? g->prm.cbs_radix_count : 1)]++;
         for (auto& kv : hist) fprintf(stderr, "[graph widths] %zu units x %zu launches\n", kv.first, kv.second);
     }
-    g->h_inputs.assign(g->inputs_bytes, 0);
+    if (!g->h_inputs.resize(g->inputs_bytes)) return fail(c, SPF_ERR_HIP, "graph: no pinned host memory for the inputs");
     g->planned = true;
     return SPF_OK;
 }
@@ -369,6 +408,40 @@ inline spf_status enqueue(spf_graph* g, hipStream_t s)
         if (st != SPF_OK) return st;
         g->n_launches++;
     }
+    return SPF_OK;
+}
+
+// Output staging (after plan(): needs the arena offsets): outputs grouped by value size, one pointer row per group
+inline spf_status plan_outputs(spf_graph* g)
+{
+    spf_ctx* c = g->ctx;
+    g->release_outputs();
+    std::map<size_t, spf_graph::OutClass> by_words;
+    for (size_t i = 0; i < g->outputs.size(); i++) {
+        const auto& n = g->nodes[g->outputs[i].first];
+        auto& oc = by_words[g->value_bytes(n.kind) / 8];
+        oc.words = g->value_bytes(n.kind) / 8;
+        oc.which.push_back(i);
+    }
+    std::vector<void*> table;
+    size_t off = 0;
+    for (auto& kv : by_words) {
+        auto& oc = kv.second;
+        oc.count = oc.which.size();
+        oc.ptr_index = table.size();
+        oc.stage_off = off;
+        for (size_t i : oc.which) table.push_back(g->d_arena + g->nodes[g->outputs[i].first].off);
+        off = align_up(off + oc.count * oc.words * 8, 256);
+        g->out_classes.push_back(oc);
+    }
+    g->out_bytes = off;
+    if (off) {
+        HIPCHK(c, hipMalloc((void**)&g->d_out_stage, off));
+        HIPCHK(c, hipMalloc((void**)&g->d_out_ptrs, table.size() * sizeof(void*)));
+        HIPCHK(c, hipMemcpy(g->d_out_ptrs, table.data(), table.size() * sizeof(void*), hipMemcpyHostToDevice));
+        if (!g->h_out_stage.resize(off)) return fail(c, SPF_ERR_HIP, "graph: no pinned host memory for the outputs");
+    }
+    g->outputs_planned = g->outputs.size();
     return SPF_OK;
 }
 
@@ -446,11 +519,20 @@ inline spf_status run(spf_graph* g)
             }
         } else if (st != SPF_OK) return st;
     }
-    for (const auto& o : g->outputs) {
-        const auto& n = g->nodes[o.first];
-        HIPCHK(c, hipMemcpyAsync(o.second, g->d_arena + n.off, g->value_bytes(n.kind), hipMemcpyDeviceToHost, s));
+    if (g->outputs_planned != g->outputs.size()) {
+        spf_status st = plan_outputs(g);
+        if (st != SPF_OK) return st;
     }
+    for (const auto& oc : g->out_classes) {
+        spf_status st = spf_gather_rows_dev(c, s, oc.count, oc.words, (const uint64_t* const*)(g->d_out_ptrs + oc.ptr_index),
+                                            (uint64_t*)(g->d_out_stage + oc.stage_off));
+        if (st != SPF_OK) return st;
+    }
+    if (g->out_bytes) HIPCHK(c, hipMemcpyAsync(g->h_out_stage.data(), g->d_out_stage, g->out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    for (const auto& oc : g->out_classes)
+        for (size_t i = 0; i < oc.count; i++)
+            std::memcpy(g->outputs[oc.which[i]].second, g->h_out_stage.data() + oc.stage_off + i * oc.words * 8, oc.words * 8);
     return SPF_OK;
 }
 
@@ -473,6 +555,7 @@ void spf_graph_destroy(spf_graph* g)
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     g->release();
+    g->h_inputs.free_buf();
     delete g;
 }
 
