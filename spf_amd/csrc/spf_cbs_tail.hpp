@@ -19,9 +19,6 @@
 #ifndef SPF_TRACE_PAIR
 #define SPF_TRACE_PAIR fft512_pair1
 #endif
-#ifndef SPF_TRACE_ROLL
-#define SPF_TRACE_ROLL 0
-#endif
 #ifndef SPF_SS_PAIR
 #define SPF_SS_PAIR fft512_pair1t // pass twiddles requested early, shared by the pair (r04: 1.16 -> 1.12 ms)
 #endif
@@ -222,122 +219,6 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             wave_lds_fence(); // gathered: the region may be overwritten (next staging / the exchange image)
         }
 
-#if SPF_TRACE_ROLL
-        STAMPT(0);
-        // (SPF_TRACE_ROLL: the three digit pairs of a round as ONE loop body — the two parity copies of the unrolled round are 98 KB,
-        // more than the 64 KiB instruction cache two CUs share; the parked half comes back behind the loop)
-        c64 prod[2][8];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) prod[q][r] = {0.0, 0.0};
-#pragma unroll 1
-        for (int m = 0; m < 3; m++, chunk++) {
-            c64 VV[2][8];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                int dre[2], dim[2];
-                if (m == 0) {
-                    dre[0] = (int)(int16_t)(d01[n1] & 0xFFFFu); dre[1] = (int)d01[n1] >> 16;
-                    dim[0] = (int)(int16_t)(d01[8 + n1] & 0xFFFFu); dim[1] = (int)d01[8 + n1] >> 16;
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 2; jj++) {
-                        uint64_t sr = st[n1], si = st[8 + n1];
-                        dre[jj] = next_digit<LOGB>(sr);
-                        dim[jj] = next_digit<LOGB>(si);
-                        st[n1] = (uint32_t)sr;
-                        st[8 + n1] = (uint32_t)si;
-                    }
-                }
-                const c64 tw = twist[64 * n1];
-                VV[0][n1] = cmul_nf({(double)dre[0], (double)dim[0]}, tw);
-                VV[1][n1] = cmul_nf({(double)dre[1], (double)dim[1]}, tw);
-            }
-            // the ring is free since the barrier behind the previous MADs: rows of this pair (those of a round's first
-            // pair were requested ahead of the previous round's inverse transforms)
-            STAMPT(1);
-            young_prio<0>(m == 0 ? is_young : 0u);
-            young_prio<1>(m == 2 ? is_young : 0u);
-            if (m > 0) ring_dma(chunk);
-            SPF_TRACE_PAIR<+1, XP>(VV[0], VV[1], mine, tab, lane);
-            STAMPT(2);
-            // radix-2 stage across the two waves, both digits in one exchange
-            if constexpr (w == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][4 + i];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) reinterpret_cast<c64*>(mine)[(j * 4 + i) * 64 + lane] = VV[j][i];
-            }
-            young_prio<0>(m == 2 ? is_young : 0u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of the key rows has landed
-            __syncthreads();
-            STAMPT(3);
-            if constexpr (w == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const c64 in = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
-                        const c64 t = cmul_tw<+1>(in, wc[64 * i]);
-                        const c64 Ei = VV[j][i];
-                        VV[j][i] = cadd(Ei, t);
-                        VV[j][i + 4] = csub(Ei, t);
-                    }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const c64 Ei = reinterpret_cast<const c64*>(theirs)[(j * 4 + i) * 64 + lane];
-                        const c64 t = cmul_tw<+1>(VV[j][4 + i], wc[64 * i]);
-                        VV[j][i] = cadd(Ei, t);
-                        VV[j][i + 4] = csub(Ei, t);
-                    }
-            }
-            // ... - sum_j <digit_j(a), glev row L-1-j>, digits in order, both output polynomials (fft_ops.rs:489-494)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const c64* row = reinterpret_cast<const c64*>(ring + (1 - j) * kBskSlotBytes) + 256 * w + lane;
-                c64 kb[2][2];
-                auto key2 = [&](int grp, c64 (&dst)[2]) {
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
-                        dst[i] = row[q * kHalf + 64 * (r & 3) + 512 * (r >> 2)];
-                    }
-                };
-                key2(0, kb[0]);
-#pragma unroll
-                for (int grp = 0; grp < 8; grp++) {
-                    if (grp + 1 < 8) key2(grp + 1, kb[(grp + 1) % 2]);
-                    compiler_fence();
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int r = (grp * 2 + i) & 7, q = grp >> 2;
-                        const c64 k = kb[grp % 2][i];
-                        double re = __builtin_fma(k.re, VV[j][r].re, prod[q][r].re);
-                        double im = __builtin_fma(k.re, VV[j][r].im, prod[q][r].im);
-                        prod[q][r].re = __builtin_fma(-k.im, VV[j][r].im, re);
-                        prod[q][r].im = __builtin_fma(k.im, VV[j][r].re, im);
-                    }
-                }
-            }
-            STAMPT(4);
-            __syncthreads(); // every wave is done with the ring and with its partner's cross data
-            STAMPT(5);
-        }
-
-#ifndef SPF_ABL_NO_PARK
-#pragma unroll
-        for (int e = 0; e < 16; e++) accb[e] = park[(size_t)e * 64]; // the parked body half comes back under the inverse cross exchange
-#endif
-#else
         STAMPT(0);
         c64 prod[2][8];
 #pragma unroll
@@ -453,7 +334,6 @@ __device__ __forceinline__ void cbs_trace_body(const TraceArgs& a, char* smem)
             STAMPT(5);
         }
 
-#endif
         // ---- back to the torus, both output polynomials together
         c64 WW[2][8];
 #pragma unroll
