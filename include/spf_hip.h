@@ -350,7 +350,9 @@ spf_status spf_graph_add_input(spf_graph *graph, spf_value_kind kind, const void
 spf_status spf_graph_add_trivial(spf_graph *graph, spf_value_kind kind, uint64_t bit, uint32_t *node);
 spf_status spf_graph_add_op(spf_graph *graph, spf_graph_op op, const uint32_t *inputs, size_t n_inputs,
                             uint64_t param, uint32_t *node);
-/* FheOp::Output*: copy the node's value to `host` at the end of every run */
+/* FheOp::Output*: copy the node's value to `host` at the end of every run.  Plain (pageable) buffers: the run gathers every
+ * output on the device and brings them back in ONE copy through the graph's own pinned staging (inputs go up the same way);
+ * per-output copies to pageable memory cost ~20 us each on this runtime — 0.68 ms of a 32-bit addition's 5.5. */
 spf_status spf_graph_add_output(spf_graph *graph, uint32_t node, void *host);
 /* `run_graph_blocking`: returns when every output has been written */
 spf_status spf_graph_run(spf_graph *graph);
