@@ -31,6 +31,13 @@ using namespace spf;
 // otherwise.  The runtime reads the variable when it initialises (first HIP call of the process); this runs when the library is
 // loaded.  A process that has initialised HIP before loading the library keeps its setting: export GPU_MAX_HW_QUEUES there.
 __attribute__((constructor(101))) static void spf_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+#if defined(SPF_ABL) && SPF_ABL != 0
+// a timing-only ablation build (spf_kernels.hpp, SPF_ABL) computes WRONG results on purpose: it says so when it is loaded
+__attribute__((constructor(102))) static void spf_ablation_banner()
+{
+    fprintf(stderr, "libspf_hip: TIMING-ONLY ablation build (SPF_ABL=%d): the blind rotation's results are WRONG by construction\n", (int)SPF_ABL);
+}
+#endif
 
 namespace {
 
