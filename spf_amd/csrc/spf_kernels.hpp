@@ -191,6 +191,9 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #ifndef SPF_TWIST_PRE
 #define SPF_TWIST_PRE 1     // the eight twist factors of a polynomial requested at once ...
 #endif
+#ifndef SPF_TWIST_PRE_E4
+#define SPF_TWIST_PRE_E4 0  // ... except in the even-rotation instantiation of the four-per-workgroup shape (r05, see the twist)
+#endif
 #ifndef SPF_GATHER_FENCE
 #define SPF_GATHER_FENCE 1  // ... and all sixteen rotation-gather reads out before the first is consumed (together −0.2 / −0.4 %)
 #endif
@@ -413,8 +416,10 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             }
 #endif
             c64 VV[2][8];
-#if SPF_TWIST_PRE
-            {
+            // (r05, on the negated-accumulator build: requested one by one 37.86-37.92 ms per 4096 against 38.20-38.24 for even rotations
+            // on the four-per-workgroup shape; the mixing instantiation and the two-per-workgroup shape keep the batch: 39.85 against 39.95, 6.68 against 6.72)
+            constexpr bool kTwistBatch = (!MIX && CTS == 4) ? (SPF_TWIST_PRE_E4 != 0) : (SPF_TWIST_PRE != 0);
+            if constexpr (kTwistBatch) {
                 // the eight twist factors in one go (hipcc fetches them two at a time, each pair waited for on the spot)
                 c64 twf[8];
 #pragma unroll
@@ -425,15 +430,14 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
                     VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, twf[n1]);
                     VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, twf[n1]);
                 }
-            }
-#else
+            } else {
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                const c64 tw = twist[64 * n1];
-                VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, tw);
-                VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, tw);
+                for (int n1 = 0; n1 < 8; n1++) {
+                    const c64 tw = twist[64 * n1];
+                    VV[0][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 0, tw);
+                    VV[1][n1] = twisted_digit_top32(dig[n1], dig[8 + n1], 1, tw);
+                }
             }
-#endif
             STAMP(1);
             if (p == 0) SPF_PRIO_POINT(3);
             rendezvous_if_mixing(); // partner is done gathering from my region
