@@ -1147,15 +1147,23 @@ __device__ __forceinline__ uint64_t add_u32_to_u64(uint64_t a, uint32_t b)
 //     bit-field extract — and the saturating-cast quirk by a running signed minimum of the results' high words (INT_MIN
 //     <=> some magnitude has the high word 0x80000000; VOP2) instead of one 64-bit compare per value.
 // The literal fall-back takes the original value (-tvn, exact) and is subtracted.
-template <bool PRESCALED>
+// TWIST_AT_ONCE: the eight twist factors requested together ahead of the products (the latency shapes, one wave per SIMD: 3.572 ->
+// 3.542 ms per 64, 6.695 -> 6.669 per 512; the four-per-workgroup shape is 0.1 % slower with it)
+template <bool PRESCALED, bool TWIST_AT_ONCE = false>
 __device__ __forceinline__ void untwist_sub_from_negated(const c64 (&V)[8], const c64* twist_lds, uint64_t (&nacc)[16])
 {
     double tvn[16];
+    c64 twf[TWIST_AT_ONCE ? 8 : 1];
+    if constexpr (TWIST_AT_ONCE) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) twf[n1] = twist_lds[64 * n1];
+        compiler_fence();
+    }
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) {
         c64 xs = V[n1];
         if constexpr (!PRESCALED) xs = {V[n1].re * (1.0 / 1024.0), V[n1].im * (1.0 / 1024.0)};
-        const c64 tw = twist_lds[64 * n1];
+        const c64 tw = TWIST_AT_ONCE ? twf[TWIST_AT_ONCE ? n1 : 0] : twist_lds[64 * n1];
         // cmul_nf_conj negated: re = -(a.re b.re) - (a.im b.im), im = a.re b.im - a.im b.re
         tvn[n1] = -(xs.re * tw.re) - xs.im * tw.im;
         tvn[8 + n1] = xs.re * tw.im - xs.im * tw.re;

@@ -331,7 +331,7 @@ spf_status launch_blind_rotate(spf_ctx* c, hipStream_t s, size_t B, const uint64
     else if (trio && log_v == 0) SPF_LAUNCH("blind_rotate2p3_kernel<2,16," SPF_STR(SPF_BR_OPT) ">", (blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 1>), kBlindRotate2p3Lds);
     else if (trio) SPF_LAUNCH("blind_rotate2p3_kernel<2,16," SPF_STR(SPF_BR_OPT) ",even>", (blind_rotate2p3_kernel<2, 16, SPF_BR_OPT, 0>), kBlindRotate2p3Lds);
 #endif
-    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16," SPF_STR(SPF_BR_OPT) ">", (blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 1>), kBlindRotate2pLds);
+    else if (log_v == 0) SPF_LAUNCH("blind_rotate2p_kernel<2,16," SPF_STR(SPF_BR_OPT_MIX) ">", (blind_rotate2p_kernel<2, 16, SPF_BR_OPT_MIX, 1>), kBlindRotate2pLds);
     else SPF_LAUNCH("blind_rotate2p_kernel<2,16," SPF_STR(SPF_BR_OPT) ",even>", (blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 0>), kBlindRotate2pLds);
 #undef SPF_LAUNCH
     HIPCHK(c, hipGetLastError());
@@ -581,7 +581,7 @@ spf_status spf_create(const spf_params* params, int device_id, spf_ctx** out)
     }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks_gemm_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            kKsLdsBytes));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 1>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, SPF_BR_OPT_MIX, 1>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&blind_rotate2p_kernel<2, 16, SPF_BR_OPT, 0>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, kBlindRotate2pLds));

@@ -182,6 +182,9 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 #ifndef SPF_BR_OPT
 #define SPF_BR_OPT 6  // blind_rotate2p_kernel (four ciphertexts per workgroup): r05 A/B 38.73-38.79 ms per 4096 against 39.01 with 14, plain PBS 40.66-40.75 against 41.06-41.16
 #endif
+#ifndef SPF_BR_OPT_MIX
+#define SPF_BR_OPT_MIX 10 // ... and its mixing instantiation (plain PBS): the inverse cross exchange through the key ring pays there (r05, on the negated-accumulator build: 39.72 / 39.83 ms against 39.98-40.17 with 6)
+#endif
 #ifndef SPF_BR2_OPT
 #define SPF_BR2_OPT 6  // blind_rotate2p2_kernel (two per workgroup): 6.87 ms per 512 against 6.96 with 14 (plain PBS 7.07 / 7.08)
 #endif
@@ -691,7 +694,7 @@ __device__ __forceinline__ void blind_rotate2p_body(const BlindRotateArgs& a, ch
             for (int e = 0; e < 16; e++) acc[q][e] += (uint64_t)__double_as_longlong(e < 8 ? WW[q][e].re : WW[q][e - 8].im);
 #else
             if constexpr (NEG) {
-                untwist_sub_from_negated<SPF_BSK_PRESCALED>(WW[q], twist, acc[q]);
+                untwist_sub_from_negated<SPF_BSK_PRESCALED, CTS != 4>(WW[q], twist, acc[q]);
             } else {
                 uint64_t t[16];
                 untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(WW[q], twist, t);
@@ -1048,7 +1051,7 @@ __device__ __forceinline__ void blind_rotate8_body(const BlindRotateArgs& a, cha
             STAMP8(10);
             if constexpr (!LAST) SPF_KEY_PIECE(3);
             if constexpr (NEG) {
-                untwist_sub_from_negated<SPF_BSK_PRESCALED>(U, twist_lds, acc);
+                untwist_sub_from_negated<SPF_BSK_PRESCALED, true>(U, twist_lds, acc);
             } else {
                 uint64_t t[16];
                 untwist_to_torus_bits<false, SPF_BSK_PRESCALED>(U, twist_lds, t);

@@ -129,11 +129,11 @@ def plain_pbs_4096(full):
 
 def test_config2_batch_4096_generalized_pbs_log_v0_every_ciphertext(full, plain_pbs_4096):
     """generalized_programmable_bootstrap(log_chi = 0, log_v = 0) at B = 4096, n = 637 through the throughput shape
-    (`blind_rotate2p_kernel<2,16,6>`, nine barriers a step): all 4096 GLWE outputs against the oracle."""
+    (`blind_rotate2p_kernel<2,16,10>`, nine barriers a step): all 4096 GLWE outputs against the oracle."""
     ks, eng = full
     lwe, lut, exp = plain_pbs_4096
     got = eng.generalized_pbs(lwe, lut, 0, 0, 0)
-    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,6>"
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,10>"
     bad = np.nonzero((got != exp).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} ciphertexts differ, first {bad[:8]}"
 
@@ -146,7 +146,7 @@ def test_config2_batch_4096_pbs_univariate_every_ciphertext(full, plain_pbs_4096
     P = ks.params
     lwe, lut, exp_glwe = plain_pbs_4096
     got = eng.pbs_univariate(lwe, lut)
-    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,6>"
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,10>"
     exp = np.stack([O.sample_extract(g, 0, P.N, P.k) for g in exp_glwe])
     bad = np.nonzero((got != exp).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} ciphertexts differ, first {bad[:8]}"
@@ -167,7 +167,7 @@ def test_config2_plain_pbs_512_and_ragged_1031(full, plain_pbs_4096):
     assert eng.last_blind_rotate_kernel() == "blind_rotate8_kernel<2,16>"
     assert np.array_equal(got, exp[3000:3200])
     got = dev_bootstrap(eng, lwe[1000:2031], lut, 0, 0, 0)        # one launch: 257 workgroups of four + 3
-    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,6>"
+    assert eng.last_blind_rotate_kernel() == "blind_rotate2p_kernel<2,16,10>"
     assert np.array_equal(got, exp[1000:2031])
     u = dev_bootstrap(eng, lwe[1000:2031], lut, extract=True)
     P = ks.params

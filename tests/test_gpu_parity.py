@@ -119,15 +119,17 @@ def test_saturating_cast_quirk_is_reproduced():
 # gather hand-overs and their own ragged tail.  One launch per batch (device-pointer entry points).
 
 EDGE_BATCHES = [1030, 600, 400, 100]   # 2p ragged, 2p, 2p2, eight-wave latency shape
-_EDGE_KERNEL = {1030: "blind_rotate2p_kernel<2,16,6", 600: "blind_rotate2p_kernel<2,16,6",
-                400: "blind_rotate2p2_kernel<2,16,6"}
+# (the four-per-workgroup shape ships build option 6 for even rotations and 10 for the mixing instantiation: SPF_BR_OPT / SPF_BR_OPT_MIX)
+_EDGE_KERNEL = {1030: ("blind_rotate2p_kernel<2,16,6,even>", "blind_rotate2p_kernel<2,16,10>"),
+                600: ("blind_rotate2p_kernel<2,16,6,even>", "blind_rotate2p_kernel<2,16,10>"),
+                400: ("blind_rotate2p2_kernel<2,16,6,even>", "blind_rotate2p2_kernel<2,16,6>")}
 
 
 def _edge_kernel(B, even):
     """the kernel a batch of B must have gone to (the latency shape has one instantiation for both rotation kinds)"""
     if B not in _EDGE_KERNEL:
         return "blind_rotate8_kernel<2,16" + (",even>" if even else ">")
-    return _EDGE_KERNEL[B] + (",even>" if even else ">")
+    return _EDGE_KERNEL[B][0 if even else 1]
 
 
 def _edge_lwe(B, n):
