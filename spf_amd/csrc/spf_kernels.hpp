@@ -153,8 +153,9 @@ static_assert(sizeof(SPF_PRIO_SCHED_EVEN) == 21 && sizeof(SPF_PRIO_SCHED_MIX) ==
 // OPT: bit 0 = exchange 2 of BOTH transforms of a pair in registers (lane_transpose_hi3), bit 1 = of the second
 // transform only (balances the LDS store path against the VALU), bit 2 = two key pairs in flight in the MAD instead of
 // three (8 registers, 32 B of scratch less), bit 3 = inverse cross exchange through the key ring (one barrier instead of
-// two).  The library instantiates OPT = 6 (SPF_BR_OPT / SPF_BR2_OPT below; r03-r04 shipped 14: bit 3 was worth 0.3 ms on the
-// ten-barrier kernel and costs 0.25 ms on today's); the A/B numbers of the others are in profiles/r05_experiments_blind_rotate.md,
+// two).  The library instantiates OPT = 6 — and 10 for the mixing instantiation of the four-per-workgroup shape (SPF_BR_OPT /
+// SPF_BR_OPT_MIX / SPF_BR2_OPT below; r03-r04 shipped 14: bit 3 was worth 0.3 ms on the ten-barrier kernel, costs 0.25 ms for even
+// rotations today and still pays 0.2 ms in the mixing instantiation); the A/B numbers are in profiles/r05_experiments_blind_rotate.md,
 // everything else tried on this kernel in profiles/r02_… and r03_experiments_blind_rotate.md.
 // Which transform pair each of the three pairs of a step uses (spf_device.hpp; all give the same words), per instantiation:
 // E = even rotations (circuit bootstrap), M = mixing (plain PBS); 0 / 1 = polynomial 0's / 1's forward pair, I = the inverse pair.
