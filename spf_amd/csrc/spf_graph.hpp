@@ -25,14 +25,20 @@
 struct spf_pinned_buf {
     uint8_t* p = nullptr;
     size_t n = 0;
+    bool pinned = false;
     uint8_t* data() const { return p; }
     bool resize(size_t bytes)
     {
-        if (p) (void)hipHostFree(p);
+        if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
         p = nullptr;
         n = 0;
         if (!bytes) return true;
-        if (hipHostMalloc((void**)&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        pinned = hipHostMalloc((void**)&p, bytes, hipHostMallocDefault) == hipSuccess;
+        if (!pinned) { // (no pinned memory left for a very large graph: pageable still works, the copies are just staged by the runtime)
+            (void)hipGetLastError();
+            p = static_cast<uint8_t*>(std::malloc(bytes));
+            if (!p) return false;
+        }
         std::memset(p, 0, bytes);
         n = bytes;
         return true;
@@ -337,7 +343,7 @@ inline spf_status plan(spf_graph* g)
             if (is_cmux_family(gr.op)) hist[gr.members.size() * (gr.op == SPF_OP_GLEV_CMUX ? g->prm.cbs_radix_count : 1)]++;
         for (auto& kv : hist) fprintf(stderr, "[graph widths] %zu units x %zu launches\n", kv.first, kv.second);
     }
-    if (!g->h_inputs.resize(g->inputs_bytes)) return fail(c, SPF_ERR_HIP, "graph: no pinned host memory for the inputs");
+    if (!g->h_inputs.resize(g->inputs_bytes)) return fail(c, SPF_ERR_HIP, "graph: out of host memory for the inputs");
     g->planned = true;
     return SPF_OK;
 }
@@ -439,7 +445,7 @@ inline spf_status plan_outputs(spf_graph* g)
         HIPCHK(c, hipMalloc((void**)&g->d_out_stage, off));
         HIPCHK(c, hipMalloc((void**)&g->d_out_ptrs, table.size() * sizeof(void*)));
         HIPCHK(c, hipMemcpy(g->d_out_ptrs, table.data(), table.size() * sizeof(void*), hipMemcpyHostToDevice));
-        if (!g->h_out_stage.resize(off)) return fail(c, SPF_ERR_HIP, "graph: no pinned host memory for the outputs");
+        if (!g->h_out_stage.resize(off)) return fail(c, SPF_ERR_HIP, "graph: out of host memory for the outputs");
     }
     g->outputs_planned = g->outputs.size();
     return SPF_OK;
