@@ -243,6 +243,28 @@ spf_status spf_glev_cmux_dev(spf_ctx *ctx, void *stream, size_t B, const double 
 spf_status spf_multiply_glwe_ggsw_dev(spf_ctx *ctx, void *stream, size_t B, const uint64_t *d_glwe,
                                       const double *d_ggsw_fft, uint64_t *d_out);
 
+/* ciphertext types (`L0LweCiphertext` ... `L1GlevCiphertext`, crypto/encryption.rs:23-110) and the computing variants of `FheOp`
+ * (fhe_circuit.rs:65-126): used by the values, the pool's generic submit and the gate graphs below */
+typedef enum spf_value_kind {
+    SPF_VAL_LWE0 = 0,  /* L0LweCiphertext: n+1 words */
+    SPF_VAL_LWE1 = 1,  /* L1LweCiphertext: k*N+1 words */
+    SPF_VAL_GLWE1 = 2, /* L1GlweCiphertext: (k+1)*N words */
+    SPF_VAL_GGSW1 = 3, /* L1GgswCiphertext, FFT domain: (k+1)*l_cbs*(k+1)*N/2 complex */
+    SPF_VAL_GLEV1 = 4  /* L1GlevCiphertext: l_cbs GLWEs */
+} spf_value_kind;
+typedef enum spf_graph_op {
+    SPF_OP_SAMPLE_EXTRACT = 0,
+    SPF_OP_KEYSWITCH_L1_TO_L0 = 1,
+    SPF_OP_NOT = 2,
+    SPF_OP_GLWE_ADD = 3,
+    SPF_OP_CMUX = 4,
+    SPF_OP_GLEV_CMUX = 5,
+    SPF_OP_MULTIPLY_GGSW_GLWE = 6,
+    SPF_OP_CIRCUIT_BOOTSTRAP = 7,
+    SPF_OP_SCHEME_SWITCH = 8,
+    SPF_OP_MUL_XN = 9
+} spf_graph_op;
+
 /* ---- call coalescing: many threads, one ciphertext each -> one batch per launch ----------
  * The reference calls `Evaluation` from many rayon workers with a single ciphertext per call
  * (circuit_processor/mod.rs:192-253).  A pool keeps that calling convention — submit, then wait like the synchronous call it
@@ -301,6 +323,90 @@ spf_status spf_pool_set_max_inflight(spf_pool *pool, size_t max_inflight);
 /* operations completed and batches launched so far (ops / launches = achieved batch size) */
 spf_status spf_pool_stats(spf_pool *pool, uint64_t *ops, uint64_t *launches);
 
+/* counters of a pool (sums over the members of a group pool) */
+typedef struct spf_pool_counters {
+    uint64_t ops, launches;                  /* as spf_pool_stats: operations completed, batches launched (both forms) */
+    uint64_t handle_ops, handle_launches;    /* ... of which by handle */
+    uint64_t reclaimed;                      /* outputs a pool thread delivered on behalf of a caller that never collected them */
+    uint64_t bootstrap_launches_by_shape[3]; /* circuit-bootstrap batches by blind-rotation shape: eight waves per ciphertext
+                                              * (blind_rotate8), two ciphertexts per workgroup (2p2), four (2p) */
+    uint64_t staging_sets;                   /* staging sets per pool (a caller may leave that many batches uncollected) */
+    uint64_t value_mallocs;                  /* hipMalloc calls of the value arena so far (steady state: no growth) */
+} spf_pool_counters;
+spf_status spf_pool_counters_get(spf_pool *pool, spf_pool_counters *out);
+
+/* ---- device-resident values: the per-operation boundary without PCIe (SURVEY.md §8 b / f3) ---------------------------- *
+ *
+ * `CircuitProcessor::exec_op` calls `Evaluation` once per `FheOp` (circuit_processor/mod.rs:255-540) with ciphertexts that
+ * live in host memory (crypto/encryption.rs:143-165); the GGSW a `CircuitBootstrap` produces is consumed by the ~45 CMux
+ * gates behind it (fhe_circuit.rs:473-494).  Through the host-pointer submits above every operand and result crosses PCIe on
+ * every call (a CMux: 256 KiB + 2 x 32 KiB in, 32 KiB out).  A *value* is a reference-counted ciphertext in the HBM of one
+ * context; the `_v` submits take values and return a value, and nothing crosses PCIe until spf_value_download.  A Rust shim
+ * keeps an `Option<SpfValue>` beside (or instead of) the host copy inside `L1GgswCiphertext` & co..
+ *
+ *   Lifetime: every value returned through an `out` parameter carries ONE reference owned by the caller; spf_value_release
+ *     drops it (spf_value_retain adds one).  The pool keeps operands alive while an operation that reads them is queued or
+ *     running, so a caller may release an operand right after the submit that used it.  Values may outlive their pool (their
+ *     memory is freed on release); they must not be USED with another pool.
+ *   Validity: a result value exists as soon as the submit returns, but becomes valid only when spf_pool_wait has returned
+ *     SPF_OK for its ticket — exactly when the reference's task output becomes visible to its dependents
+ *     (circuit_processor/mod.rs:214-246).  Using it earlier (or after a failed batch) is SPF_ERR_INVALID_ARGUMENT, never a
+ *     read of unfinished data.  It must be released in every case.
+ *   Placement: a value lives on ONE member of a group pool (member 0 of a plain pool).  `member` < 0 in spf_value_upload /
+ *     spf_value_trivial = the calling thread's home member (as the host-pointer submits deal their callers); an operation
+ *     runs on the member its operands live on, its result stays there; operands on different members are
+ *     SPF_ERR_INVALID_ARGUMENT — spf_value_copy_to_member makes a copy on another member (peer copy over xGMI).
+ *   Memory: the results of one batch share one block of the pool's arena (the kernels write consecutive rows); the block is
+ *     reused when its last value is released, so a value pins the block of its batch mates.  Blocks are cached (never
+ *     hipFree'd on the steady-state path: hipFree waits for the whole device); spf_pool_trim gives the cache back to the
+ *     driver, spf_pool_value_stats reports live values, live bytes (blocks handed out) and cached bytes.
+ *     Environment: SPF_VALUE_CACHE_MB bounds the cache (default 32768). */
+typedef struct spf_value spf_value;
+/* host -> HBM: `host` holds one ciphertext of `kind` in the layout of the conventions above (spf_ciphertext_words(kind) u64
+ * words; SPF_VAL_GGSW1: (k+1)*l_cbs*(k+1)*N/2 complex) */
+spf_status spf_value_upload(spf_pool *pool, int member, spf_value_kind kind, const void *host, spf_value **out);
+/* FheOp::{Zero,One}{Lwe0,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116; also LWE1) as values: the trivial encryption of `bit`; the
+ * GGSW constants are `Evaluation::l1ggsw_zero / l1ggsw_one` (crypto/evaluation.rs:254-262) and need all four keys */
+spf_status spf_value_trivial(spf_pool *pool, int member, spf_value_kind kind, uint64_t bit, spf_value **out);
+/* HBM -> host (blocking); `host` has room for the kind's words */
+spf_status spf_value_download(const spf_value *value, void *host);
+spf_status spf_value_retain(spf_value *value);
+void spf_value_release(spf_value *value);
+/* any of the out pointers may be NULL */
+spf_status spf_value_info(const spf_value *value, spf_value_kind *kind, size_t *bytes, int *member, int *valid);
+/* the device address of a valid value, for a caller that chains the `_dev` entry points on the member's context
+ * (spf_group_ctx); stays valid while the caller holds its reference */
+spf_status spf_value_device_ptr(const spf_value *value, void **dev_ptr);
+/* a copy of a valid value on `member` of the group pool (device-to-device on the same GPU, peer copy otherwise; blocking) */
+spf_status spf_value_copy_to_member(spf_pool *pool, const spf_value *value, int member, spf_value **out);
+spf_status spf_pool_value_stats(spf_pool *pool, size_t *live_values, size_t *live_bytes, size_t *cached_bytes);
+spf_status spf_pool_trim(spf_pool *pool);
+
+/* The pool's submits by handle: same operations, same batching, same spf_pool_wait as the host-pointer forms above; operands
+ * are valid values of this pool, *out receives the result value (see Validity).  Batches by handle never mix with host-pointer
+ * callers.  No staging, no copies: the CMUX family reads its operands where they are, the other kinds pack theirs on the device
+ * (gather_rows_kernel) unless they already lie consecutively. */
+spf_status spf_pool_submit_keyswitch_v(spf_pool *pool, const spf_value *lwe1, spf_value **lwe0_out, uint64_t *ticket);
+spf_status spf_pool_submit_circuit_bootstrap_v(spf_pool *pool, const spf_value *lwe0, spf_value **ggsw_out, uint64_t *ticket);
+spf_status spf_pool_submit_keyswitch_circuit_bootstrap_v(spf_pool *pool, const spf_value *lwe1, spf_value **ggsw_out,
+                                                         uint64_t *ticket);
+spf_status spf_pool_submit_cmux_v(spf_pool *pool, const spf_value *sel_ggsw, const spf_value *a, const spf_value *b,
+                                  spf_value **out, uint64_t *ticket);
+spf_status spf_pool_submit_sample_extract_v(spf_pool *pool, const spf_value *glwe, size_t idx, spf_value **lwe1_out,
+                                            uint64_t *ticket);
+spf_status spf_pool_submit_not_v(spf_pool *pool, const spf_value *glwe, spf_value **out, uint64_t *ticket);
+spf_status spf_pool_submit_glwe_add_v(spf_pool *pool, const spf_value *a, const spf_value *b, spf_value **out, uint64_t *ticket);
+spf_status spf_pool_submit_mul_xn_v(spf_pool *pool, const spf_value *glwe, size_t n, spf_value **out, uint64_t *ticket);
+spf_status spf_pool_submit_multiply_ggsw_glwe_v(spf_pool *pool, const spf_value *ggsw, const spf_value *glwe, spf_value **out,
+                                                uint64_t *ticket);
+spf_status spf_pool_submit_glev_cmux_v(spf_pool *pool, const spf_value *sel_ggsw, const spf_value *a, const spf_value *b,
+                                       spf_value **glev_out, uint64_t *ticket);
+spf_status spf_pool_submit_scheme_switch_v(spf_pool *pool, const spf_value *glev, spf_value **ggsw_out, uint64_t *ticket);
+/* `exec_op`'s whole match in one entry (circuit_processor/mod.rs:255-540): the operation as a spf_graph_op, operands in the order
+ * spf_graph_add_op takes them (CMUX: selector, low, high), `param` = SampleExtract index / MulXN amount */
+spf_status spf_pool_submit_op_v(spf_pool *pool, spf_graph_op op, const spf_value *const *inputs, size_t n_inputs, uint64_t param,
+                                spf_value **out, uint64_t *ticket);
+
 /* ---- gate graphs: level-batched, device-resident execution ------------- *
  *
  * The counterpart of `FheCircuit` + `CircuitProcessor::run_graph_blocking`
@@ -321,25 +427,6 @@ spf_status spf_pool_stats(spf_pool *pool, uint64_t *ops, uint64_t *launches);
  * repeatedly with new input contents.  A graph is not thread-safe; distinct graphs on one
  * context may run from different threads (their launches serialise on the context's stream). */
 typedef struct spf_graph spf_graph;
-typedef enum spf_value_kind {
-    SPF_VAL_LWE0 = 0,  /* L0LweCiphertext: n+1 words */
-    SPF_VAL_LWE1 = 1,  /* L1LweCiphertext: k*N+1 words */
-    SPF_VAL_GLWE1 = 2, /* L1GlweCiphertext: (k+1)*N words */
-    SPF_VAL_GGSW1 = 3, /* L1GgswCiphertext, FFT domain: (k+1)*l_cbs*(k+1)*N/2 complex */
-    SPF_VAL_GLEV1 = 4  /* L1GlevCiphertext: l_cbs GLWEs */
-} spf_value_kind;
-typedef enum spf_graph_op {
-    SPF_OP_SAMPLE_EXTRACT = 0,
-    SPF_OP_KEYSWITCH_L1_TO_L0 = 1,
-    SPF_OP_NOT = 2,
-    SPF_OP_GLWE_ADD = 3,
-    SPF_OP_CMUX = 4,
-    SPF_OP_GLEV_CMUX = 5,
-    SPF_OP_MULTIPLY_GGSW_GLWE = 6,
-    SPF_OP_CIRCUIT_BOOTSTRAP = 7,
-    SPF_OP_SCHEME_SWITCH = 8,
-    SPF_OP_MUL_XN = 9
-} spf_graph_op;
 spf_status spf_graph_create(spf_ctx *ctx, spf_graph **out);
 void spf_graph_destroy(spf_graph *graph);
 /* FheOp::Input{Lwe0,Lwe1,Glwe1,Ggsw1,Glev1} */

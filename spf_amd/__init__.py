@@ -13,11 +13,11 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .params import Params, DEFAULT_128  # noqa: F401,E402
-from ._ffi import (Engine, Group, Pool, SpfError, ciphertext_from_bincode, ciphertext_to_bincode, ciphertext_words,  # noqa: F401
+from ._ffi import (Engine, Group, Pool, SpfError, Value, ciphertext_from_bincode, ciphertext_to_bincode, ciphertext_words,  # noqa: F401
                    generate_lut, lib_path, load_library)
 from .evaluation import Evaluation, ComputeKey  # noqa: F401
-from .graph import FheCircuit, FheOp, ValueKind  # noqa: F401
+from .graph import FheCircuit, FheOp, RecordedCircuit, ValueKind  # noqa: F401
 from .build import build_library  # noqa: F401
 
-__all__ = ["Params", "DEFAULT_128", "Engine", "Group", "Pool", "SpfError", "Evaluation", "ComputeKey", "FheCircuit", "FheOp", "ValueKind",
+__all__ = ["Params", "DEFAULT_128", "Engine", "Group", "Pool", "Value", "SpfError", "Evaluation", "ComputeKey", "FheCircuit", "FheOp", "ValueKind", "RecordedCircuit",
            "build_library", "ciphertext_from_bincode", "ciphertext_to_bincode", "ciphertext_words", "generate_lut", "lib_path", "load_library"]

@@ -155,6 +155,30 @@ SYMBOLS = [
     ("spf_group_keyswitch_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_group_l1ggsw_constant", _I, [_P, _I, _P]),
     ("spf_pool_create_group", _I, [_P, _SZ, _U32, C.POINTER(_P)]),
+    # device-resident values and the pool's submits by handle
+    ("spf_pool_counters_get", _I, [_P, C.POINTER(_U64 * 10)]),
+    ("spf_value_upload", _I, [_P, _I, _I, _P, C.POINTER(_P)]),
+    ("spf_value_trivial", _I, [_P, _I, _I, _U64, C.POINTER(_P)]),
+    ("spf_value_download", _I, [_P, _P]),
+    ("spf_value_retain", _I, [_P]),
+    ("spf_value_release", None, [_P]),
+    ("spf_value_info", _I, [_P, C.POINTER(_I), C.POINTER(_SZ), C.POINTER(_I), C.POINTER(_I)]),
+    ("spf_value_device_ptr", _I, [_P, C.POINTER(_P)]),
+    ("spf_value_copy_to_member", _I, [_P, _P, _I, C.POINTER(_P)]),
+    ("spf_pool_value_stats", _I, [_P, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
+    ("spf_pool_trim", _I, [_P]),
+    ("spf_pool_submit_keyswitch_v", _I, [_P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_circuit_bootstrap_v", _I, [_P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_keyswitch_circuit_bootstrap_v", _I, [_P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_cmux_v", _I, [_P, _P, _P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_sample_extract_v", _I, [_P, _P, _SZ, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_not_v", _I, [_P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_glwe_add_v", _I, [_P, _P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_mul_xn_v", _I, [_P, _P, _SZ, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_multiply_ggsw_glwe_v", _I, [_P, _P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_glev_cmux_v", _I, [_P, _P, _P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_scheme_switch_v", _I, [_P, _P, C.POINTER(_P), C.POINTER(_U64)]),
+    ("spf_pool_submit_op_v", _I, [_P, _I, C.POINTER(_P), _SZ, _U64, C.POINTER(_P), C.POINTER(_U64)]),
 ]
 
 
@@ -789,3 +813,113 @@ class Pool:
         ops, launches = C.c_uint64(), C.c_uint64()
         self._lib.spf_pool_stats(self._h, C.byref(ops), C.byref(launches))
         return ops.value, launches.value
+
+    def counters(self) -> dict:
+        a = (C.c_uint64 * 10)()
+        self._ck(self._lib.spf_pool_counters_get(self._h, C.byref(a)), "spf_pool_counters_get")
+        return {"ops": a[0], "launches": a[1], "handle_ops": a[2], "handle_launches": a[3], "reclaimed": a[4],
+                "bootstrap_launches_by_shape": {"blind_rotate8": a[5], "blind_rotate2p2": a[6], "blind_rotate2p": a[7]},
+                "staging_sets": a[8], "value_mallocs": a[9]}
+
+    # -- device-resident values (spf_value_*): the operands and results of the `_v` submits ---------------------------------
+    def _ck(self, st: int, what: str):
+        if st != 0:
+            eng = self.engine.member(0) if isinstance(self.engine, Group) else self.engine
+            raise SpfError(st, f"{what}: " + (self._lib.spf_last_error(eng._h) or b"").decode())
+
+    _VALUE_DTYPE = {3: np.complex128}
+
+    def upload(self, kind: int, array: np.ndarray, member: int = -1) -> "Value":
+        P = self.engine.params
+        words = {0: P.lwe0_words, 1: P.lwe1_words, 2: P.glwe_words, 3: 2 * P.cbs_ggsw_complex, 4: P.cbs_radix_count * P.glwe_words}[int(kind)]
+        a = np.ascontiguousarray(array)
+        if a.nbytes != words * 8:
+            raise SpfError(1, f"value of kind {int(kind)} must have {words * 8} bytes, got {a.nbytes}")
+        h = C.c_void_p()
+        self._ck(self._lib.spf_value_upload(self._h, member, int(kind), _ptr(a), C.byref(h)), "spf_value_upload")
+        return Value(self, h)
+
+    def trivial(self, kind: int, bit: int, member: int = -1) -> "Value":
+        h = C.c_void_p()
+        self._ck(self._lib.spf_value_trivial(self._h, member, int(kind), int(bit), C.byref(h)), "spf_value_trivial")
+        return Value(self, h)
+
+    def copy_to_member(self, value: "Value", member: int) -> "Value":
+        h = C.c_void_p()
+        self._ck(self._lib.spf_value_copy_to_member(self._h, value._h, member, C.byref(h)), "spf_value_copy_to_member")
+        return Value(self, h)
+
+    def submit_v(self, op: int, inputs, param: int = 0):
+        """`spf_pool_submit_op_v`: op is a spf_graph_op (spf_amd.FheOp); returns (result value, ticket) — the value is valid
+        once wait(ticket) has returned"""
+        arr = (C.c_void_p * len(inputs))(*[v._h for v in inputs])
+        h, t = C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.spf_pool_submit_op_v(self._h, int(op), arr, len(inputs), int(param), C.byref(h), C.byref(t)), "spf_pool_submit_op_v")
+        return Value(self, h), t.value
+
+    def run_v(self, op: int, inputs, param: int = 0) -> "Value":
+        v, t = self.submit_v(op, inputs, param)
+        try:
+            self._wait(t)
+        except SpfError:
+            v.release()
+            raise
+        return v
+
+    def keyswitch_circuit_bootstrap_v(self, lwe1: "Value") -> "Value":
+        h, t = C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.spf_pool_submit_keyswitch_circuit_bootstrap_v(self._h, lwe1._h, C.byref(h), C.byref(t)),
+                 "spf_pool_submit_keyswitch_circuit_bootstrap_v")
+        v = Value(self, h)
+        self._wait(t.value)
+        return v
+
+    def value_stats(self) -> dict:
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._ck(self._lib.spf_pool_value_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "spf_pool_value_stats")
+        return {"live_values": a.value, "live_bytes": b.value, "cached_bytes": c.value}
+
+    def trim(self):
+        self._ck(self._lib.spf_pool_trim(self._h), "spf_pool_trim")
+
+
+class Value:
+    """one device-resident ciphertext (`spf_value`): holds ONE reference, dropped by release() / garbage collection"""
+
+    def __init__(self, pool: Pool, handle):
+        self._pool = pool
+        self._lib = pool._lib
+        self._h = handle
+
+    def info(self) -> dict:
+        k, b, m, r = C.c_int(), C.c_size_t(), C.c_int(), C.c_int()
+        st = self._lib.spf_value_info(self._h, C.byref(k), C.byref(b), C.byref(m), C.byref(r))
+        if st != 0:
+            raise SpfError(st, "spf_value_info")
+        return {"kind": k.value, "bytes": b.value, "member": m.value, "valid": bool(r.value)}
+
+    def download(self) -> np.ndarray:
+        i = self.info()
+        out = np.empty(i["bytes"] // (16 if i["kind"] == 3 else 8), dtype=np.complex128 if i["kind"] == 3 else np.uint64)
+        st = self._lib.spf_value_download(self._h, _ptr(out))
+        if st != 0:
+            raise SpfError(st, "spf_value_download: the value is not valid (wait for its ticket first)")
+        return out
+
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        st = self._lib.spf_value_device_ptr(self._h, C.byref(p))
+        if st != 0:
+            raise SpfError(st, "spf_value_device_ptr: the value is not valid")
+        return p.value
+
+    def release(self):
+        if getattr(self, "_h", None):
+            self._lib.spf_value_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -1870,6 +1870,7 @@ static void scratch_free(Scratch& sc)
     }
 }
 
+#include "spf_values.hpp"
 #include "spf_pool.hpp"
 
 extern "C" {
@@ -1894,13 +1895,16 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the pool's streams");
     }
     try {
+        p->arena = std::make_shared<spf_value_impl::Arena>();
+        p->arena->device = c->device;
+        if (const char* e = getenv("SPF_VALUE_CACHE_MB")) p->arena->cache_limit = (size_t)std::max(0L, atol(e)) << 20;
         p->launcher = std::thread([p] {
             p->launch_loop();
             std::lock_guard<std::mutex> lk(p->mu);
             p->launcher_gone = true;
-            p->cv_flight.notify_all();
+            for (auto& cv : p->cv_fly) cv.notify_all();
         });
-        p->completer = std::thread([p] { p->complete_loop(); });
+        for (int i = 0; i < spf_pool_impl::kSets; i++) p->completers[i] = std::thread([p, i] { p->complete_loop(i); });
     } catch (const std::exception& e) { // std::system_error: no thread to be had — must not cross extern "C"
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -1908,8 +1912,10 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
             p->launcher_gone = !p->launcher.joinable();
         }
         p->cv_work.notify_all();
-        p->cv_flight.notify_all();
         if (p->launcher.joinable()) p->launcher.join();
+        for (auto& cv : p->cv_fly) cv.notify_all();
+        for (auto& t : p->completers)
+            if (t.joinable()) t.join();
         p->free_sets();
         (void)hipStreamDestroy(p->s_in);
         delete p;
@@ -1951,8 +1957,9 @@ void spf_pool_destroy(spf_pool* p)
     p->cv_space.notify_all();
     p->cv_set.notify_all();
     if (p->launcher.joinable()) p->launcher.join();
-    p->cv_flight.notify_all();
-    if (p->completer.joinable()) p->completer.join();
+    for (auto& cv : p->cv_fly) cv.notify_all();
+    for (auto& t : p->completers)
+        if (t.joinable()) t.join();
     {
         // nobody may still be inside submit() / spf_pool_wait() on the mutex and condition variables freed below
         std::unique_lock<std::mutex> lk(p->mu);
@@ -1963,6 +1970,7 @@ void spf_pool_destroy(spf_pool* p)
     }
     p->free_sets();
     (void)hipStreamDestroy(p->s_in);
+    if (p->arena) p->arena->close(); // cached blocks go back to the driver; values still alive free theirs when they are released
     delete p;
 }
 
@@ -2068,6 +2076,359 @@ spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
     std::lock_guard<std::mutex> lk(p->mu);
     *ops = p->n_ops; *launches = p->n_launches;
     return SPF_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------- values: device-resident operands of the per-operation boundary
+namespace {
+
+size_t value_bytes(const spf_params& p, int kind)
+{
+    const size_t k = p.glwe_size, N = p.polynomial_degree, l = p.cbs_radix_count;
+    switch (kind) {
+    case SPF_VAL_LWE0: return ((size_t)p.lwe_dimension + 1) * 8;
+    case SPF_VAL_LWE1: return (k * N + 1) * 8;
+    case SPF_VAL_GLWE1: return (k + 1) * N * 8;
+    case SPF_VAL_GGSW1: return (k + 1) * l * (k + 1) * (N / 2) * 16;
+    case SPF_VAL_GLEV1: return l * (k + 1) * N * 8;
+    default: return 0;
+    }
+}
+
+// operand kinds and result kind of a pool operation (the `FheOp` arms of circuit_processor/mod.rs:255-540)
+struct PoolOpInfo { int arity; int in_kind[3]; int out_kind; };
+bool pool_op_info(int op, PoolOpInfo* o)
+{
+    using namespace spf_pool_impl;
+    switch (op) {
+    case OP_KEYSWITCH: *o = {1, {SPF_VAL_LWE1, -1, -1}, SPF_VAL_LWE0}; return true;
+    case OP_CBS: *o = {1, {SPF_VAL_LWE0, -1, -1}, SPF_VAL_GGSW1}; return true;
+    case OP_GATE_CBS: *o = {1, {SPF_VAL_LWE1, -1, -1}, SPF_VAL_GGSW1}; return true;
+    case OP_CMUX: *o = {3, {SPF_VAL_GGSW1, SPF_VAL_GLWE1, SPF_VAL_GLWE1}, SPF_VAL_GLWE1}; return true;
+    case OP_SAMPLE_EXTRACT: *o = {1, {SPF_VAL_GLWE1, -1, -1}, SPF_VAL_LWE1}; return true;
+    case OP_NOT: case OP_MUL_XN: *o = {1, {SPF_VAL_GLWE1, -1, -1}, SPF_VAL_GLWE1}; return true;
+    case OP_GLWE_ADD: *o = {2, {SPF_VAL_GLWE1, SPF_VAL_GLWE1, -1}, SPF_VAL_GLWE1}; return true;
+    case OP_MULTIPLY_GGSW_GLWE: *o = {2, {SPF_VAL_GGSW1, SPF_VAL_GLWE1, -1}, SPF_VAL_GLWE1}; return true;
+    case OP_GLEV_CMUX: *o = {3, {SPF_VAL_GGSW1, SPF_VAL_GLEV1, SPF_VAL_GLEV1}, SPF_VAL_GLEV1}; return true;
+    case OP_SCHEME_SWITCH: *o = {1, {SPF_VAL_GLEV1, -1, -1}, SPF_VAL_GGSW1}; return true;
+    default: return false;
+    }
+}
+
+// the pool of one context that a value of `member` belongs to: the pool itself, or — a group pool — that member's pool
+// (member < 0: the calling thread's home member, dealt as for the host-pointer submits)
+spf_pool* value_pool(spf_pool* top, int member, int* which)
+{
+    *which = 0;
+    if (top->members.empty()) return (member <= 0) ? top : nullptr;
+    if (member < 0) return pool_deal(top, which);
+    if (member >= (int)top->members.size()) return nullptr;
+    *which = member;
+    return top->members[member];
+}
+
+spf_status pool_submit_v(spf_pool* top, int op, const spf_value* const* vals, size_t n_vals, uint64_t param, spf_value** out,
+                         uint64_t* ticket)
+{
+    if (!top || !out || !ticket || !vals) return SPF_ERR_INVALID_ARGUMENT;
+    PoolOpInfo info{};
+    if (!pool_op_info(op, &info) || n_vals != (size_t)info.arity) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: wrong number of operands");
+    spf_value* v[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < info.arity; k++) {
+        v[k] = const_cast<spf_value*>(vals[k]);
+        if (!v[k]) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: null operand");
+        if (v[k]->kind != info.in_kind[k]) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operand has the wrong ciphertext type");
+        if (!v[k]->ready())
+            return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operand is not valid (its producing operation has not been waited for, or failed)");
+        if (v[k]->home != v[0]->home)
+            return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operands live on different members of the group (spf_value_copy_to_member moves one)");
+    }
+    spf_pool* leaf = v[0]->home;
+    const int member = v[0]->member;
+    const bool mine = top->members.empty() ? leaf == top : (member >= 0 && member < (int)top->members.size() && top->members[member] == leaf);
+    if (!mine) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operand belongs to another pool");
+    spf_value* res = spf_value::make(leaf->arena, leaf, member, info.out_kind, value_bytes(leaf->prm, info.out_kind));
+    if (!res) return fail(leaf->ctx, SPF_ERR_HIP, "out of host memory");
+    const spf_status st = leaf->submit_v(op, v, res, ticket, param);
+    if (st != SPF_OK) {
+        res->release();
+        return st;
+    }
+    if (leaf != top) *ticket |= (uint64_t)member << spf_pool::kMemberShift;
+    *out = res;
+    return SPF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+spf_status spf_value_upload(spf_pool* p, int member, spf_value_kind kind, const void* host, spf_value** out)
+{
+    if (!p || !host || !out) return SPF_ERR_INVALID_ARGUMENT;
+    int which = 0;
+    spf_pool* leaf = value_pool(p, member, &which);
+    if (!leaf) return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_upload: no such member (or none in rotation)");
+    const size_t bytes = value_bytes(leaf->prm, kind);
+    if (!bytes) return fail(leaf->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_upload: unknown ciphertext kind");
+    spf_value* v = spf_value::make(leaf->arena, leaf, which, kind, bytes);
+    if (!v) return fail(leaf->ctx, SPF_ERR_HIP, "out of host memory");
+    v->blk = spf_value_impl::Block::make(leaf->arena, bytes);
+    if (!v->blk) {
+        v->release();
+        return fail(leaf->ctx, SPF_ERR_HIP, "spf_value_upload: out of device memory");
+    }
+    spf_value_impl::Arena::DeviceScope ds(leaf->ctx->device);
+    const hipError_t e = ds.ok ? hipMemcpy(v->ptr(), host, bytes, hipMemcpyHostToDevice) : hipErrorInvalidDevice;
+    if (e != hipSuccess) {
+        v->release();
+        return fail(leaf->ctx, SPF_ERR_HIP, std::string("spf_value_upload: ") + hipGetErrorString(e));
+    }
+    v->state.store(spf_value_impl::READY, std::memory_order_release);
+    *out = v;
+    return SPF_OK;
+}
+
+// FheOp::{Zero,One}{Lwe0,Lwe1,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116) as values
+spf_status spf_value_trivial(spf_pool* p, int member, spf_value_kind kind, uint64_t bit, spf_value** out)
+{
+    if (!p || !out || bit > 1) return SPF_ERR_INVALID_ARGUMENT;
+    int which = 0;
+    spf_pool* leaf = value_pool(p, member, &which);
+    if (!leaf) return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_trivial: no such member (or none in rotation)");
+    const spf_params& prm = leaf->prm;
+    const size_t bytes = value_bytes(prm, kind);
+    if (!bytes) return fail(leaf->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_trivial: unknown ciphertext kind");
+    if (kind != SPF_VAL_GGSW1) {
+        // trivial_lwe / trivial_glwe / trivial_glev of a bit (crypto/encryption.rs:345-451): zero mask, body (coefficient 0) =
+        // bit << 63, or bit * q / B^(j+1) for GLWE j of a GLEV — the same words spf_graph_add_trivial puts into a graph
+        std::vector<uint64_t> w;
+        try {
+            w.assign(bytes / 8, 0);
+        } catch (const std::exception&) {
+            return fail(leaf->ctx, SPF_ERR_HIP, "out of host memory");
+        }
+        const size_t k = prm.glwe_size, N = prm.polynomial_degree;
+        if (kind == SPF_VAL_GLEV1)
+            for (size_t j = 0; j < prm.cbs_radix_count; j++) w[j * (k + 1) * N + k * N] = bit << (64 - prm.cbs_radix_log * (j + 1));
+        else
+            w[kind == SPF_VAL_LWE0 ? prm.lwe_dimension : k * N] = bit << 63;
+        return spf_value_upload(p, which, kind, w.data(), out);
+    }
+    // l1ggsw_zero / l1ggsw_one: the context's circuit bootstraps of the trivial level-0 LWE (Evaluation::new, evaluation.rs:161-197)
+    spf_ctx* c = leaf->ctx;
+    spf_value* v = spf_value::make(leaf->arena, leaf, which, kind, bytes);
+    if (!v) return fail(c, SPF_ERR_HIP, "out of host memory");
+    v->blk = spf_value_impl::Block::make(leaf->arena, bytes);
+    if (!v->blk) {
+        v->release();
+        return fail(c, SPF_ERR_HIP, "spf_value_trivial: out of device memory");
+    }
+    spf_status st;
+    {
+        spf_value_impl::Arena::DeviceScope ds(c->device);
+        std::lock_guard<std::recursive_mutex> g(c->mu);
+        st = ds.ok ? ensure_ggsw_constants(c) : fail(c, SPF_ERR_HIP, "hipSetDevice failed");
+        if (st == SPF_OK && hipMemcpy(v->ptr(), (const char*)c->d_ggsw_const + (size_t)bit * bytes, bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+            st = fail(c, SPF_ERR_HIP, "spf_value_trivial: device copy failed");
+    }
+    if (st != SPF_OK) {
+        v->release();
+        return st;
+    }
+    v->state.store(spf_value_impl::READY, std::memory_order_release);
+    *out = v;
+    return SPF_OK;
+}
+
+spf_status spf_value_download(const spf_value* v, void* host)
+{
+    if (!v || !host || !v->ready()) return SPF_ERR_INVALID_ARGUMENT;
+    spf_value_impl::Arena::DeviceScope ds(v->arena->device);
+    if (!ds.ok || hipMemcpy(host, v->ptr(), v->bytes, hipMemcpyDeviceToHost) != hipSuccess) return SPF_ERR_HIP;
+    return SPF_OK;
+}
+
+spf_status spf_value_retain(spf_value* v)
+{
+    if (!v) return SPF_ERR_INVALID_ARGUMENT;
+    v->retain();
+    return SPF_OK;
+}
+
+void spf_value_release(spf_value* v)
+{
+    if (v) v->release();
+}
+
+spf_status spf_value_info(const spf_value* v, spf_value_kind* kind, size_t* bytes, int* member, int* ready)
+{
+    if (!v) return SPF_ERR_INVALID_ARGUMENT;
+    if (kind) *kind = (spf_value_kind)v->kind;
+    if (bytes) *bytes = v->bytes;
+    if (member) *member = v->member;
+    if (ready) *ready = v->ready() ? 1 : 0;
+    return SPF_OK;
+}
+
+spf_status spf_value_device_ptr(const spf_value* v, void** dev_ptr)
+{
+    if (!v || !dev_ptr || !v->ready()) return SPF_ERR_INVALID_ARGUMENT;
+    *dev_ptr = v->ptr();
+    return SPF_OK;
+}
+
+spf_status spf_value_copy_to_member(spf_pool* p, const spf_value* v, int member, spf_value** out)
+{
+    if (!p || !v || !out || !v->ready()) return SPF_ERR_INVALID_ARGUMENT;
+    int which = 0;
+    spf_pool* leaf = value_pool(p, member, &which);
+    if (!leaf || member < 0) return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_copy_to_member: no such member");
+    spf_value* w = spf_value::make(leaf->arena, leaf, which, v->kind, v->bytes);
+    if (!w) return fail(leaf->ctx, SPF_ERR_HIP, "out of host memory");
+    w->blk = spf_value_impl::Block::make(leaf->arena, v->bytes);
+    if (!w->blk) {
+        w->release();
+        return fail(leaf->ctx, SPF_ERR_HIP, "spf_value_copy_to_member: out of device memory");
+    }
+    spf_value_impl::Arena::DeviceScope ds(leaf->ctx->device);
+    const hipError_t e = !ds.ok ? hipErrorInvalidDevice
+                         : (v->arena->device == leaf->ctx->device ? hipMemcpy(w->ptr(), v->ptr(), v->bytes, hipMemcpyDeviceToDevice)
+                                                                  : hipMemcpyPeer(w->ptr(), leaf->ctx->device, v->ptr(), v->arena->device, v->bytes));
+    if (e != hipSuccess) {
+        w->release();
+        return fail(leaf->ctx, SPF_ERR_HIP, std::string("spf_value_copy_to_member: ") + hipGetErrorString(e));
+    }
+    w->state.store(spf_value_impl::READY, std::memory_order_release);
+    *out = w;
+    return SPF_OK;
+}
+
+spf_status spf_pool_value_stats(spf_pool* p, size_t* live_values, size_t* live_bytes, size_t* cached_bytes)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    size_t lv = 0, lb = 0, cb = 0;
+    auto add = [&](spf_pool* q) {
+        lv += q->arena->live_values.load();
+        lb += q->arena->live_bytes.load();
+        std::lock_guard<std::mutex> lk(q->arena->mu);
+        cb += q->arena->cached_bytes;
+    };
+    if (p->members.empty()) add(p);
+    else for (spf_pool* q : p->members) add(q);
+    if (live_values) *live_values = lv;
+    if (live_bytes) *live_bytes = lb;
+    if (cached_bytes) *cached_bytes = cb;
+    return SPF_OK;
+}
+
+spf_status spf_pool_trim(spf_pool* p)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    if (p->members.empty()) p->arena->trim();
+    else for (spf_pool* q : p->members) q->arena->trim();
+    return SPF_OK;
+}
+
+spf_status spf_pool_counters_get(spf_pool* p, spf_pool_counters* out)
+{
+    if (!p || !out) return SPF_ERR_INVALID_ARGUMENT;
+    *out = spf_pool_counters{};
+    auto add = [&](spf_pool* q) {
+        std::lock_guard<std::mutex> lk(q->mu);
+        out->ops += q->n_ops; out->launches += q->n_launches;
+        out->handle_ops += q->n_handle_ops; out->handle_launches += q->n_handle_launches;
+        out->reclaimed += q->n_reclaimed;
+        for (int i = 0; i < 3; i++) out->bootstrap_launches_by_shape[i] += q->n_shape[i];
+        out->staging_sets = spf_pool_impl::kSets;
+        out->value_mallocs += q->arena->n_malloc.load();
+    };
+    if (p->members.empty()) add(p);
+    else for (spf_pool* q : p->members) add(q);
+    return SPF_OK;
+}
+
+// ---- the pool's submits by handle
+spf_status spf_pool_submit_keyswitch_v(spf_pool* p, const spf_value* lwe1, spf_value** lwe0_out, uint64_t* ticket)
+{
+    return pool_submit_v(p, spf_pool_impl::OP_KEYSWITCH, &lwe1, 1, 0, lwe0_out, ticket);
+}
+spf_status spf_pool_submit_circuit_bootstrap_v(spf_pool* p, const spf_value* lwe0, spf_value** ggsw_out, uint64_t* ticket)
+{
+    return pool_submit_v(p, spf_pool_impl::OP_CBS, &lwe0, 1, 0, ggsw_out, ticket);
+}
+spf_status spf_pool_submit_keyswitch_circuit_bootstrap_v(spf_pool* p, const spf_value* lwe1, spf_value** ggsw_out, uint64_t* ticket)
+{
+    return pool_submit_v(p, spf_pool_impl::OP_GATE_CBS, &lwe1, 1, 0, ggsw_out, ticket);
+}
+spf_status spf_pool_submit_cmux_v(spf_pool* p, const spf_value* sel, const spf_value* a, const spf_value* b, spf_value** out,
+                                  uint64_t* ticket)
+{
+    const spf_value* v[3] = {sel, a, b};
+    return pool_submit_v(p, spf_pool_impl::OP_CMUX, v, 3, 0, out, ticket);
+}
+spf_status spf_pool_submit_sample_extract_v(spf_pool* p, const spf_value* glwe, size_t idx, spf_value** lwe1_out, uint64_t* ticket)
+{
+    if (!p || idx >= p->prm.polynomial_degree) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit_v(p, spf_pool_impl::OP_SAMPLE_EXTRACT, &glwe, 1, idx, lwe1_out, ticket);
+}
+spf_status spf_pool_submit_not_v(spf_pool* p, const spf_value* glwe, spf_value** out, uint64_t* ticket)
+{
+    return pool_submit_v(p, spf_pool_impl::OP_NOT, &glwe, 1, 0, out, ticket);
+}
+spf_status spf_pool_submit_glwe_add_v(spf_pool* p, const spf_value* a, const spf_value* b, spf_value** out, uint64_t* ticket)
+{
+    const spf_value* v[2] = {a, b};
+    return pool_submit_v(p, spf_pool_impl::OP_GLWE_ADD, v, 2, 0, out, ticket);
+}
+spf_status spf_pool_submit_mul_xn_v(spf_pool* p, const spf_value* glwe, size_t n, spf_value** out, uint64_t* ticket)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    return pool_submit_v(p, spf_pool_impl::OP_MUL_XN, &glwe, 1, n % (2 * (size_t)p->prm.polynomial_degree), out, ticket);
+}
+spf_status spf_pool_submit_multiply_ggsw_glwe_v(spf_pool* p, const spf_value* ggsw, const spf_value* glwe, spf_value** out,
+                                                uint64_t* ticket)
+{
+    const spf_value* v[2] = {ggsw, glwe};
+    return pool_submit_v(p, spf_pool_impl::OP_MULTIPLY_GGSW_GLWE, v, 2, 0, out, ticket);
+}
+spf_status spf_pool_submit_glev_cmux_v(spf_pool* p, const spf_value* sel, const spf_value* a, const spf_value* b, spf_value** out,
+                                       uint64_t* ticket)
+{
+    const spf_value* v[3] = {sel, a, b};
+    return pool_submit_v(p, spf_pool_impl::OP_GLEV_CMUX, v, 3, 0, out, ticket);
+}
+spf_status spf_pool_submit_scheme_switch_v(spf_pool* p, const spf_value* glev, spf_value** ggsw_out, uint64_t* ticket)
+{
+    return pool_submit_v(p, spf_pool_impl::OP_SCHEME_SWITCH, &glev, 1, 0, ggsw_out, ticket);
+}
+
+// one entry for `exec_op`'s whole match (circuit_processor/mod.rs:255-540): the operation as a spf_graph_op, operands in the
+// order spf_graph_add_op takes them
+spf_status spf_pool_submit_op_v(spf_pool* p, spf_graph_op op, const spf_value* const* inputs, size_t n_inputs, uint64_t param,
+                                spf_value** out, uint64_t* ticket)
+{
+    using namespace spf_pool_impl;
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    int pop;
+    switch (op) {
+    case SPF_OP_SAMPLE_EXTRACT:
+        if (param >= p->prm.polynomial_degree) return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "sample_extract index >= polynomial_degree");
+        pop = OP_SAMPLE_EXTRACT;
+        break;
+    case SPF_OP_KEYSWITCH_L1_TO_L0: pop = OP_KEYSWITCH; param = 0; break;
+    case SPF_OP_NOT: pop = OP_NOT; param = 0; break;
+    case SPF_OP_GLWE_ADD: pop = OP_GLWE_ADD; param = 0; break;
+    case SPF_OP_CMUX: pop = OP_CMUX; param = 0; break;
+    case SPF_OP_GLEV_CMUX: pop = OP_GLEV_CMUX; param = 0; break;
+    case SPF_OP_MULTIPLY_GGSW_GLWE: pop = OP_MULTIPLY_GGSW_GLWE; param = 0; break;
+    case SPF_OP_CIRCUIT_BOOTSTRAP: pop = OP_CBS; param = 0; break;
+    case SPF_OP_SCHEME_SWITCH: pop = OP_SCHEME_SWITCH; param = 0; break;
+    case SPF_OP_MUL_XN: pop = OP_MUL_XN; param %= 2 * (uint64_t)p->prm.polynomial_degree; break;
+    default: return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "unknown operation");
+    }
+    return pool_submit_v(p, pop, inputs, n_inputs, param, out, ticket);
 }
 
 } // extern "C"

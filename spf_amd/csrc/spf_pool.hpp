@@ -33,6 +33,14 @@
 // in the pool (or everybody who can come is there), every batch is launched with the workgroup shape the WHOLE population would
 // get (one / two / four ciphertexts per workgroup: launch_blind_rotate's per_wg_hint), so that up to four batches tile the CUs
 // side by side, each on its set's stream: while one group copies out and comes back, the others compute.
+// r06: operations BY HANDLE (spf_values.hpp).  The same submit / wait convention with device-resident operands and result:
+// a handle batch has no staging copies at all — the launcher writes one pointer row per operand into the set's pinned table,
+// the CMUX family reads its operands where their producers left them (`CmuxArgs::ptrs`), the small operands of the other kinds
+// are packed by `gather_rows_kernel` unless they already lie consecutively (a keyswitch batch feeding a circuit-bootstrap
+// batch), and the outputs of the batch are ONE block of the pool's arena that the result values view.  Handle batches use
+// lanes of their own (they never mix with host-pointer callers); the cheap kinds take ONE caller group and no pacing — a
+// 15 us CMUX level gains nothing from four resident batches.  Completion is per staging set (one completer thread each), so
+// a CMUX batch that finishes in 15 us is handed back at once although a 4 ms bootstrap batch was enqueued before it.
 // Errors follow the reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters.
 #pragma once
 #include "../../include/spf_hip.h"
@@ -50,6 +58,7 @@
 #include <exception>
 #include <memory>
 #include <pthread.h>
+#include <sys/prctl.h>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -65,6 +74,10 @@ enum Op {
     OP_SAMPLE_EXTRACT = 4, OP_NOT = 5, OP_GLWE_ADD = 6, OP_MUL_XN = 7, OP_MULTIPLY_GGSW_GLWE = 8, OP_GLEV_CMUX = 9, OP_SCHEME_SWITCH = 10,
     N_OPS = 11
 };
+// the kinds whose batches are worth keeping resident side by side (milliseconds on the GPU): caller groups, pacing and the
+// "previous batch still out" rule apply to these; everything else is microseconds per launch
+inline bool heavy(int op) { return op == OP_CBS || op == OP_GATE_CBS; }
+inline bool cmux_family(int op) { return op == OP_CMUX || op == OP_GLEV_CMUX || op == OP_MULTIPLY_GGSW_GLWE; }
 constexpr int kMaxGroups = 4;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
 constexpr int kSets = 2 * kMaxGroups; // per group one batch in flight / being collected and one filling
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
@@ -75,6 +88,8 @@ struct Slot {
     uint8_t delivered; // 0: output still in the staging set; 1: being copied to `out` by reclaim() on the owner's behalf (the lock is
                        // dropped for the copy: a wait() that arrives meanwhile parks on cv_deliver); 2: in `out`
     uintptr_t who;  // the submitting thread (see `last_members`)
+    spf_value* vin[3]; // by handle: the operands (retained until the batch has run) ...
+    spf_value* vout;   // ... and the result (the batch's own reference; the caller holds another)
 };
 
 struct Staging {
@@ -83,7 +98,9 @@ struct Staging {
     void* d_in[3] = {nullptr, nullptr, nullptr};
     void* d_out = nullptr;
     void* d_mid = nullptr;
-    size_t cap_in[3] = {0, 0, 0}, cap_out = 0, cap_mid = 0;
+    void** h_ptrs = nullptr;  // by handle: pinned pointer table the kernels read (operand rows / CMUX units)
+    size_t cap_in[3] = {0, 0, 0}, cap_out = 0, cap_mid = 0, cap_ptrs = 0; // host buffers (bytes; cap_ptrs in pointers)
+    size_t dcap_in[3] = {0, 0, 0}, dcap_out = 0;                          // device buffers (bytes)
     bool busy = false;
     hipStream_t sk = nullptr; // this set's kernels (created with the pool)
     Scratch scr;              // ... and their intermediates
@@ -100,7 +117,9 @@ inline void futex_wake_all(std::atomic<uint32_t>* w)
 }
 
 struct Batch {
-    int op = 0, set = 0, lane = 0; // lane = op * kMaxGroups + caller group
+    int op = 0, set = 0, lane = 0; // lane = ((by handle ? N_OPS : 0) + op) * kMaxGroups + caller group
+    bool by_handle = false;
+    std::shared_ptr<spf_value_impl::Block> out_blk; // by handle: the outputs of the batch
     size_t cap = 0;               // slots of this batch
     size_t n = 0, n_ready = 0;    // slots taken / inputs copied in
     size_t n_collected = 0;
@@ -168,31 +187,40 @@ struct spf_pool {
     size_t max_batch = 4096;
     std::chrono::microseconds max_wait{200};
     std::mutex mu;
-    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_flight, cv_deliver;
-    static constexpr int kLanes = spf_pool_impl::N_OPS * spf_pool_impl::kMaxGroups;
+    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_deliver;
+    static constexpr int kKinds = 2 * spf_pool_impl::N_OPS; // host-pointer kinds, then the same by handle
+    static constexpr int kLanes = kKinds * spf_pool_impl::kMaxGroups;
+    static int lane_of(int op, bool by_handle, int grp) { return ((by_handle ? spf_pool_impl::N_OPS : 0) + op) * spf_pool_impl::kMaxGroups + grp; }
+    std::shared_ptr<spf_value_impl::Arena> arena;                                   // device memory of the values (spf_values.hpp)
     std::shared_ptr<Batch> filling[kLanes];                                           // per (operation kind, caller group)
     std::unordered_map<uintptr_t, size_t> home_group;                               // calling thread -> its arrival number (group = arrival % groups: sticky)
     size_t next_group = 0;
     std::unordered_map<uintptr_t, int> open_by_thread;                              // submitting thread -> its open tickets
     std::deque<std::shared_ptr<Batch>> closing;                                     // closed, waiting for their members' input copies
-    std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, waited for by the completer
+    std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, each waited for by its set's completer
     std::deque<std::shared_ptr<Batch>> collecting;                                  // done, not yet fully collected
     std::unordered_map<uint64_t, std::pair<std::shared_ptr<Batch>, size_t>> tickets; // open tickets -> (batch, slot)
     std::unordered_set<uint64_t> claimed; // tickets some thread is already waiting for (a ticket has ONE waiter)
     size_t blocked = 0;                   // callers inside submit() / wait(): destroy waits until they have left
     size_t space_waiters = 0, set_waiters = 0; // submitters parked on back-pressure / on a staging set
     size_t max_inflight = 16384;          // submit blocks while this many tickets are open (back-pressure)
+    size_t heavy_open = 0;                // open tickets of the bootstrap kinds: the population that shapes their batches
     size_t groups = 0;                    // caller groups in use: 0 = by population (groups_now), else SPF_POOL_GROUPS = 1 .. kMaxGroups
     int pace_div = 0;                     // pacing: a batch starts no sooner than 1 / pace_div of a batch's GPU time after the previous one (0 = groups; SPF_POOL_PACE)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
     bool stop = false;
-    std::thread launcher, completer;
+    std::thread launcher, completers[spf_pool_impl::kSets];
     spf_pool_impl::Staging sets[spf_pool_impl::kSets];
+    std::shared_ptr<Batch> flying[spf_pool_impl::kSets]; // the enqueued batch of each set (one at most)
+    std::condition_variable cv_fly[spf_pool_impl::kSets];
+    uint64_t n_reclaimed = 0;             // outputs delivered on their owners' behalf (reclaim)
+    uint64_t n_handle_ops = 0, n_handle_launches = 0;
+    uint64_t n_shape[3] = {0, 0, 0};      // bootstrap launches by blind-rotation shape: eight waves per ciphertext / two / four per workgroup
     hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
     std::vector<uintptr_t> last_members[kLanes]; // threads of the most recently finished batch of a lane, sorted
-    size_t cap_hint[spf_pool_impl::N_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
+    size_t cap_hint[kKinds] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
                                                               // (pinned staging is sized by what the callers actually produce:
                                                               // 2048 slots of 256 KiB would pin 0.5 GiB per set up front)
     bool preparing[kLanes] = {}; // a submitter is allocating a set for this lane (lock dropped)
@@ -243,31 +271,47 @@ struct spf_pool {
         cap = bytes;
         return true;
     }
-    static bool grow_dev(void*& p, size_t have, size_t bytes)
+    // (the new buffer first, the old one freed afterwards: a failed allocation leaves the pointer and its capacity as they were)
+    static bool grow_dev(void*& p, size_t& have, size_t bytes)
     {
         if (have >= bytes) return true;
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         if (p) (void)hipFree(p);
-        p = nullptr;
-        return hipMalloc(&p, bytes) == hipSuccess;
+        p = q;
+        have = bytes;
+        return true;
     }
-    bool prepare_set(spf_pool_impl::Staging& s, int op, size_t cap)
+    // pointers of a handle batch's table: one row of `cap` per operand, or four per CMUX unit
+    size_t table_pointers(int op, size_t cap) const
+    {
+        return spf_pool_impl::cmux_family(op) ? 4 * cap * (op == spf_pool_impl::OP_GLEV_CMUX ? prm.cbs_radix_count : 1) + 3 * cap : 3 * cap;
+    }
+    bool prepare_set(spf_pool_impl::Staging& s, int op, size_t cap, bool by_handle)
     {
         size_t in[3], out;
         in_out_sizes(op, in, out);
         if (hipSetDevice(ctx->device) != hipSuccess) return false;
         for (int k = 0; k < 3; k++) {
             if (!in[k]) continue;
-            const size_t had = s.cap_in[k];
-            if (!grow_dev(s.d_in[k], had, cap * in[k])) return false; // (device first: cap_in is updated by grow_host)
-            if (!grow_host(s.h_in[k], s.cap_in[k], cap * in[k])) return false;
+            if (by_handle && scattered_cmux(op)) continue; // read in place through the pointer table
+            if (!grow_dev(s.d_in[k], s.dcap_in[k], cap * in[k])) return false;
+            if (!by_handle && !grow_host(s.h_in[k], s.cap_in[k], cap * in[k])) return false;
         }
-        const size_t had_out = s.cap_out;
-        if (!grow_dev(s.d_out, had_out, cap * out)) return false;
-        if (!grow_host(s.h_out, s.cap_out, cap * out)) return false;
-        if (op == spf_pool_impl::OP_GATE_CBS && s.cap_mid < cap * lwe0_bytes()) {
-            if (!grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
-            s.cap_mid = cap * lwe0_bytes();
+        if (by_handle) {
+            size_t bytes = s.cap_ptrs * sizeof(void*);
+            void* p = s.h_ptrs;
+            if (!grow_host(p, bytes, table_pointers(op, cap) * sizeof(void*))) { s.h_ptrs = nullptr; s.cap_ptrs = 0; return false; }
+            s.h_ptrs = static_cast<void**>(p);
+            s.cap_ptrs = bytes / sizeof(void*);
+        } else {
+            if (!grow_dev(s.d_out, s.dcap_out, cap * out)) return false;
+            if (!grow_host(s.h_out, s.cap_out, cap * out)) return false;
         }
+        if (op == spf_pool_impl::OP_GATE_CBS && !grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
         if ((op == spf_pool_impl::OP_KEYSWITCH || op == spf_pool_impl::OP_CBS || op == spf_pool_impl::OP_GATE_CBS) && s.scr_cap < cap) {
             if (scratch_reserve(ctx, s.scr, cap, true, true) != SPF_OK) return false; // (both: the set serves any kind later)
             s.scr_cap = cap;
@@ -285,6 +329,7 @@ struct spf_pool {
             if (s.h_out) (void)hipHostFree(s.h_out);
             if (s.d_out) (void)hipFree(s.d_out);
             if (s.d_mid) (void)hipFree(s.d_mid);
+            if (s.h_ptrs) (void)hipHostFree(s.h_ptrs);
             scratch_free(s.scr);
             if (s.sk) (void)hipStreamDestroy(s.sk);
             s = spf_pool_impl::Staging{};
@@ -310,10 +355,30 @@ struct spf_pool {
         }
     }
 
+    // the CMUX family reads scattered operands in place where the tuned kernels serve the parameter set (CmuxArgs::ptrs);
+    // elsewhere (generic family, another cbs radix) its operands are packed like everybody else's
+    bool scattered_cmux(int op) const
+    {
+        return spf_pool_impl::cmux_family(op) && !ctx->generic && prm.cbs_radix_log == 4 && prm.cbs_radix_count == 4;
+    }
+
     spf_status submit(int op, const void* a, const void* b_in, const void* c, void* out, uint64_t* ticket, uint64_t param = 0)
     {
-        using namespace spf_pool_impl;
         if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
+        const void* src[3] = {a, b_in, c};
+        return submit_impl(op, false, src, out, nullptr, nullptr, ticket, param);
+    }
+    // by handle: `v` are ready values of this pool (checked by the caller, pool_submit_v); *result is a new value that becomes
+    // valid when spf_pool_wait returns SPF_OK for the ticket
+    spf_status submit_v(int op, spf_value* const* v, spf_value* result, uint64_t* ticket, uint64_t param = 0)
+    {
+        return submit_impl(op, true, nullptr, nullptr, v, result, ticket, param);
+    }
+
+    spf_status submit_impl(int op, bool by_handle, const void* const* src, void* out, spf_value* const* vin, spf_value* vout,
+                           uint64_t* ticket, uint64_t param)
+    {
+        using namespace spf_pool_impl;
         std::unique_lock<std::mutex> lk(mu);
         blocked++;
         struct Leave { spf_pool* p; ~Leave() { p->blocked--; if (p->stop) p->cv_idle.notify_all(); } } leave{this};
@@ -325,9 +390,10 @@ struct spf_pool {
         // The caller's group: dealt round-robin on the thread's first submit, kept from then on.  The threads of a group meet in
         // the same batches, call after call — so a group's batch is complete the moment the members of its previous batch are
         // back (everybody_is_back), whatever the other groups are doing, and a straggler only ever delays itself.
+        // (By handle only the bootstrap kinds are dealt to groups: the cheap kinds are one batch per launch.)
         const uintptr_t who = (uintptr_t)pthread_self();
         int grp = 0;
-        {
+        if (!by_handle || heavy(op)) {
             size_t arrival;
             auto it = home_group.find(who);
             if (it != home_group.end()) arrival = it->second;
@@ -340,7 +406,8 @@ struct spf_pool {
             }
             grp = (int)(arrival % groups_now());
         }
-        const int lane = op * kMaxGroups + grp;
+        const int lane = lane_of(op, by_handle, grp);
+        const int kind = (by_handle ? N_OPS : 0) + op;
         std::shared_ptr<Batch> b;
         for (;;) {
             b = filling[lane];
@@ -362,11 +429,11 @@ struct spf_pool {
                 if (stop) return SPF_ERR_INVALID_ARGUMENT;
                 continue;
             }
-            const size_t cap = std::min(batch_cap(op), cap_hint[op]);
+            const size_t cap = std::min(batch_cap(op), cap_hint[kind]);
             sets[set].busy = true;
             preparing[lane] = true;
             lk.unlock(); // (allocation calls wait for the device: never under the pool's mutex)
-            const bool prepared = prepare_set(sets[set], op, cap);
+            const bool prepared = prepare_set(sets[set], op, cap, by_handle);
             lk.lock();
             preparing[lane] = false;
             if (set_waiters) cv_set.notify_all();
@@ -384,14 +451,14 @@ struct spf_pool {
                 cv_set.notify_all();
                 return SPF_ERR_HIP;
             }
-            b->op = op; b->set = set; b->cap = cap; b->lane = lane; b->param = param;
+            b->op = op; b->set = set; b->cap = cap; b->lane = lane; b->param = param; b->by_handle = by_handle;
             filling[lane] = b;
             break;
         }
         size_t slot;
         try {
             slot = b->n;
-            b->slots.push_back(Slot{out, next_ticket, 0, who});
+            b->slots.push_back(Slot{out, next_ticket, 0, who, {nullptr, nullptr, nullptr}, nullptr});
             // a caller "comes back" when it submits with nothing else outstanding (the synchronous pattern); a thread that
             // submits many tickets before it waits for any is not waited for — its batches close on the timer or when full
             int& mine_open = open_by_thread[who]; // (may allocate: before the ticket exists)
@@ -402,22 +469,34 @@ struct spf_pool {
             if (b->slots.size() > b->n) b->slots.pop_back();
             return SPF_ERR_HIP;
         }
+        if (heavy(op)) heavy_open++;
+        if (by_handle) { // the operands stay alive until the batch has run; the batch holds its own reference to the result
+            Slot& sl = b->slots[slot];
+            for (int k = 0; k < 3; k++)
+                if (vin[k]) { vin[k]->retain(); sl.vin[k] = vin[k]; }
+            vout->retain();
+            sl.vout = vout;
+        }
         b->t_last = std::chrono::steady_clock::now();
         if (b->n == 0) b->t0 = b->t_last;
         b->n++;
         *ticket = next_ticket++;
         if (b->n == b->cap) {
-            cap_hint[op] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
+            cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(lane);
         } else if (everybody_is_back(*b)) {
             cv_work.notify_all(); // the launcher need not wait for more
+        }
+        if (by_handle) { // nothing to copy: the slot is ready as it stands
+            b->n_ready++;
+            if (slot == 0 || (b->closed && b->n_ready == b->n)) cv_work.notify_all();
+            return SPF_OK;
         }
         size_t in[3], outsz;
         in_out_sizes(op, in, outsz);
         const Staging& s = sets[b->set];
         lk.unlock();
         // the caller's own bytes, by the caller's own thread, straight into pinned memory
-        const void* src[3] = {a, b_in, c};
         for (int k = 0; k < 3; k++)
             if (in[k]) std::memcpy(static_cast<uint8_t*>(s.h_in[k]) + slot * in[k], src[k], in[k]);
         lk.lock();
@@ -437,8 +516,10 @@ struct spf_pool {
         return b.n > 0 && !last.empty() && b.n_returning >= last.size();
     }
 
-    // `mu` held.  The callers blocked in the pool right now (open tickets) stand for the population that keeps coming back.
-    size_t population() const { return tickets.size(); }
+    // `mu` held.  The callers of the bootstrap kinds blocked in the pool right now (open tickets) stand for the population that
+    // keeps coming back.  (Tickets of the cheap kinds do not count: a thousand open CMUX gates say nothing about how many
+    // bootstraps the next batches will hold.)
+    size_t population() const { return heavy_open; }
     // Caller groups in use.  Measured (tools/pool_bench.py, fraction of the device-resident rate; profiles/r05_pool.md):
     //   callers      32    64    128   256   384   512   768   1024  1536  2048
     //   2 groups    0.88  0.91  0.77  0.71  0.81  0.67  0.77  0.73  0.88  0.53
@@ -460,10 +541,10 @@ struct spf_pool {
         const size_t pop = population(), n_cu = (size_t)ctx->n_cu;
         return pop <= n_cu ? 1 : (pop <= 2 * n_cu ? 2 : 4);
     }
-    size_t running() const
+    size_t running() const // bootstrap batches whose kernels are on the GPU
     {
         size_t r = 0;
-        for (auto& f : in_flight) r += f->kernels_done ? 0 : 1;
+        for (auto& f : in_flight) r += (f->kernels_done || !spf_pool_impl::heavy(f->op)) ? 0 : 1;
         return r;
     }
 
@@ -510,6 +591,7 @@ struct spf_pool {
                     lk.lock();
                 }
                 sl.delivered = 2;
+                n_reclaimed++;
                 cv_deliver.notify_all();
                 collected_one(b); // the ticket stays open (its status is still to be fetched), its bytes are out
                 if (!sets[b->set].busy) return;
@@ -537,13 +619,16 @@ struct spf_pool {
         const spf_status st = b->st;
         // (`delivered` leaves 0 only for an unclaimed ticket, under the mutex this thread's claim went through: what this thread
         // reads here without the lock is either 0 for good, or the 1 / 2 that reclaim() set before the claim)
-        if (st == SPF_OK && b->slots[slot].delivered == 0) deliver(*b, slot); // this caller's output, by this caller's thread
+        if (!b->by_handle && st == SPF_OK && b->slots[slot].delivered == 0) deliver(*b, slot); // this caller's output, by this caller's thread
         std::unique_lock<std::mutex> lk(mu);
-        cv_deliver.wait(lk, [&] { return b->slots[slot].delivered != 1; }); // a delivery on this ticket's behalf is still copying
-        if (b->slots[slot].delivered == 0) {
-            b->slots[slot].delivered = 2;
-            collected_one(b);
+        if (!b->by_handle) { // (a handle batch has nothing to collect: its set went back when it completed)
+            cv_deliver.wait(lk, [&] { return b->slots[slot].delivered != 1; }); // a delivery on this ticket's behalf is still copying
+            if (b->slots[slot].delivered == 0) {
+                b->slots[slot].delivered = 2;
+                collected_one(b);
+            }
         }
+        if (spf_pool_impl::heavy(b->op) && heavy_open) heavy_open--;
         tickets.erase(ticket);
         claimed.erase(ticket);
         {
@@ -557,9 +642,110 @@ struct spf_pool {
     }
 
     // ---- launcher: closes batches and enqueues them
+    // the kernels of one batch: inputs d[0..2] (contiguous rows), output d_out, on the set's stream and intermediates
+    spf_status run_kernels(const Batch& b, const spf_pool_impl::Staging& s, size_t B, void* const d[3], void* d_out)
+    {
+        using namespace spf_pool_impl;
+        hipStream_t sk = s.sk;
+        Scratch* scr = const_cast<Scratch*>(&s.scr);
+        spf_status st;
+        switch (b.op) {
+        case OP_KEYSWITCH:
+            return pool_keyswitch(ctx, sk, B, (const uint64_t*)d[0], (uint64_t*)d_out, scr);
+        case OP_CBS:
+            return pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)d[0], (double*)d_out, scr, b.per_wg);
+        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
+            st = pool_keyswitch(ctx, sk, B, (const uint64_t*)d[0], (uint64_t*)s.d_mid, scr);
+            if (st == SPF_OK) st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)d_out, scr, b.per_wg);
+            return st;
+        case OP_SAMPLE_EXTRACT:
+            return spf_sample_extract_l1_dev(ctx, sk, B, (const uint64_t*)d[0], (size_t)b.param, (uint64_t*)d_out);
+        case OP_NOT:
+            return spf_glwe_not_dev(ctx, sk, B, (const uint64_t*)d[0], (uint64_t*)d_out);
+        case OP_GLWE_ADD:
+            return spf_glwe_xor_dev(ctx, sk, B, (const uint64_t*)d[0], (const uint64_t*)d[1], (uint64_t*)d_out);
+        case OP_MUL_XN:
+            return spf_glwe_mul_xn_dev(ctx, sk, B, (const uint64_t*)d[0], (size_t)b.param, (uint64_t*)d_out);
+        case OP_MULTIPLY_GGSW_GLWE:
+            return spf_multiply_glwe_ggsw_dev(ctx, sk, B, (const uint64_t*)d[1], (const double*)d[0], (uint64_t*)d_out);
+        case OP_GLEV_CMUX:
+            return spf_glev_cmux_dev(ctx, sk, B, (const double*)d[0], (const uint64_t*)d[1], (const uint64_t*)d[2], (uint64_t*)d_out);
+        case OP_SCHEME_SWITCH:
+            return spf_scheme_switch_dev(ctx, sk, B, (const uint64_t*)d[0], (double*)d_out);
+        default:
+            return spf_cmux_dev(ctx, sk, B, (const double*)d[0], (const uint64_t*)d[1], (const uint64_t*)d[2], (uint64_t*)d_out);
+        }
+    }
+
+    // A batch by handle: no copies.  The outputs are one block of the arena; the operands are read where they are (CMUX family)
+    // or packed into the set's device rows by gather_rows_kernel — unless they already lie consecutively.
+    spf_status enqueue_v(Batch& b)
+    {
+        using namespace spf_pool_impl;
+        size_t in[3], out;
+        in_out_sizes(b.op, in, out);
+        const Staging& s = sets[b.set];
+        const size_t B = b.n;
+        if (hipSetDevice(ctx->device) != hipSuccess) return SPF_ERR_HIP;
+        b.out_blk = spf_value_impl::Block::make(arena, B * out);
+        if (!b.out_blk) return SPF_ERR_HIP;
+        char* d_out = static_cast<char*>(b.out_blk->p);
+        if (hipEventCreateWithFlags(&b.ev_k, hipEventDefault) != hipSuccess) return SPF_ERR_HIP;
+        hipStream_t sk = s.sk;
+        spf_status st = SPF_OK;
+        if (scattered_cmux(b.op)) {
+            // units {selector, low (taken when the selector is 0; null = the zero ciphertext), high, out}; units of one selector next
+            // to each other (neighbouring workgroups then hit the same 256 KiB in L2: spf_graph.hpp)
+            const size_t per = b.op == OP_GLEV_CMUX ? prm.cbs_radix_count : 1, gw = glwe_bytes();
+            struct Unit { void* p[4]; };
+            Unit* units = reinterpret_cast<Unit*>(s.h_ptrs);
+            size_t n_units = 0;
+            for (size_t i = 0; i < B; i++) {
+                const Slot& sl = b.slots[i];
+                for (size_t j = 0; j < per; j++) {
+                    Unit u;
+                    u.p[0] = sl.vin[0]->ptr();
+                    if (b.op == OP_MULTIPLY_GGSW_GLWE) {
+                        u.p[1] = nullptr;
+                        u.p[2] = sl.vin[1]->ptr();
+                    } else {
+                        u.p[1] = static_cast<char*>(sl.vin[1]->ptr()) + j * gw;
+                        u.p[2] = static_cast<char*>(sl.vin[2]->ptr()) + j * gw;
+                    }
+                    u.p[3] = d_out + i * out + j * gw;
+                    units[n_units++] = u;
+                }
+            }
+            std::stable_sort(units, units + n_units, [](const Unit& x, const Unit& y) { return x.p[0] < y.p[0]; });
+            st = spf_cmux_scattered_dev(ctx, sk, n_units, (const void* const*)s.h_ptrs);
+        } else {
+            void* d[3] = {nullptr, nullptr, nullptr};
+            for (int k = 0; k < 3 && st == SPF_OK; k++) {
+                if (!in[k]) continue;
+                char* first = static_cast<char*>(b.slots[0].vin[k]->ptr());
+                bool contiguous = true;
+                for (size_t i = 1; i < B && contiguous; i++) contiguous = b.slots[i].vin[k]->ptr() == first + i * in[k];
+                if (contiguous) { d[k] = first; continue; }
+                void** row = s.h_ptrs + (size_t)k * b.cap;
+                for (size_t i = 0; i < B; i++) row[i] = b.slots[i].vin[k]->ptr();
+                st = spf_gather_rows_dev(ctx, sk, B, in[k] / 8, (const uint64_t* const*)row, (uint64_t*)s.d_in[k]);
+                d[k] = s.d_in[k];
+            }
+            if (st == SPF_OK) st = run_kernels(b, s, B, d, d_out);
+        }
+        if (st != SPF_OK) return st;
+        if (hipEventRecord(b.ev_k, sk) != hipSuccess) return SPF_ERR_HIP;
+        for (size_t i = 0; i < B; i++) { // (published to the callers by the completer: READY is set behind the event)
+            b.slots[i].vout->blk = b.out_blk;
+            b.slots[i].vout->off = i * out;
+        }
+        return SPF_OK;
+    }
+
     spf_status enqueue(Batch& b)
     {
         using namespace spf_pool_impl;
+        if (b.by_handle) return enqueue_v(b);
         size_t in[3], out;
         in_out_sizes(b.op, in, out);
         const Staging& s = sets[b.set];
@@ -587,46 +773,7 @@ struct spf_pool {
         for (int k = 0; k < 3; k++) // (a kernel that reads the pinned buffer, not an SDMA copy: spf_kernels.hpp, copy_words_kernel)
             if (in[k] && pool_copy_in(ctx, sk, s.h_in[k], s.d_in[k], B * in[k]) != SPF_OK) return SPF_ERR_HIP;
         if (hipEventRecord(b.ev_in, sk) != hipSuccess) return SPF_ERR_HIP;
-        Scratch* scr = const_cast<Scratch*>(&s.scr);
-        spf_status st;
-        switch (b.op) {
-        case OP_KEYSWITCH:
-            st = pool_keyswitch(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out, scr);
-            break;
-        case OP_CBS:
-            st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out, scr, b.per_wg);
-            break;
-        case OP_GATE_CBS: // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap, the level-0 LWE stays in HBM
-            st = pool_keyswitch(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_mid, scr);
-            if (st == SPF_OK) st = pool_circuit_bootstrap(ctx, sk, B, (const uint64_t*)s.d_mid, (double*)s.d_out, scr, b.per_wg);
-            break;
-        case OP_SAMPLE_EXTRACT:
-            st = spf_sample_extract_l1_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (size_t)b.param, (uint64_t*)s.d_out);
-            break;
-        case OP_NOT:
-            st = spf_glwe_not_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (uint64_t*)s.d_out);
-            break;
-        case OP_GLWE_ADD:
-            st = spf_glwe_xor_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (const uint64_t*)s.d_in[1], (uint64_t*)s.d_out);
-            break;
-        case OP_MUL_XN:
-            st = spf_glwe_mul_xn_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (size_t)b.param, (uint64_t*)s.d_out);
-            break;
-        case OP_MULTIPLY_GGSW_GLWE:
-            st = spf_multiply_glwe_ggsw_dev(ctx, sk, B, (const uint64_t*)s.d_in[1], (const double*)s.d_in[0], (uint64_t*)s.d_out);
-            break;
-        case OP_GLEV_CMUX:
-            st = spf_glev_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],
-                                   (uint64_t*)s.d_out);
-            break;
-        case OP_SCHEME_SWITCH:
-            st = spf_scheme_switch_dev(ctx, sk, B, (const uint64_t*)s.d_in[0], (double*)s.d_out);
-            break;
-        default:
-            st = spf_cmux_dev(ctx, sk, B, (const double*)s.d_in[0], (const uint64_t*)s.d_in[1], (const uint64_t*)s.d_in[2],
-                              (uint64_t*)s.d_out);
-            break;
-        }
+        const spf_status st = run_kernels(b, s, B, s.d_in, s.d_out);
         if (st != SPF_OK) return st;
         if (hipEventRecord(b.ev_k, sk) != hipSuccess) return SPF_ERR_HIP;
         hipStream_t so = sk;
@@ -644,25 +791,40 @@ struct spf_pool {
     void launch_loop()
     {
         using namespace spf_pool_impl;
+        using clock = std::chrono::steady_clock;
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // the quiet times below are tens of microseconds: the default slack is 50
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in
-            if (!closing.empty()) {
-                std::shared_ptr<Batch> b = closing.front();
-                if (b->n_ready < b->n) { cv_work.wait(lk); continue; }
-                // Pacing: resident batches that start together also finish together — their copies out queue behind each other
-                // and their callers come back in one crowd, i.e. they behave as ONE big batch and the GPU idles through the
-                // common turn-around.  A batch therefore starts no sooner than a 1 / groups share of a batch's time on the GPU
-                // after the previous one: once spread out, the groups keep their phases (each comes back one cycle later), and
-                // while one copies out and resubmits the others compute.
-                if (!stop && running() > 0 && pace_div >= 0) {
-                    const auto due = last_enq + std::min<std::chrono::steady_clock::duration>(last_gpu_span / (pace_div > 0 ? pace_div : (int)groups_now()), std::chrono::milliseconds(5));
-                    if (std::chrono::steady_clock::now() < due) { cv_work.wait_until(lk, due); continue; }
+            const auto now = clock::now();
+            auto wake = clock::time_point::max();
+            // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in (the first one that can go:
+            // a batch whose members are still copying does not hold up the ones behind it)
+            std::shared_ptr<Batch> go;
+            for (auto it = closing.begin(); it != closing.end(); ++it) {
+                Batch& b = **it;
+                if (b.n_ready < b.n) continue; // (submit wakes this thread when the last input is in)
+                // Pacing of the bootstrap kinds: resident batches that start together also finish together — their copies out
+                // queue behind each other and their callers come back in one crowd, i.e. they behave as ONE big batch and the GPU
+                // idles through the common turn-around.  A batch therefore starts no sooner than a 1 / groups share of a batch's
+                // time on the GPU after the previous one: once spread out, the groups keep their phases (each comes back one cycle
+                // later), and while one copies out and resubmits the others compute.
+                if (!stop && heavy(b.op) && running() > 0 && pace_div >= 0) {
+                    const auto due = last_enq + std::min<clock::duration>(last_gpu_span[b.op] / (pace_div > 0 ? pace_div : (int)groups_now()), std::chrono::milliseconds(5));
+                    if (now < due) { wake = std::min(wake, due); continue; }
                 }
-                closing.pop_front();
-                b->t_ready = std::chrono::steady_clock::now();
-                last_enq = b->t_ready;
+                go = *it;
+                closing.erase(it);
+                break;
+            }
+            if (go) {
+                std::shared_ptr<Batch> b = go;
+                b->t_ready = clock::now();
+                if (heavy(b->op)) last_enq = b->t_ready;
                 b->per_wg = per_wg_hint();
+                if (heavy(b->op)) { // (the shape launch_blind_rotate will pick from the batch size and the hint)
+                    const size_t n_cu = (size_t)ctx->n_cu;
+                    n_shape[(b->n <= n_cu && b->per_wg <= 1) ? 0 : ((b->n <= 2 * n_cu && b->per_wg <= 2) ? 1 : 2)]++;
+                }
                 lk.unlock();
                 spf_status st;
                 try {
@@ -672,53 +834,69 @@ struct spf_pool {
                 }
                 lk.lock();
                 b->st = st;
-                b->t_enq = std::chrono::steady_clock::now();
+                b->t_enq = clock::now();
                 in_flight.push_back(b);
-                cv_flight.notify_all();
+                flying[b->set] = b;
+                cv_fly[b->set].notify_one();
                 continue;
             }
             // 2. time-based closing.  A group's batch is complete when the members of its previous batch are all back (submit
             // wakes this thread then); otherwise — first-time callers, a member that does not come back — it closes when nobody has
-            // joined it for the quiet time: max_wait, stretched to an eighth of the last batch's time on the GPU (a caller
-            // needs that long to copy 256 KiB out and come back when its CPU is shared), and at most 20 quiet times after its
-            // first member arrived, so that a trickle of arrivals cannot hold it open.
+            // joined it for the quiet time: max_wait, stretched to an eighth of the last batch OF ITS KIND's time on the GPU (a
+            // caller of a bootstrap needs that long to copy 256 KiB out and come back when its CPU is shared), and at most 20 quiet
+            // times after its first member arrived, so that a trickle of arrivals cannot hold it open.
             int lane = -1;
-            std::chrono::steady_clock::time_point best{};
-            const auto now = std::chrono::steady_clock::now();
-            const auto quiet = std::max(std::chrono::duration_cast<std::chrono::steady_clock::duration>(max_wait),
-                                        std::min<std::chrono::steady_clock::duration>(last_gpu_span / 8, std::chrono::milliseconds(2)));
+            clock::time_point best{};
             for (int k = 0; k < kLanes; k++) {
                 if (!filling[k] || filling[k]->n == 0) continue;
-                if (outstanding[k] > 0 && !stop) continue; // its group's previous batch is still out: the callers are not back yet
+                const int op = filling[k]->op;
+                // its group's previous batch is still out: the callers are not back yet (the cheap kinds by handle are fed by
+                // whoever has an operation ready — the gates of a circuit's next level — not by returning callers)
+                if (outstanding[k] > 0 && !stop && (heavy(op) || !filling[k]->by_handle)) continue;
+                const auto quiet = std::max(std::chrono::duration_cast<clock::duration>(max_wait),
+                                            std::min<clock::duration>(last_gpu_span[op] / 8, std::chrono::milliseconds(2)));
                 const auto due = (stop || everybody_is_back(*filling[k])) ? now : std::min(filling[k]->t_last + quiet, filling[k]->t0 + 20 * quiet);
                 if (lane < 0 || due < best) { lane = k; best = due; }
             }
-            if (lane < 0) {
-                if (stop) return;
-                cv_work.wait(lk);
+            if (lane >= 0 && now >= best) {
+                close_batch(lane);
                 continue;
             }
-            if (now < best) { cv_work.wait_until(lk, best); continue; }
-            close_batch(lane);
+            if (lane >= 0) wake = std::min(wake, best);
+            if (wake == clock::time_point::max()) {
+                if (stop && closing.empty()) return;
+                cv_work.wait(lk);
+            } else {
+                cv_work.wait_until(lk, wake);
+            }
         }
     }
 
-    void complete_loop()
+    // one completer per staging set: each waits for its own batch, so a batch is handed back when IT has finished, whatever was
+    // enqueued before it on other sets
+    void complete_loop(int si)
     {
+        using namespace spf_pool_impl;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_flight.wait(lk, [&] { return !in_flight.empty() || (stop && launcher_gone); });
-            if (in_flight.empty()) return;
-            std::shared_ptr<Batch> b = in_flight.front();
+            cv_fly[si].wait(lk, [&] { return flying[si] || (stop && launcher_gone); });
+            if (!flying[si]) return;
+            std::shared_ptr<Batch> b = flying[si];
             lk.unlock();
-            if (b->st == SPF_OK) {
-                (void)hipSetDevice(ctx->device);
+            (void)hipSetDevice(ctx->device);
+            if (b->st == SPF_OK && b->by_handle) {
+                if (hipEventSynchronize(b->ev_k) != hipSuccess) {
+                    b->st = SPF_ERR_HIP;
+                    (void)hipStreamSynchronize(sets[b->set].sk);
+                }
+                b->t_sync = std::chrono::steady_clock::now();
+            } else if (b->st == SPF_OK) {
                 // first the kernels: the launcher closes and enqueues the batch that filled meanwhile, so that its copy in and
                 // its kernels run under this batch's copy out
                 const bool k_ok = hipEventSynchronize(b->ev_k) == hipSuccess;
                 lk.lock();
                 b->kernels_done = true;
-                last_gpu_span = std::chrono::steady_clock::now() - b->t_enq;
+                last_gpu_span[b->op] = std::chrono::steady_clock::now() - b->t_enq;
                 cv_work.notify_all();
                 lk.unlock();
                 if (!k_ok) b->st = SPF_ERR_HIP;
@@ -734,12 +912,28 @@ struct spf_pool {
                 b->t_sync = std::chrono::steady_clock::now();
             } else {
                 // something was enqueued before the failure: let it drain before the staging set is reused
-                (void)hipSetDevice(ctx->device);
                 (void)hipStreamSynchronize(sets[b->set].sk);
             }
+            if (b->by_handle) {
+                // the results become visible, the operands are let go (outside the lock: the last reference to a value gives its
+                // block back to the arena)
+                const int state = b->st == SPF_OK ? spf_value_impl::READY : spf_value_impl::FAILED;
+                for (size_t i = 0; i < b->n; i++) {
+                    Slot& sl = b->slots[i];
+                    sl.vout->state.store(state, std::memory_order_release);
+                    sl.vout->release();
+                    sl.vout = nullptr;
+                    for (spf_value*& v : sl.vin)
+                        if (v) { v->release(); v = nullptr; }
+                }
+                b->out_blk.reset();
+            }
             lk.lock();
+            if (b->by_handle) last_gpu_span[b->op] = b->t_sync - b->t_enq;
             b->kernels_done = true;
-            in_flight.pop_front();
+            for (auto it = in_flight.begin(); it != in_flight.end(); ++it)
+                if (it->get() == b.get()) { in_flight.erase(it); break; }
+            flying[si].reset();
             b->done = true;
             b->t_done = std::chrono::steady_clock::now();
             last_done = b->t_done;
@@ -749,11 +943,20 @@ struct spf_pool {
                 float gpu_ms = -1.f;
                 if (b->ev_in && b->n_chunks > 0 && b->ev_chunk[b->n_chunks - 1])
                     (void)hipEventElapsedTime(&gpu_ms, b->ev_in, b->ev_chunk[b->n_chunks - 1]);
-                fprintf(stderr, "[pool] batch op %d n %zu: filled %ld us, closed->inputs in %ld us, enqueue %ld us, enqueued->event %ld us (gpu h2d..d2h %.0f us), event->marked %ld us\n", b->op, b->n,
+                fprintf(stderr, "[pool] batch op %d%s n %zu: filled %ld us, closed->inputs in %ld us, enqueue %ld us, enqueued->event %ld us (gpu h2d..d2h %.0f us), event->marked %ld us\n", b->op, b->by_handle ? " (by handle)" : "", b->n,
                         us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), gpu_ms * 1e3f, us(b->t_done - b->t_sync));
             }
 #endif
-            collecting.push_back(b);
+            if (b->by_handle) {
+                // nothing to collect: the staging set is free again
+                sets[b->set].busy = false;
+                b->destroy_events();
+                if (set_waiters) cv_set.notify_all();
+                n_handle_launches++;
+                n_handle_ops += b->n;
+            } else {
+                collecting.push_back(b);
+            }
             outstanding[b->lane]--;
             n_launches++;
             n_ops += b->n;
@@ -763,7 +966,7 @@ struct spf_pool {
         }
     }
     bool launcher_gone = false;
-    std::chrono::steady_clock::duration last_gpu_span{0}; // enqueue -> kernels done of the most recent batch
+    std::chrono::steady_clock::duration last_gpu_span[spf_pool_impl::N_OPS] = {}; // enqueue -> kernels done of the most recent batch of a kind
     std::chrono::steady_clock::time_point last_done;      // when the most recent batch was handed to its waiters
     std::chrono::steady_clock::time_point last_enq;       // when the most recent batch was enqueued (pacing)
 };

@@ -63,19 +63,20 @@ def run_sharded(jobs: Sequence, costs: Sequence[float], rank: int, world: int,
     return [merged[i] for i in range(len(jobs))]
 
 
-def circuit_jobs_as_one_graph(engine, circuit, bit_glwes: np.ndarray):
+def circuit_jobs_as_one_graph(engine, circuit, bit_glwes: np.ndarray, record: bool = False):
     """Lower K evaluations of a `MuxCircuit` into ONE gate graph the way `add_circuit` / `mul_impl` feed their
     blocks (`FheCircuit::insert_mux_circuit_and_connect_inputs`, fhe_circuit.rs:473-494; circuits/add.rs:10-32,
     circuits/mul.rs:104-117): per input bit an L1 GLWE -> SampleExtract(0) -> KeyswitchL1toL0 -> CircuitBootstrap,
     the GGSWs select the block's CMUX tree.
     bit_glwes: [K, n_inputs, glwe_words] uint64.  Returns (graph, outs) with outs[k][o] the array that
-    graph.run() fills with output bit o of evaluation k."""
-    from .graph import FheCircuit, FheOp, ValueKind
+    graph.run() fills with output bit o of evaluation k.  record=True: the graph is a `RecordedCircuit` (not bound to
+    an executor) and outs[k][o] is the index of the output in its `outputs` list."""
+    from .graph import FheCircuit, FheOp, RecordedCircuit, ValueKind
     from .mux_circuits import insert_mux_circuit
     K, n_in = bit_glwes.shape[0], bit_glwes.shape[1]
     if n_in != circuit.n_inputs:
         raise ValueError("one GLWE per circuit input")
-    g = FheCircuit(engine)
+    g = RecordedCircuit() if record else FheCircuit(engine)
     outs = []
     for k in range(K):
         sel = []

@@ -104,3 +104,68 @@ class FheCircuit:
         n, lv, la = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._eng._ck(self._lib.spf_graph_stats(self._g, C.byref(n), C.byref(lv), C.byref(la)))
         return {"nodes": n.value, "levels": lv.value, "launches": la.value}
+
+
+class RecordedCircuit:
+    """The builder calls of :class:`FheCircuit` kept as plain arrays, not bound to an executor: the same DAG can then be
+    lowered into a gate graph (`lower`) or walked node by node the way the reference's `CircuitProcessor` does
+    (circuit_processor/mod.rs:130-253) — `arrays()` is what such a per-operation driver takes."""
+
+    _OUT_KIND = {FheOp.SampleExtract: ValueKind.LWE1, FheOp.KeyswitchL1toL0: ValueKind.LWE0, FheOp.Not: ValueKind.GLWE1,
+                 FheOp.GlweAdd: ValueKind.GLWE1, FheOp.CMux: ValueKind.GLWE1, FheOp.GlevCMux: ValueKind.GLEV1,
+                 FheOp.MultiplyGgswGlwe: ValueKind.GLWE1, FheOp.CircuitBootstrap: ValueKind.GGSW1,
+                 FheOp.SchemeSwitch: ValueKind.GGSW1, FheOp.MulXN: ValueKind.GLWE1}
+
+    def __init__(self):
+        self.op: List[int] = []        # FheOp, -1 input, -2 trivial constant
+        self.kind: List[int] = []
+        self.param: List[int] = []     # SampleExtract index / MulXN amount / trivial bit
+        self.inputs: List[tuple] = []
+        self.host: List = []           # inputs: the caller's array
+        self.outputs: List[int] = []   # nodes, in add_output order
+
+    def _add(self, op, kind, param, inputs, host=None) -> int:
+        self.op.append(int(op)); self.kind.append(int(kind)); self.param.append(int(param))
+        self.inputs.append(tuple(int(i) for i in inputs)); self.host.append(host)
+        return len(self.op) - 1
+
+    def add_input(self, kind: ValueKind, value: np.ndarray) -> int:
+        return self._add(-1, kind, 0, (), np.ascontiguousarray(value))
+
+    def add_trivial(self, kind: ValueKind, bit: int) -> int:
+        return self._add(-2, kind, bit, ())
+
+    def add_op(self, op: FheOp, inputs: Sequence[int], param: int = 0) -> int:
+        if any(i >= len(self.op) for i in inputs):
+            raise SpfError(1, "operand is not a node of this circuit")
+        return self._add(FheOp(op), self._OUT_KIND[FheOp(op)], param, inputs)
+
+    def add_output(self, node: int, kind: ValueKind) -> int:
+        if self.kind[node] != int(kind):
+            raise SpfError(1, "output kind does not match the node")
+        self.outputs.append(int(node))
+        return len(self.outputs) - 1
+
+    def lower(self, engine: Engine):
+        """-> (FheCircuit, [output arrays]) with the same nodes in the same order"""
+        g = FheCircuit(engine)
+        for i in range(len(self.op)):
+            if self.op[i] == -1:
+                n = g.add_input(ValueKind(self.kind[i]), self.host[i])
+            elif self.op[i] == -2:
+                n = g.add_trivial(ValueKind(self.kind[i]), self.param[i])
+            else:
+                n = g.add_op(FheOp(self.op[i]), self.inputs[i], self.param[i])
+            assert n == i
+        return g, [g.add_output(n, ValueKind(self.kind[n])) for n in self.outputs]
+
+    def arrays(self) -> dict:
+        n = len(self.op)
+        ins = np.zeros((n, 3), dtype=np.uint32)
+        for i, t in enumerate(self.inputs):
+            ins[i, :len(t)] = t
+        keep = np.zeros(n, dtype=np.uint8)
+        keep[self.outputs] = 1
+        return {"op": np.array([o if o >= 0 else -1 for o in self.op], dtype=np.int32), "in": ins,
+                "n_in": np.array([len(t) for t in self.inputs], dtype=np.uint32),
+                "param": np.array(self.param, dtype=np.uint64), "keep": keep}

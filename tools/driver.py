@@ -1,0 +1,109 @@
+"""The native caller drivers of tests and bench.py (tools/pool_driver.cpp), built on demand beside the library: load() returns
+the ctypes handle with prototypes; run_circuit_by_handles() walks a `spf_amd.RecordedCircuit` node by node through the pool's
+submits by handle the way the reference's `CircuitProcessor` walks an `FheCircuit` (circuit_processor/mod.rs:130-253).
+Test infrastructure: uses the public C ABI only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_DRV = None
+
+
+def load():
+    global _DRV
+    if _DRV is not None:
+        return _DRV
+    drv_path = os.path.join(ROOT, "tools", "bin", "libpool_driver.so")
+    src = os.path.join(ROOT, "tools", "pool_driver.cpp")
+    hdr = os.path.join(ROOT, "include", "spf_hip.h")
+    if not os.path.exists(drv_path) or os.path.getmtime(drv_path) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(drv_path), exist_ok=True)
+        tmp = f"{drv_path}.{os.getpid()}.tmp"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", os.path.join(ROOT, "include"),
+                        "-o", tmp, src], check=True)
+        os.replace(tmp, drv_path)
+    d = C.CDLL(drv_path)
+    P, D = C.c_void_p, C.POINTER(C.c_double)
+    d.spf_pool_drive.restype = C.c_long
+    d.spf_pool_drive.argtypes = [P, P, P, C.c_int, C.c_double, P, C.c_size_t, C.c_size_t, D, D]
+    d.spf_pool_drive_collect.restype = C.c_long
+    d.spf_pool_drive_collect.argtypes = [P, P, P, C.c_int, C.c_double, P, C.c_size_t, C.c_size_t, D, P]
+    d.spf_pool_drive_v.restype = C.c_long
+    d.spf_pool_drive_v.argtypes = [P, P, P, P, C.c_int, C.c_double, P, D, P]
+    d.spf_pool_drive_cmux.restype = C.c_long
+    d.spf_pool_drive_cmux.argtypes = [P, P, P, C.c_int, C.c_double, P, C.c_size_t, P, P, C.c_size_t, D]
+    d.spf_pool_drive_cmux_v.restype = C.c_long
+    d.spf_pool_drive_cmux_v.argtypes = [P, P, P, P, C.c_int, C.c_double, P, P, P, D]
+    d.spf_circuit_drive.restype = C.c_int
+    d.spf_circuit_drive.argtypes = [P, P, P, P, C.c_int, C.c_uint32, P, P, P, P, P, P, D]
+    _DRV = d
+    return d
+
+
+def fn(lib, name):
+    return C.cast(getattr(lib, name), C.c_void_p)
+
+
+def handles(values):
+    """a C array of spf_value* from spf_amd.Value objects"""
+    return (C.c_void_p * len(values))(*[v._h for v in values])
+
+
+def upload_circuit_inputs(pool, rec, member=-1):
+    """values[i] for the input / constant nodes of a RecordedCircuit (None elsewhere)"""
+    vals = [None] * len(rec.op)
+    for i, op in enumerate(rec.op):
+        if op == -1:
+            vals[i] = pool.upload(rec.kind[i], rec.host[i], member)
+        elif op == -2:
+            vals[i] = pool.trivial(rec.kind[i], rec.param[i], member)
+    return vals
+
+
+def run_circuit_by_handles(pool, rec, threads=64, member=-1, vals=None):
+    """-> (outputs as arrays in rec.outputs order, seconds inside the driver, seconds with upload and download).  Every
+    operation of the circuit is ONE spf_pool_submit_op_v + spf_pool_wait from one of `threads` native workers."""
+    import time
+    from spf_amd import Value
+    d = load()
+    lib = pool._lib
+    a = rec.arrays()
+    n = len(rec.op)
+    t0 = time.perf_counter()
+    if vals is None:
+        vals = upload_circuit_inputs(pool, rec, member)
+    table = (C.c_void_p * n)(*[(v._h if v is not None else None) for v in vals])
+    el = C.c_double()
+    st = d.spf_circuit_drive(pool._h, fn(lib, "spf_pool_submit_op_v"), fn(lib, "spf_pool_wait"), fn(lib, "spf_value_release"),
+                             threads, n, a["op"].ctypes.data, a["in"].ctypes.data, a["n_in"].ctypes.data,
+                             a["param"].ctypes.data, table, a["keep"].ctypes.data, C.byref(el))
+    # the driver released (and nulled) what nobody keeps; inputs it released must not be released again by their wrappers
+    for i, v in enumerate(vals):
+        if v is not None and not table[i]:
+            v._h = None
+    outs = []
+    kept = {}
+    for node in rec.outputs:
+        if node not in kept:
+            if not table[node]:
+                kept[node] = None
+            elif vals[node] is not None:
+                kept[node] = vals[node]
+            else:
+                kept[node] = Value(pool, C.c_void_p(table[node]))
+    if st != 0:
+        for v in kept.values():
+            if v is not None:
+                v.release()
+        raise RuntimeError(f"spf_circuit_drive: status {st}")
+    outs = [kept[node].download() for node in rec.outputs]
+    t1 = time.perf_counter()
+    for v in kept.values():
+        v.release()
+    for v in vals:
+        if v is not None:
+            v.release()
+    return outs, el.value, t1 - t0

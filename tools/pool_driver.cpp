@@ -71,3 +71,188 @@ long spf_pool_drive_collect(spf_pool* pool, submit_fn submit, wait_fn wait, int 
 }
 
 }
+
+// ---- r06: the same scenario BY HANDLE (device-resident values, include/spf_hip.h "device-resident values") --------------------
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+extern "C" {
+
+typedef spf_status (*submit_v1_fn)(spf_pool*, const spf_value*, spf_value**, uint64_t*);
+typedef spf_status (*submit_cmux_fn)(spf_pool*, const double*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*);
+typedef spf_status (*submit_cmux_v_fn)(spf_pool*, const spf_value*, const spf_value*, const spf_value*, spf_value**, uint64_t*);
+typedef spf_status (*submit_op_v_fn)(spf_pool*, spf_graph_op, const spf_value* const*, size_t, uint64_t, spf_value**, uint64_t*);
+typedef void (*release_fn)(spf_value*);
+
+// `threads` callers loop submit_v(one input value each: inputs[t]) + wait + release of the result for `seconds`.
+// keep_last (may be null): threads slots; every caller's LAST result is kept there (the test downloads and checks them, then
+// releases them).  Returns operations completed, -1 on an error status.
+long spf_pool_drive_v(spf_pool* pool, submit_v1_fn submit, wait_fn wait, release_fn release, int threads, double seconds,
+                      spf_value* const* inputs, double* elapsed_s, spf_value** keep_last)
+{
+    std::atomic<long> done{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto until = t0 + std::chrono::duration<double>(seconds);
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            spf_value* last = nullptr;
+            while (std::chrono::steady_clock::now() < until && !failed.load()) {
+                uint64_t ticket = 0;
+                spf_value* out = nullptr;
+                if (submit(pool, inputs[t], &out, &ticket) != SPF_OK) { failed.store(1); break; }
+                if (wait(pool, ticket) != SPF_OK) { release(out); failed.store(1); break; }
+                if (last) release(last);
+                last = out;
+                done.fetch_add(1);
+            }
+            if (keep_last) keep_last[t] = last;
+            else if (last) release(last);
+        });
+    for (auto& x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load() ? -1 : done.load();
+}
+
+// CMUX gates one per call from `threads` callers: host-pointer form (every operand and result crosses PCIe) ...
+long spf_pool_drive_cmux(spf_pool* pool, submit_cmux_fn submit, wait_fn wait, int threads, double seconds, const double* sel,
+                         size_t ggsw_doubles, const uint64_t* a, const uint64_t* b, size_t glwe_words, double* elapsed_s)
+{
+    std::atomic<long> done{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> th;
+    std::vector<std::vector<uint64_t>> out((size_t)threads);
+    for (auto& o : out) o.assign(glwe_words, 0);
+    // (every caller owns its operands, as every task of the reference owns its ciphertexts)
+    std::vector<std::vector<double>> sels((size_t)threads, std::vector<double>(sel, sel + ggsw_doubles));
+    std::vector<std::vector<uint64_t>> as((size_t)threads, std::vector<uint64_t>(a, a + glwe_words)), bs((size_t)threads, std::vector<uint64_t>(b, b + glwe_words));
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto until = t0 + std::chrono::duration<double>(seconds);
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            while (std::chrono::steady_clock::now() < until && !failed.load()) {
+                uint64_t ticket = 0;
+                if (submit(pool, sels[(size_t)t].data(), as[(size_t)t].data(), bs[(size_t)t].data(), out[(size_t)t].data(), &ticket) != SPF_OK ||
+                    wait(pool, ticket) != SPF_OK) {
+                    failed.store(1);
+                    return;
+                }
+                done.fetch_add(1);
+            }
+        });
+    for (auto& x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load() ? -1 : done.load();
+}
+
+// ... and by handle: sel / a / b are `threads` values each (caller t uses sel[t], a[t], b[t]); the result is released at once
+long spf_pool_drive_cmux_v(spf_pool* pool, submit_cmux_v_fn submit, wait_fn wait, release_fn release, int threads, double seconds,
+                           spf_value* const* sel, spf_value* const* a, spf_value* const* b, double* elapsed_s)
+{
+    std::atomic<long> done{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto until = t0 + std::chrono::duration<double>(seconds);
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            while (std::chrono::steady_clock::now() < until && !failed.load()) {
+                uint64_t ticket = 0;
+                spf_value* out = nullptr;
+                if (submit(pool, sel[t], a[t], b[t], &out, &ticket) != SPF_OK) { failed.store(1); return; }
+                const spf_status st = wait(pool, ticket);
+                release(out);
+                if (st != SPF_OK) { failed.store(1); return; }
+                done.fetch_add(1);
+            }
+        });
+    for (auto& x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load() ? -1 : done.load();
+}
+
+// A gate graph executed the way the reference executes it (circuit_processor/mod.rs:130-253): one task per node, a task runs as
+// soon as its operands exist, every task calls the evaluator with ONE operation and blocks until it is done — here
+// spf_pool_submit_op_v + spf_pool_wait from a pool of `threads` workers; a node's value is released when its last consumer has
+// finished (the reference drops the task's `Arc`).
+//   op[i]      spf_graph_op of node i, or -1: the node is an input / constant whose value is already in values[i]
+//   in[3*i..]  operand nodes (n_in[i] of them, earlier nodes), param[i] SampleExtract index / MulXN amount
+//   keep[i]    nonzero: the value stays in values[i] for the caller (outputs); otherwise values[i] is released and set to null
+// Returns 0, or the first failing status (first-error-wins, :214-223): later tasks become no-ops, as in the reference.
+int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, release_fn release, int threads, uint32_t n_nodes,
+                      const int32_t* op, const uint32_t* in, const uint32_t* n_in, const uint64_t* param, spf_value** values,
+                      const uint8_t* keep, double* elapsed_s)
+{
+    std::vector<std::atomic<uint32_t>> deps(n_nodes), users(n_nodes);
+    std::vector<std::vector<uint32_t>> dependents(n_nodes);
+    uint32_t n_tasks = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) { deps[i].store(0); users[i].store(0); }
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (op[i] < 0) continue;
+        n_tasks++;
+        for (uint32_t k = 0; k < n_in[i]; k++) {
+            const uint32_t src = in[3 * i + k];
+            users[src].fetch_add(1);
+            if (op[src] >= 0) { deps[i].fetch_add(1); dependents[src].push_back(i); }
+        }
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<uint32_t> ready;
+    uint32_t finished = 0;
+    std::atomic<int> error{0};
+    for (uint32_t i = 0; i < n_nodes; i++)
+        if (op[i] >= 0 && deps[i].load() == 0) ready.push_back(i);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&] {
+        for (;;) {
+            uint32_t node;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty() || finished == n_tasks; });
+                if (ready.empty()) return;
+                node = ready.front();
+                ready.pop_front();
+            }
+            if (!error.load()) { // (after an error the remaining tasks only retire)
+                const spf_value* args[3] = {nullptr, nullptr, nullptr};
+                for (uint32_t k = 0; k < n_in[node]; k++) args[k] = values[in[3 * node + k]];
+                uint64_t ticket = 0;
+                spf_value* out = nullptr;
+                spf_status st = submit(pool, (spf_graph_op)op[node], args, n_in[node], param[node], &out, &ticket);
+                if (st == SPF_OK) {
+                    st = wait(pool, ticket);
+                    if (st != SPF_OK) { release(out); out = nullptr; }
+                }
+                if (st != SPF_OK) { int zero = 0; error.compare_exchange_strong(zero, (int)st); }
+                values[node] = out;
+            }
+            for (uint32_t k = 0; k < n_in[node]; k++) { // the operands' last user lets them go
+                const uint32_t src = in[3 * node + k];
+                if (users[src].fetch_sub(1) == 1 && !keep[src] && values[src]) { release(values[src]); values[src] = nullptr; }
+            }
+            if (users[node].load() == 0 && !keep[node] && values[node]) { release(values[node]); values[node] = nullptr; }
+            std::vector<uint32_t> now_ready;
+            for (uint32_t d : dependents[node])
+                if (deps[d].fetch_sub(1) == 1) now_ready.push_back(d);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (uint32_t d : now_ready) ready.push_back(d);
+                finished++;
+                if (finished == n_tasks) cv.notify_all();
+                else if (now_ready.size() == 1) cv.notify_one();
+                else if (!now_ready.empty()) cv.notify_all();
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto& x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return error.load();
+}
+
+}
