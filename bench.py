@@ -931,6 +931,158 @@ def _pool_runs(out, thread_counts, seconds, eng, P, dev, torch, drv, submit, wai
                             "frac_of_device_resident": round(rate / dev_rate, 4)})
 
 
+def _pinned_to_quota():
+    """context: the process (and the native threads it starts) confined to the CPUs its CFS quota grants (see
+    _bench_evaluation_pool)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def scope():
+        before = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(before)[:_host_cpus()[0]]))
+        try:
+            yield
+        finally:
+            os.sched_setaffinity(0, before)
+    return scope()
+
+
+def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), seconds=2.0):
+    """The drop-in scenario BY HANDLE (r06, include/spf_hip.h "device-resident values"): the same T native callers, one operation
+    per call, operands and results device-resident values — nothing crosses PCIe per call.
+      cmux            T callers loop one CMux gate each (the reference's `FheOp::CMux` task, circuit_processor/mod.rs:391-421):
+                      host-pointer submits (256 KiB + 2 x 32 KiB up, 32 KiB down per gate) against submits by handle
+      circuit_bootstrap  T callers loop KeyswitchL1toL0 -> CircuitBootstrap by handle (the GGSW stays in HBM), against the
+                      device-resident rate of the same kernels at a batch of T"""
+    import ctypes as C
+    import spf_amd
+    import tools.driver as drvmod
+    drv = drvmod.load()
+    lib = eng._lib
+    wait = drvmod.fn(lib, "spf_pool_wait")
+    release = drvmod.fn(lib, "spf_value_release")
+    rng = np.random.default_rng(0x9002)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"host_cpus": _host_cpus()[0], "cmux": [], "circuit_bootstrap": []}
+    sel = (rng.standard_normal(P.cbs_ggsw_complex * 2) * 2.0 ** 58)
+    a = rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64)
+    lwe1 = rng.integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
+    with _pinned_to_quota():
+        for T in (64, 256):
+            row = {"threads": T}
+            pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
+            try:
+                el = C.c_double()
+                args = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux"), wait, T)
+                drv.spf_pool_drive_cmux(*args, 0.3, sel.ctypes.data, sel.size, a.ctypes.data, b.ctypes.data, a.size, C.byref(el))
+                n = drv.spf_pool_drive_cmux(*args, seconds, sel.ctypes.data, sel.size, a.ctypes.data, b.ctypes.data, a.size, C.byref(el))
+                if n < 0:
+                    raise RuntimeError("pool driver: a host-pointer CMux failed")
+                row["host_pointer_gates_per_s"] = round(n / el.value, 1)
+                c0 = pool.counters()
+                vs = [pool.upload(3, sel.view(np.complex128)) for _ in range(T)]
+                va = [pool.upload(2, a) for _ in range(T)]
+                vb = [pool.upload(2, b) for _ in range(T)]
+                hs, ha, hb = drvmod.handles(vs), drvmod.handles(va), drvmod.handles(vb)
+                argv = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux_v"), wait, release, T)
+                drv.spf_pool_drive_cmux_v(*argv, 0.3, hs, ha, hb, C.byref(el))
+                c1 = pool.counters()
+                n = drv.spf_pool_drive_cmux_v(*argv, seconds, hs, ha, hb, C.byref(el))
+                c2 = pool.counters()
+                if n < 0:
+                    raise RuntimeError("pool driver: a CMux by handle failed")
+                row["by_handle_gates_per_s"] = round(n / el.value, 1)
+                row["by_handle_achieved_batch"] = round((c2["handle_ops"] - c1["handle_ops"]) / max(1, c2["handle_launches"] - c1["handle_launches"]), 1)
+                row["by_handle_over_host_pointer"] = round(row["by_handle_gates_per_s"] / row["host_pointer_gates_per_s"], 2)
+                for v in vs + va + vb:
+                    v.release()
+            finally:
+                pool.close()
+            out["cmux"].append(row)
+        for T in thread_counts:
+            d_in = torch.randint(-(2 ** 63), 2 ** 63 - 1, (T, P.lwe1_words), device=dev, dtype=torch.int64)
+            d_mid = torch.empty((T, P.lwe0_words), device=dev, dtype=torch.int64)
+            d_out = torch.empty((T, P.cbs_ggsw_complex * 2), device=dev, dtype=torch.float64)
+
+            def dev_step():
+                eng.keyswitch_dev(stream, T, d_in.data_ptr(), d_mid.data_ptr())
+                eng.circuit_bootstrap_dev(stream, T, d_mid.data_ptr(), d_out.data_ptr())
+
+            dev_step()
+            torch.cuda.synchronize()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dev_step()
+            torch.cuda.synchronize()
+            dev_rate = T * reps / (time.perf_counter() - t0)
+            del d_in, d_mid, d_out
+            pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=200)
+            try:
+                ins = [pool.upload(1, lwe1 + np.uint64(t)) for t in range(T)]
+                hin = drvmod.handles(ins)
+                el = C.c_double()
+                argv = (pool._h, drvmod.fn(lib, "spf_pool_submit_keyswitch_circuit_bootstrap_v"), wait, release, T)
+                drv.spf_pool_drive_v(*argv, 0.5, hin, C.byref(el), None)
+                c0 = pool.counters()
+                n = drv.spf_pool_drive_v(*argv, seconds, hin, C.byref(el), None)
+                c1 = pool.counters()
+                for v in ins:
+                    v.release()
+            finally:
+                pool.close()
+            if n < 0:
+                raise RuntimeError(f"pool driver: a circuit bootstrap by handle failed at T = {T}")
+            rate = n / el.value
+            shapes = {k: c1["bootstrap_launches_by_shape"][k] - c0["bootstrap_launches_by_shape"][k] for k in c1["bootstrap_launches_by_shape"]}
+            out["circuit_bootstrap"].append({"threads": T, "circuit_bootstraps_per_s": round(rate, 1), "operations": int(n),
+                                             "achieved_batch": round((c1["handle_ops"] - c0["handle_ops"]) / max(1, c1["handle_launches"] - c0["handle_launches"]), 1),
+                                             "launches_by_shape": shapes,
+                                             "device_resident_rate_at_batch_T": round(dev_rate, 1),
+                                             "frac_of_device_resident": round(rate / dev_rate, 4)})
+    return out
+
+
+def _bench_add32_by_handles(eng, P, threads=64, reps=5):
+    """BASELINE config 3 the way the reference runs it: the adder's DAG walked node by node (one task per `FheOp`, each ONE
+    spf_pool_submit_op_v + spf_pool_wait from a pool of native workers: tools/pool_driver.cpp spf_circuit_drive =
+    circuit_processor/mod.rs:130-253 in small), values device-resident, against the same DAG as ONE gate graph."""
+    import spf_amd
+    import tools.driver as drvmod
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph
+    from spf_amd.mux_circuits import ripple_carry_adder
+    adder = ripple_carry_adder(32, 32, False)
+    cts = np.random.default_rng(3).integers(0, 1 << 64, size=(1, 64, P.glwe_words), dtype=np.uint64)
+    rec, _ = circuit_jobs_as_one_graph(eng, adder, cts, record=True)
+    g, g_outs = rec.lower(eng)
+    g.run()
+    best_g = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        g.run()
+        best_g = min(best_g, time.perf_counter() - t0)
+    with _pinned_to_quota():
+        pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
+        try:
+            outs, _, _ = drvmod.run_circuit_by_handles(pool, rec, threads=threads)
+            same = all(np.array_equal(x, y) for x, y in zip(outs, g_outs))
+            c0 = pool.counters()
+            best = (1e9, 1e9)
+            for _ in range(reps):
+                _, inner, whole = drvmod.run_circuit_by_handles(pool, rec, threads=threads)
+                best = min(best, (whole, inner))
+            c1 = pool.counters()
+        finally:
+            pool.close()
+    g.close()
+    return {"threads": threads, "operations": (c1["handle_ops"] - c0["handle_ops"]) // reps,
+            "launches": round((c1["handle_launches"] - c0["handle_launches"]) / reps, 1),
+            "ms_per_add_by_handles": round(best[0] * 1e3, 3), "ms_inside_the_driver": round(best[1] * 1e3, 3),
+            "ms_per_add_as_one_graph": round(best_g * 1e3, 3), "by_handles_over_graph": round(best[0] / best_g, 2),
+            "word_equal_to_the_graph": bool(same)}
+
+
 def _bench_mul8_pool(eng, P, rank, world, per_gpu=8):
     """BASELINE config 5's shape: a pool of independent multiplications through the reference's 8 x 8 multiplier
     block (mux_circuits `unsigned_multiplier(8, 8)`: 3 228 CMUX in 126 levels + 16 bit conversions each), `per_gpu`

@@ -1885,6 +1885,9 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     p->max_wait = std::chrono::microseconds(max_wait_us);
     if (const char* e = getenv("SPF_POOL_GROUPS")) p->groups = (size_t)std::min(std::max(1, atoi(e)), spf_pool_impl::kMaxGroups);
     if (const char* e = getenv("SPF_POOL_PACE")) p->pace_div = atoi(e); // (experiments: -1 = no pacing)
+    if (const char* e = getenv("SPF_POOL_SPLIT")) p->split = (size_t)std::min(std::max(1, atoi(e)), 16);
+    if (const char* e = getenv("SPF_POOL_SPIN_US")) p->spin_us = std::max(0, atoi(e));
+    if (const char* e = getenv("SPF_POOL_HOT_US")) p->hot_us = std::max(0, atoi(e)); // (0: the launcher never polls; completers complete every batch)
     bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) == hipSuccess;
     for (auto& set : p->sets)
         streams_ok = streams_ok && hipStreamCreateWithFlags(&set.sk, hipStreamNonBlocking) == hipSuccess;
@@ -1900,17 +1903,18 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         if (const char* e = getenv("SPF_VALUE_CACHE_MB")) p->arena->cache_limit = (size_t)std::max(0L, atol(e)) << 20;
         p->launcher = std::thread([p] {
             p->launch_loop();
-            std::lock_guard<std::mutex> lk(p->mu);
+            std::lock_guard<spf_pool::Mutex> lk(p->mu);
             p->launcher_gone = true;
             for (auto& cv : p->cv_fly) cv.notify_all();
         });
         for (int i = 0; i < spf_pool_impl::kSets; i++) p->completers[i] = std::thread([p, i] { p->complete_loop(i); });
     } catch (const std::exception& e) { // std::system_error: no thread to be had — must not cross extern "C"
         {
-            std::lock_guard<std::mutex> lk(p->mu);
+            std::lock_guard<spf_pool::Mutex> lk(p->mu);
             p->stop = true;
             p->launcher_gone = !p->launcher.joinable();
         }
+        p->work_epoch++;
         p->cv_work.notify_all();
         if (p->launcher.joinable()) p->launcher.join();
         for (auto& cv : p->cv_fly) cv.notify_all();
@@ -1932,7 +1936,7 @@ spf_status spf_pool_set_max_inflight(spf_pool* p, size_t max_inflight)
         for (spf_pool* q : p->members) (void)spf_pool_set_max_inflight(q, max_inflight);
         return SPF_OK;
     }
-    std::lock_guard<std::mutex> lk(p->mu);
+    std::lock_guard<spf_pool::Mutex> lk(p->mu);
     p->max_inflight = max_inflight;
     p->cv_space.notify_all();
     return SPF_OK;
@@ -1947,12 +1951,13 @@ void spf_pool_destroy(spf_pool* p)
         return;
     }
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        std::lock_guard<spf_pool::Mutex> lk(p->mu);
         p->stop = true;
     }
     // wake everything that can be parked on this pool: the launcher (it closes and enqueues what is pending, then
     // leaves), producers blocked on back-pressure or on a staging set (they return an error), and waiters (their
     // batches complete: the completion thread outlives the launcher)
+    p->work_epoch++;
     p->cv_work.notify_all();
     p->cv_space.notify_all();
     p->cv_set.notify_all();
@@ -1962,9 +1967,9 @@ void spf_pool_destroy(spf_pool* p)
         if (t.joinable()) t.join();
     {
         // nobody may still be inside submit() / spf_pool_wait() on the mutex and condition variables freed below
-        std::unique_lock<std::mutex> lk(p->mu);
+        std::unique_lock<spf_pool::Mutex> lk(p->mu);
         p->cv_set.notify_all();
-        p->cv_idle.wait(lk, [&] { return p->blocked == 0; });
+        p->cv_idle.wait(lk, [&] { return p->blocked.load() == 0; });
         for (auto& b : p->collecting) // batches with tickets nobody collected
             b->destroy_events();
     }
@@ -2073,7 +2078,7 @@ spf_status spf_pool_stats(spf_pool* p, uint64_t* ops, uint64_t* launches)
         }
         return SPF_OK;
     }
-    std::lock_guard<std::mutex> lk(p->mu);
+    std::lock_guard<spf_pool::Mutex> lk(p->mu);
     *ops = p->n_ops; *launches = p->n_launches;
     return SPF_OK;
 }
@@ -2336,7 +2341,7 @@ spf_status spf_pool_counters_get(spf_pool* p, spf_pool_counters* out)
     if (!p || !out) return SPF_ERR_INVALID_ARGUMENT;
     *out = spf_pool_counters{};
     auto add = [&](spf_pool* q) {
-        std::lock_guard<std::mutex> lk(q->mu);
+        std::lock_guard<spf_pool::Mutex> lk(q->mu);
         out->ops += q->n_ops; out->launches += q->n_launches;
         out->handle_ops += q->n_handle_ops; out->handle_launches += q->n_handle_launches;
         out->reclaimed += q->n_reclaimed;

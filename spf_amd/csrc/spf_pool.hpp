@@ -79,7 +79,9 @@ enum Op {
 inline bool heavy(int op) { return op == OP_CBS || op == OP_GATE_CBS; }
 inline bool cmux_family(int op) { return op == OP_CMUX || op == OP_GLEV_CMUX || op == OP_MULTIPLY_GGSW_GLWE; }
 constexpr int kMaxGroups = 4;     // caller groups per operation kind: that many batches of a kind resident on the GPU at once
-constexpr int kSets = 2 * kMaxGroups; // per group one batch in flight / being collected and one filling
+constexpr int kSets = 4 * kMaxGroups; // per group one batch in flight / being collected and one filling; by handle up to split + 2 bootstrap batches
+                                      // resident beside the cheap kinds' batches
+
 constexpr size_t kMaxStagingBytes = (size_t)512 << 20; // per buffer of a set: caps the batch of the operations with 256 KiB outputs
 
 struct Slot {
@@ -88,6 +90,8 @@ struct Slot {
     uint8_t delivered; // 0: output still in the staging set; 1: being copied to `out` by reclaim() on the owner's behalf (the lock is
                        // dropped for the copy: a wait() that arrives meanwhile parks on cv_deliver); 2: in `out`
     uintptr_t who;  // the submitting thread (see `last_members`)
+    uint8_t claim;  // 0: nobody waits for the ticket yet; 1: its (one) waiter is inside spf_pool_wait; 2: collected.  Host-pointer
+                    // batches change it under the pool's mutex (reclaim() reads it there); by handle it is a lock-free CAS
     spf_value* vin[3]; // by handle: the operands (retained until the batch has run) ...
     spf_value* vout;   // ... and the result (the batch's own reference; the caller holds another)
 };
@@ -105,6 +109,42 @@ struct Staging {
     hipStream_t sk = nullptr; // this set's kernels (created with the pool)
     Scratch scr;              // ... and their intermediates
     size_t scr_cap = 0;       // operations the intermediates are sized for
+};
+
+inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expected);
+inline void futex_wake_all(std::atomic<uint32_t>* w);
+// The pool's mutex.  Its critical sections are a few hundred nanoseconds (slot bookkeeping) but dozens of callers reach them in
+// the same microseconds — the gates of one circuit level returning from their wait and submitting the next (r06: with a plain
+// pthread mutex every one of them slept on the futex and was woken in turn, a convoy of ~10 us per caller: 300 us per level of a
+// 32-bit adder).  So: spin briefly, then sleep (the three-state futex lock: 0 free, 1 held, 2 held with sleepers).
+struct PoolMutex {
+    std::atomic<uint32_t> s{0};
+    bool try_lock()
+    {
+        uint32_t z = 0;
+        return s.load(std::memory_order_relaxed) == 0 && s.compare_exchange_strong(z, 1, std::memory_order_acquire);
+    }
+    void lock()
+    {
+        for (int i = 0; i < 400; i++) {
+            if (try_lock()) return;
+            __builtin_ia32_pause();
+        }
+        uint32_t c = 0;
+        if (s.compare_exchange_strong(c, 1, std::memory_order_acquire)) return;
+        if (c != 2) c = s.exchange(2, std::memory_order_acquire);
+        while (c != 0) {
+            futex_wait(&s, 2);
+            c = s.exchange(2, std::memory_order_acquire);
+        }
+    }
+    void unlock()
+    {
+        if (s.fetch_sub(1, std::memory_order_release) != 1) {
+            s.store(0, std::memory_order_release);
+            (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&s), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+        }
+    }
 };
 
 inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expected)
@@ -158,6 +198,24 @@ struct Batch {
         chunk_word[w].store(1, std::memory_order_release);
         futex_wake_all(&chunk_word[w]);
     }
+    // By handle the waiters are woken as a TREE: they sleep in groups of eight on a word per group; whoever completes the batch
+    // sets every word, wakes group 0, and every waiter that comes through wakes one child group (group g's member j: group
+    // 8 g + 1 + j) before it goes on.  One thread waking a thousand sleepers one by one took 6 us each (r06: 1.5 ms of a 256-caller
+    // batch's 5.8 ms cycle); the tree is three levels deep.  The completing thread also walks all groups in order and wakes what
+    // nobody has woken yet, so a waiter that never comes (an abandoned ticket) leaves no group asleep.
+    static constexpr size_t kTreeGroup = 8;
+    std::unique_ptr<std::atomic<uint32_t>[]> gword, gwoken; // by handle: [cap / 8 + 1]
+    size_t n_groups() const { return (n + kTreeGroup - 1) / kTreeGroup; }
+    void wake_group(size_t g)
+    {
+        if (gwoken[g].exchange(1, std::memory_order_acq_rel) == 0) futex_wake_all(&gword[g]);
+    }
+    void wake_tree() // by the thread that completed the batch (n is final)
+    {
+        const size_t ng = n_groups();
+        for (size_t g = 0; g < ng; g++) gword[g].store(1, std::memory_order_release);
+        for (size_t g = 0; g < ng; g++) wake_group(g);
+    }
     void wake_chunk(int i) // the words of copy i
     {
         // (the last word stands for every slot from 64 * (kMaxWords - 1) on, however many: only the last copy wakes it)
@@ -167,6 +225,32 @@ struct Batch {
             if (chunk_word[w].load(std::memory_order_relaxed) == 0) wake_word(w);
     }
 };
+
+// open tickets -> (batch, slot), sharded by ticket number: a submit inserts and a wait erases under ONE shard's lock, not the
+// pool's (r06: with everything under the pool's mutex 64 callers of a 15 us CMUX took three turns each on one lock per gate)
+struct TicketShard {
+    PoolMutex mu;
+    std::unordered_map<uint64_t, std::pair<std::shared_ptr<Batch>, size_t>> map;
+};
+constexpr size_t kTicketShards = 64;
+
+// The synchronous caller — submit, then wait for that very ticket on the same thread, what a rayon task of the reference does —
+// finds its batch here without any lookup.
+struct LastSubmit {
+    uint64_t pool_gen = 0, ticket = 0;
+    std::shared_ptr<Batch> batch;
+    size_t slot = 0;
+};
+inline LastSubmit& last_submit()
+{
+    thread_local LastSubmit t;
+    return t;
+}
+inline uint64_t next_pool_generation()
+{
+    static std::atomic<uint64_t> g{1};
+    return g.fetch_add(1);
+}
 
 } // namespace spf_pool_impl
 
@@ -186,8 +270,9 @@ struct spf_pool {
     spf_params prm{};
     size_t max_batch = 4096;
     std::chrono::microseconds max_wait{200};
-    std::mutex mu;
-    std::condition_variable cv_work, cv_space, cv_set, cv_idle, cv_deliver;
+    using Mutex = spf_pool_impl::PoolMutex;
+    Mutex mu;
+    std::condition_variable_any cv_work, cv_space, cv_set, cv_idle, cv_deliver;
     static constexpr int kKinds = 2 * spf_pool_impl::N_OPS; // host-pointer kinds, then the same by handle
     static constexpr int kLanes = kKinds * spf_pool_impl::kMaxGroups;
     static int lane_of(int op, bool by_handle, int grp) { return ((by_handle ? spf_pool_impl::N_OPS : 0) + op) * spf_pool_impl::kMaxGroups + grp; }
@@ -199,23 +284,32 @@ struct spf_pool {
     std::deque<std::shared_ptr<Batch>> closing;                                     // closed, waiting for their members' input copies
     std::deque<std::shared_ptr<Batch>> in_flight;                                   // enqueued, each waited for by its set's completer
     std::deque<std::shared_ptr<Batch>> collecting;                                  // done, not yet fully collected
-    std::unordered_map<uint64_t, std::pair<std::shared_ptr<Batch>, size_t>> tickets; // open tickets -> (batch, slot)
-    std::unordered_set<uint64_t> claimed; // tickets some thread is already waiting for (a ticket has ONE waiter)
-    size_t blocked = 0;                   // callers inside submit() / wait(): destroy waits until they have left
-    size_t space_waiters = 0, set_waiters = 0; // submitters parked on back-pressure / on a staging set
+    spf_pool_impl::TicketShard tickets[spf_pool_impl::kTicketShards]; // open tickets -> (batch, slot)
+    spf_pool_impl::TicketShard& shard_of(uint64_t ticket) { return tickets[ticket % spf_pool_impl::kTicketShards]; }
+    std::atomic<size_t> n_open{0};        // open tickets (back-pressure)
+    const uint64_t gen = spf_pool_impl::next_pool_generation(); // (a new pool at a recycled address is another pool: LastSubmit)
+    std::atomic<size_t> blocked{0};       // callers inside submit() / wait(): destroy waits until they have left
+    std::atomic<size_t> space_waiters{0};  // submitters parked on back-pressure
+    size_t set_waiters = 0;                // ... / on a staging set
     size_t max_inflight = 16384;          // submit blocks while this many tickets are open (back-pressure)
-    size_t heavy_open = 0;                // open tickets of the bootstrap kinds: the population that shapes their batches
+    std::atomic<size_t> heavy_open{0};    // open tickets of the bootstrap kinds: the population that shapes their batches
     size_t groups = 0;                    // caller groups in use: 0 = by population (groups_now), else SPF_POOL_GROUPS = 1 .. kMaxGroups
     int pace_div = 0;                     // pacing: a batch starts no sooner than 1 / pace_div of a batch's GPU time after the previous one (0 = groups; SPF_POOL_PACE)
     uint64_t next_ticket = 1;
     uint64_t n_ops = 0, n_launches = 0;
-    bool stop = false;
+    std::atomic<bool> stop{false};
     std::thread launcher, completers[spf_pool_impl::kSets];
     spf_pool_impl::Staging sets[spf_pool_impl::kSets];
     std::shared_ptr<Batch> flying[spf_pool_impl::kSets]; // the enqueued batch of each set (one at most)
-    std::condition_variable cv_fly[spf_pool_impl::kSets];
+    std::condition_variable_any cv_fly[spf_pool_impl::kSets];
     uint64_t n_reclaimed = 0;             // outputs delivered on their owners' behalf (reclaim)
     uint64_t n_handle_ops = 0, n_handle_launches = 0;
+    size_t split = 4;                     // by handle a bootstrap batch goes as soon as it holds 1 / split of the callers (SPF_POOL_SPLIT; see submit_impl)
+    int spin_us = 40;                     // how long a waiter of a cheap operation by handle looks before it sleeps (SPF_POOL_SPIN_US)
+    int hot_us = 300;                     // how long the launcher keeps polling after its last piece of work (SPF_POOL_HOT_US)
+    std::atomic<uint64_t> work_epoch{0};  // bumped whenever the launcher has something new to look at
+    std::atomic<bool> launcher_asleep{false};
+    std::vector<std::shared_ptr<Batch>> polling; // the launcher's own: cheap batches by handle it enqueued and completes itself
     uint64_t n_shape[3] = {0, 0, 0};      // bootstrap launches by blind-rotation shape: eight waves per ciphertext / two / four per workgroup
     hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
@@ -362,6 +456,14 @@ struct spf_pool {
         return spf_pool_impl::cmux_family(op) && !ctx->generic && prm.cbs_radix_log == 4 && prm.cbs_radix_count == 4;
     }
 
+    // `mu` held: the launcher has something new to look at.  It is only sent a wake-up (a system call) when it sleeps: while
+    // operations keep coming it polls `work_epoch`.
+    void poke()
+    {
+        work_epoch.fetch_add(1, std::memory_order_release);
+        if (launcher_asleep.load(std::memory_order_acquire)) cv_work.notify_all();
+    }
+
     spf_status submit(int op, const void* a, const void* b_in, const void* c, void* out, uint64_t* ticket, uint64_t param = 0)
     {
         if (!a || !out || !ticket) return SPF_ERR_INVALID_ARGUMENT;
@@ -379,13 +481,16 @@ struct spf_pool {
                            uint64_t* ticket, uint64_t param)
     {
         using namespace spf_pool_impl;
-        std::unique_lock<std::mutex> lk(mu);
         blocked++;
-        struct Leave { spf_pool* p; ~Leave() { p->blocked--; if (p->stop) p->cv_idle.notify_all(); } } leave{this};
+        // (the last one out tells a destroy that waits for everybody to leave; the destroyer re-checks under the mutex)
+        struct Leave { spf_pool* p; ~Leave() { if (--p->blocked == 0 && p->stop) { std::lock_guard<Mutex> g(p->mu); p->cv_idle.notify_all(); } } } leave{this};
+        std::unique_lock<Mutex> lk(mu);
         // back-pressure: a producer that runs ahead of its own waits blocks here instead of growing the queues
-        space_waiters++;
-        cv_space.wait(lk, [&] { return stop || tickets.size() < max_inflight; });
-        space_waiters--;
+        if (n_open.load() >= max_inflight) {
+            space_waiters++;
+            cv_space.wait(lk, [&] { return stop || n_open.load() < max_inflight; });
+            space_waiters--;
+        }
         if (stop) return SPF_ERR_INVALID_ARGUMENT;
         // The caller's group: dealt round-robin on the thread's first submit, kept from then on.  The threads of a group meet in
         // the same batches, call after call — so a group's batch is complete the moment the members of its previous batch are
@@ -393,7 +498,7 @@ struct spf_pool {
         // (By handle only the bootstrap kinds are dealt to groups: the cheap kinds are one batch per launch.)
         const uintptr_t who = (uintptr_t)pthread_self();
         int grp = 0;
-        if (!by_handle || heavy(op)) {
+        if (!by_handle) {
             size_t arrival;
             auto it = home_group.find(who);
             if (it != home_group.end()) arrival = it->second;
@@ -445,7 +550,13 @@ struct spf_pool {
             if (stop) { sets[set].busy = false; return SPF_ERR_INVALID_ARGUMENT; }
             try {
                 b = std::make_shared<Batch>();
-                b->slots.reserve(cap);
+                b->slots.resize(cap); // (never grows: a slot's address is stable, its owner reads it without the mutex)
+                if (by_handle) {
+                    const size_t ng = cap / Batch::kTreeGroup + 1;
+                    b->gword.reset(new std::atomic<uint32_t>[ng]);
+                    b->gwoken.reset(new std::atomic<uint32_t>[ng]);
+                    for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); }
+                }
             } catch (const std::exception&) {
                 sets[set].busy = false;
                 cv_set.notify_all();
@@ -455,21 +566,24 @@ struct spf_pool {
             filling[lane] = b;
             break;
         }
-        size_t slot;
-        try {
-            slot = b->n;
-            b->slots.push_back(Slot{out, next_ticket, 0, who, {nullptr, nullptr, nullptr}, nullptr});
-            // a caller "comes back" when it submits with nothing else outstanding (the synchronous pattern); a thread that
-            // submits many tickets before it waits for any is not waited for — its batches close on the timer or when full
-            int& mine_open = open_by_thread[who]; // (may allocate: before the ticket exists)
-            tickets.emplace(next_ticket, std::make_pair(b, slot));
-            if (mine_open == 0 && std::binary_search(last_members[lane].begin(), last_members[lane].end(), who)) b->n_returning++;
-            mine_open++;
-        } catch (const std::exception&) {
-            if (b->slots.size() > b->n) b->slots.pop_back();
-            return SPF_ERR_HIP;
+        const size_t slot = b->n;
+        const uint64_t my_ticket = next_ticket;
+        b->slots[slot] = Slot{out, my_ticket, 0, who, 0, {nullptr, nullptr, nullptr}, nullptr};
+        // a caller "comes back" when it submits with nothing else outstanding (the synchronous pattern); a thread that
+        // submits many tickets before it waits for any is not waited for — its batches close on the timer or when full.
+        // (Only where batches are closed by who is back: not for the cheap kinds by handle.)
+        const bool tracks_callers = !by_handle;
+        if (tracks_callers) {
+            try {
+                int& mine_open = open_by_thread[who]; // (may allocate)
+                if (mine_open == 0 && std::binary_search(last_members[lane].begin(), last_members[lane].end(), who)) b->n_returning++;
+                mine_open++;
+            } catch (const std::exception&) {
+                return SPF_ERR_HIP;
+            }
         }
         if (heavy(op)) heavy_open++;
+        n_open++;
         if (by_handle) { // the operands stay alive until the batch has run; the batch holds its own reference to the result
             Slot& sl = b->slots[slot];
             for (int k = 0; k < 3; k++)
@@ -484,18 +598,42 @@ struct spf_pool {
         if (b->n == b->cap) {
             cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(lane);
-        } else if (everybody_is_back(*b)) {
-            cv_work.notify_all(); // the launcher need not wait for more
+        } else if (by_handle && heavy(op) && b->n * split >= heavy_population(b->t_last)) {
+            // By handle a caller is back microseconds after its result (nothing to copy out), so the callers need no dealing into
+            // groups that meet again: a bootstrap batch simply goes as soon as it holds a quarter of the callers in the pool
+            // (or nobody has joined it for max_wait), on the workgroup shape of the whole population — up to four or five
+            // batches tile the CUs side by side, each on its set's stream, and whoever comes back meanwhile is the next one.
+            // A 32-bit adder's 64 conversions are four launches within the time the callers take to arrive, not four paced
+            // quarter batches; 1 024 synchronous callers keep four batches of 256 in flight.
+            close_batch(lane);
+        } else if (tracks_callers && everybody_is_back(*b)) {
+            poke(); // the launcher need not wait for more
         }
         if (by_handle) { // nothing to copy: the slot is ready as it stands
             b->n_ready++;
-            if (slot == 0 || (b->closed && b->n_ready == b->n)) cv_work.notify_all();
-            return SPF_OK;
+            if (slot == 0 || (b->closed && b->n_ready == b->n)) poke();
         }
+        lk.unlock();
+        // the ticket becomes findable (by any thread) and, for this thread, findable without looking
+        bool registered = true;
+        {
+            TicketShard& sh = shard_of(my_ticket);
+            std::lock_guard<PoolMutex> g(sh.mu);
+            try {
+                sh.map.emplace(my_ticket, std::make_pair(b, slot));
+            } catch (const std::exception&) {
+                registered = false; // (out of host memory: the ticket can still be waited for by THIS thread, below)
+            }
+        }
+        {
+            LastSubmit& ls = last_submit();
+            ls.pool_gen = gen; ls.ticket = my_ticket; ls.batch = b; ls.slot = slot;
+        }
+        (void)registered;
+        if (by_handle) return SPF_OK;
         size_t in[3], outsz;
         in_out_sizes(op, in, outsz);
-        const Staging& s = sets[b->set];
-        lk.unlock();
+        const Staging& s = sets[b->set]; // (a set's buffers are stable while its batch is open)
         // the caller's own bytes, by the caller's own thread, straight into pinned memory
         for (int k = 0; k < 3; k++)
             if (in[k]) std::memcpy(static_cast<uint8_t*>(s.h_in[k]) + slot * in[k], src[k], in[k]);
@@ -503,7 +641,7 @@ struct spf_pool {
         b->n_ready++;
         // the launcher sleeps until something changes for it: a batch got its first member (its deadline starts), or a
         // closed batch just got its last input
-        if (slot == 0 || (b->closed && b->n_ready == b->n)) cv_work.notify_all();
+        if (slot == 0 || (b->closed && b->n_ready == b->n)) poke();
         return SPF_OK;
     }
 
@@ -520,6 +658,19 @@ struct spf_pool {
     // keeps coming back.  (Tickets of the cheap kinds do not count: a thousand open CMUX gates say nothing about how many
     // bootstraps the next batches will hold.)
     size_t population() const { return heavy_open; }
+    // ... and, for the quarter rule of the bootstrap batches by handle, the most callers seen at once lately: while a crowd of
+    // callers is still arriving (the conversions of a circuit becoming ready one after the other) the open tickets undercount it
+    size_t heavy_peak = 0;
+    std::chrono::steady_clock::time_point heavy_peak_at{};
+    size_t heavy_population(std::chrono::steady_clock::time_point now)
+    {
+        const size_t open = heavy_open.load();
+        if (open >= heavy_peak || now - heavy_peak_at > std::chrono::milliseconds(100)) {
+            heavy_peak = open;
+            heavy_peak_at = now;
+        }
+        return heavy_peak;
+    }
     // Caller groups in use.  Measured (tools/pool_bench.py, fraction of the device-resident rate; profiles/r05_pool.md):
     //   callers      32    64    128   256   384   512   768   1024  1536  2048
     //   2 groups    0.88  0.91  0.77  0.71  0.81  0.67  0.77  0.73  0.88  0.53
@@ -541,10 +692,10 @@ struct spf_pool {
         const size_t pop = population(), n_cu = (size_t)ctx->n_cu;
         return pop <= n_cu ? 1 : (pop <= 2 * n_cu ? 2 : 4);
     }
-    size_t running() const // bootstrap batches whose kernels are on the GPU
+    size_t running() const // host-pointer bootstrap batches whose kernels are on the GPU
     {
         size_t r = 0;
-        for (auto& f : in_flight) r += (f->kernels_done || !spf_pool_impl::heavy(f->op)) ? 0 : 1;
+        for (auto& f : in_flight) r += (f->kernels_done || f->by_handle || !spf_pool_impl::heavy(f->op)) ? 0 : 1;
         return r;
     }
 
@@ -569,11 +720,11 @@ struct spf_pool {
         }
         outstanding[lane]++;
         closing.push_back(b);
-        cv_work.notify_all();
+        poke();
     }
 
     // `mu` held.  Deliver the uncollected outputs of done batches that have waited longer than the grace period.
-    void reclaim(std::unique_lock<std::mutex>& lk)
+    void reclaim(std::unique_lock<Mutex>& lk)
     {
         const auto now = std::chrono::steady_clock::now();
         for (size_t bi = 0; bi < collecting.size(); bi++) {
@@ -581,9 +732,7 @@ struct spf_pool {
             if (now - b->t_done < grace) continue;
             for (size_t i = 0; i < b->n; i++) {
                 spf_pool_impl::Slot& sl = b->slots[i];
-                if (sl.delivered || claimed.count(sl.ticket)) continue; // (a claimed ticket's waiter is copying right now)
-                auto it = tickets.find(sl.ticket);
-                if (it == tickets.end()) continue;                      // collected already
+                if (sl.delivered || sl.claim != 0) continue; // (a claimed ticket's waiter is copying right now, or has collected it)
                 if (b->st == SPF_OK) {
                     sl.delivered = 1; // (a wait() for this ticket that arrives during the copy must not return before it ends:
                     lk.unlock();      //  the caller may free or read `out` the moment wait returns, spf_hip.h)
@@ -601,43 +750,91 @@ struct spf_pool {
 
     spf_status wait(uint64_t ticket)
     {
+        using namespace spf_pool_impl;
+        blocked++;
+        struct Leave { spf_pool* p; ~Leave() { if (--p->blocked == 0 && p->stop) { std::lock_guard<Mutex> g(p->mu); p->cv_idle.notify_all(); } } } leave{this};
         std::shared_ptr<Batch> b;
-        size_t slot;
+        size_t slot = 0;
         {
-            std::lock_guard<std::mutex> lk(mu);
-            // a ticket can be waited for exactly once: unknown, already collected, or already being waited for by
-            // another thread is an error (not a hang) — the claim is taken under the same lock as the check
-            auto it = tickets.find(ticket);
-            if (it == tickets.end() || !claimed.insert(ticket).second) return SPF_ERR_INVALID_ARGUMENT;
-            b = it->second.first;
-            slot = it->second.second;
-            blocked++;
-        }
-        // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
-        std::atomic<uint32_t>& word = b->chunk_word[spf_pool_impl::Batch::word_of(slot)];
-        while (word.load(std::memory_order_acquire) == 0) spf_pool_impl::futex_wait(&word, 0);
-        const spf_status st = b->st;
-        // (`delivered` leaves 0 only for an unclaimed ticket, under the mutex this thread's claim went through: what this thread
-        // reads here without the lock is either 0 for good, or the 1 / 2 that reclaim() set before the claim)
-        if (!b->by_handle && st == SPF_OK && b->slots[slot].delivered == 0) deliver(*b, slot); // this caller's output, by this caller's thread
-        std::unique_lock<std::mutex> lk(mu);
-        if (!b->by_handle) { // (a handle batch has nothing to collect: its set went back when it completed)
-            cv_deliver.wait(lk, [&] { return b->slots[slot].delivered != 1; }); // a delivery on this ticket's behalf is still copying
-            if (b->slots[slot].delivered == 0) {
-                b->slots[slot].delivered = 2;
-                collected_one(b);
+            LastSubmit& ls = last_submit();
+            if (ls.pool_gen == gen && ls.ticket == ticket && ls.batch) { // the synchronous caller: its own last submit
+                b = std::move(ls.batch);
+                slot = ls.slot;
+                ls.ticket = 0;
+            } else {
+                TicketShard& sh = shard_of(ticket);
+                std::lock_guard<PoolMutex> g(sh.mu);
+                auto it = sh.map.find(ticket);
+                if (it == sh.map.end()) return SPF_ERR_INVALID_ARGUMENT; // unknown or already collected: an error, not a hang
+                b = it->second.first;
+                slot = it->second.second;
             }
         }
-        if (spf_pool_impl::heavy(b->op) && heavy_open) heavy_open--;
-        tickets.erase(ticket);
-        claimed.erase(ticket);
-        {
-            auto it = open_by_thread.find(b->slots[slot].who);
-            if (it != open_by_thread.end() && --it->second <= 0) open_by_thread.erase(it);
+        // a ticket can be waited for exactly once: a second waiter (or a wait after it was collected) is an error
+        Slot& sl = b->slots[slot];
+        if (b->by_handle) {
+            uint8_t zero = 0;
+            if (!__atomic_compare_exchange_n(&sl.claim, &zero, (uint8_t)1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) return SPF_ERR_INVALID_ARGUMENT;
+        } else {
+            std::lock_guard<Mutex> lk(mu); // (reclaim() decides under the mutex whether a ticket has a waiter)
+            if (sl.claim != 0) return SPF_ERR_INVALID_ARGUMENT;
+            sl.claim = 1;
         }
-        blocked--;
-        if (space_waiters) cv_space.notify_all();
-        if (stop) cv_idle.notify_all();
+        // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
+        const bool is_heavy = heavy(b->op);
+        if (b->by_handle) {
+            const size_t g = slot / Batch::kTreeGroup;
+            std::atomic<uint32_t>& word = b->gword[g];
+            if (!is_heavy && spin_us > 0) {
+                // a cheap operation is back in tens of microseconds: look for a moment before going to sleep (a sleeping thread
+                // costs its waker a system call and itself a wake-up, ~40 us end to end on the bench's host)
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+                for (int i = 0; word.load(std::memory_order_acquire) == 0; i++) {
+                    for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+                    if ((i & 7) == 7) {
+                        if (std::chrono::steady_clock::now() >= until) break;
+                        (void)sched_yield(); // (more callers than CPUs: the ones that still have to submit go first)
+                    }
+                }
+            }
+            while (word.load(std::memory_order_acquire) == 0) futex_wait(&word, 0);
+            const size_t child = Batch::kTreeGroup * g + 1 + slot % Batch::kTreeGroup; // this waiter's share of the waking
+            if (child < b->n_groups()) b->wake_group(child);
+        } else {
+            std::atomic<uint32_t>& word = b->chunk_word[Batch::word_of(slot)];
+            while (word.load(std::memory_order_acquire) == 0) futex_wait(&word, 0);
+        }
+        const spf_status st = b->st;
+        if (!b->by_handle) {
+            // (`delivered` leaves 0 only for an unclaimed ticket, under the mutex this thread's claim went through: what this
+            // thread reads here without the lock is either 0 for good, or the 1 / 2 that reclaim() set before the claim)
+            if (st == SPF_OK && sl.delivered == 0) deliver(*b, slot); // this caller's output, by this caller's thread
+            std::unique_lock<Mutex> lk(mu);
+            cv_deliver.wait(lk, [&] { return sl.delivered != 1; }); // a delivery on this ticket's behalf is still copying
+            if (sl.delivered == 0) {
+                sl.delivered = 2;
+                collected_one(b);
+            }
+            sl.claim = 2;
+            auto it = open_by_thread.find(sl.who);
+            if (it != open_by_thread.end() && --it->second <= 0) open_by_thread.erase(it);
+        } else {
+            __atomic_store_n(&sl.claim, (uint8_t)2, __ATOMIC_RELEASE);
+        }
+        {
+            TicketShard& sh = shard_of(ticket);
+            std::lock_guard<PoolMutex> g(sh.mu);
+            sh.map.erase(ticket);
+        }
+        if (is_heavy) {
+            size_t h = heavy_open.load();
+            while (h && !heavy_open.compare_exchange_weak(h, h - 1)) {}
+        }
+        n_open--;
+        if (space_waiters.load()) {
+            std::lock_guard<Mutex> lk(mu);
+            cv_space.notify_all();
+        }
         return st;
     }
 
@@ -788,14 +985,82 @@ struct spf_pool {
         return SPF_OK;
     }
 
+    // A batch by handle has completed (or failed): its results become visible, its operands are let go, its staging set is free,
+    // its waiters are woken.  Called without `mu` by whoever saw the batch's event: its set's completer, or — the cheap kinds —
+    // the launcher itself.
+    void finish_handle_batch(const std::shared_ptr<Batch>& b)
+    {
+        using namespace spf_pool_impl;
+        const int state = b->st == SPF_OK ? spf_value_impl::READY : spf_value_impl::FAILED;
+        for (size_t i = 0; i < b->n; i++) { // (outside the lock: the last reference to a value gives its block back to the arena)
+            Slot& sl = b->slots[i];
+            sl.vout->state.store(state, std::memory_order_release);
+            sl.vout->release();
+            sl.vout = nullptr;
+            for (spf_value*& v : sl.vin)
+                if (v) { v->release(); v = nullptr; }
+        }
+        b->out_blk.reset();
+        {
+            std::lock_guard<Mutex> lk(mu);
+            last_gpu_span[b->op] = b->t_sync - b->t_enq;
+            b->kernels_done = true;
+            for (auto it = in_flight.begin(); it != in_flight.end(); ++it)
+                if (it->get() == b.get()) { in_flight.erase(it); break; }
+            b->done = true;
+            b->t_done = std::chrono::steady_clock::now();
+            last_done = b->t_done;
+#ifdef SPF_POOL_TRACE
+            {
+                auto us = [](auto d) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(d).count(); };
+                fprintf(stderr, "[pool] batch op %d (by handle) n %zu: filled %ld us, closed->ready %ld us, enqueue %ld us, enqueued->event %ld us, event->marked %ld us\n", b->op, b->n,
+                        us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), us(b->t_done - b->t_sync));
+            }
+#endif
+            sets[b->set].busy = false; // nothing to collect: the staging set is free again
+            b->destroy_events();
+            if (set_waiters) cv_set.notify_all();
+            n_handle_launches++;
+            n_handle_ops += b->n;
+            outstanding[b->lane]--;
+            n_launches++;
+            n_ops += b->n;
+            poke(); // the launcher closes the batch that filled meanwhile
+        }
+        b->wake_tree();
+    }
+
     void launch_loop()
     {
         using namespace spf_pool_impl;
         using clock = std::chrono::steady_clock;
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // the quiet times below are tens of microseconds: the default slack is 50
-        std::unique_lock<std::mutex> lk(mu);
+        std::unique_lock<Mutex> lk(mu);
+        auto hot_until = clock::now();
         for (;;) {
-            const auto now = clock::now();
+            auto now = clock::now();
+            // 0. the cheap batches by handle this thread enqueued: it also completes them (a 15 us CMUX level handed to a
+            // completer thread costs that thread's wake-up — more than the kernel — before anybody looks at the event)
+            if (!polling.empty()) {
+                lk.unlock();
+                for (size_t i = 0; i < polling.size();) {
+                    Batch& b = *polling[i];
+                    const hipError_t e = hipEventQuery(b.ev_k);
+                    if (e == hipErrorNotReady) { i++; continue; }
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        b.st = SPF_ERR_HIP;
+                        (void)hipStreamSynchronize(sets[b.set].sk);
+                    }
+                    b.t_sync = clock::now();
+                    std::shared_ptr<Batch> done = polling[i];
+                    polling.erase(polling.begin() + (long)i);
+                    finish_handle_batch(done);
+                }
+                lk.lock();
+                now = clock::now();
+                hot_until = now + std::chrono::microseconds(hot_us);
+            }
             auto wake = clock::time_point::max();
             // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in (the first one that can go:
             // a batch whose members are still copying does not hold up the ones behind it)
@@ -808,7 +1073,7 @@ struct spf_pool {
                 // idles through the common turn-around.  A batch therefore starts no sooner than a 1 / groups share of a batch's
                 // time on the GPU after the previous one: once spread out, the groups keep their phases (each comes back one cycle
                 // later), and while one copies out and resubmits the others compute.
-                if (!stop && heavy(b.op) && running() > 0 && pace_div >= 0) {
+                if (!stop && heavy(b.op) && !b.by_handle && running() > 0 && pace_div >= 0) {
                     const auto due = last_enq + std::min<clock::duration>(last_gpu_span[b.op] / (pace_div > 0 ? pace_div : (int)groups_now()), std::chrono::milliseconds(5));
                     if (now < due) { wake = std::min(wake, due); continue; }
                 }
@@ -836,8 +1101,19 @@ struct spf_pool {
                 b->st = st;
                 b->t_enq = clock::now();
                 in_flight.push_back(b);
-                flying[b->set] = b;
-                cv_fly[b->set].notify_one();
+                bool mine = false;
+                if (b->by_handle && !heavy(b->op) && st == SPF_OK && hot_us > 0) {
+                    try {
+                        polling.push_back(b);
+                        mine = true;
+                    } catch (const std::exception&) {
+                    }
+                }
+                if (!mine) {
+                    flying[b->set] = b;
+                    cv_fly[b->set].notify_one();
+                }
+                hot_until = b->t_enq + std::chrono::microseconds(hot_us);
                 continue;
             }
             // 2. time-based closing.  A group's batch is complete when the members of its previous batch are all back (submit
@@ -852,10 +1128,14 @@ struct spf_pool {
                 const int op = filling[k]->op;
                 // its group's previous batch is still out: the callers are not back yet (the cheap kinds by handle are fed by
                 // whoever has an operation ready — the gates of a circuit's next level — not by returning callers)
-                if (outstanding[k] > 0 && !stop && (heavy(op) || !filling[k]->by_handle)) continue;
-                const auto quiet = std::max(std::chrono::duration_cast<clock::duration>(max_wait),
-                                            std::min<clock::duration>(last_gpu_span[op] / 8, std::chrono::milliseconds(2)));
-                const auto due = (stop || everybody_is_back(*filling[k])) ? now : std::min(filling[k]->t_last + quiet, filling[k]->t0 + 20 * quiet);
+                if (outstanding[k] > 0 && !stop && !filling[k]->by_handle) continue;
+                const auto quiet = filling[k]->by_handle ? std::chrono::duration_cast<clock::duration>(max_wait)
+                                   : std::max(std::chrono::duration_cast<clock::duration>(max_wait),
+                                              std::min<clock::duration>(last_gpu_span[op] / 8, std::chrono::milliseconds(2)));
+                // (the cheap kinds by handle: at most four quiet times — the gates of a circuit level trickle in as their callers
+                // wake up, and the ones that are there should not wait for the last)
+                const int max_quiets = (filling[k]->by_handle && !heavy(op)) ? 4 : 20;
+                const auto due = (stop || everybody_is_back(*filling[k])) ? now : std::min(filling[k]->t_last + quiet, filling[k]->t0 + max_quiets * quiet);
                 if (lane < 0 || due < best) { lane = k; best = due; }
             }
             if (lane >= 0 && now >= best) {
@@ -863,12 +1143,25 @@ struct spf_pool {
                 continue;
             }
             if (lane >= 0) wake = std::min(wake, best);
-            if (wake == clock::time_point::max()) {
-                if (stop && closing.empty()) return;
-                cv_work.wait(lk);
-            } else {
-                cv_work.wait_until(lk, wake);
+            if (stop && closing.empty() && polling.empty() && lane < 0) return;
+            // 3. nothing to do right now.  While cheap operations by handle are in flight or were a moment ago, poll (the event
+            // of a 15 us kernel, the next level's submits): going to sleep costs a wake-up per circuit level.  Otherwise sleep
+            // until the next deadline or the next poke.
+            if (!polling.empty() || now < hot_until) {
+                const uint64_t seen = work_epoch.load(std::memory_order_acquire);
+                lk.unlock();
+                const auto until = std::min(wake, polling.empty() ? hot_until : now + std::chrono::microseconds(2));
+                for (int i = 0; work_epoch.load(std::memory_order_acquire) == seen; i++) {
+                    for (int k = 0; k < 16; k++) __builtin_ia32_pause();
+                    if ((i & 3) == 3 && clock::now() >= until) break;
+                }
+                lk.lock();
+                continue;
             }
+            launcher_asleep.store(true, std::memory_order_release);
+            if (wake == clock::time_point::max()) cv_work.wait(lk);
+            else cv_work.wait_until(lk, wake);
+            launcher_asleep.store(false, std::memory_order_release);
         }
     }
 
@@ -877,7 +1170,7 @@ struct spf_pool {
     void complete_loop(int si)
     {
         using namespace spf_pool_impl;
-        std::unique_lock<std::mutex> lk(mu);
+        std::unique_lock<Mutex> lk(mu);
         for (;;) {
             cv_fly[si].wait(lk, [&] { return flying[si] || (stop && launcher_gone); });
             if (!flying[si]) return;
@@ -897,7 +1190,7 @@ struct spf_pool {
                 lk.lock();
                 b->kernels_done = true;
                 last_gpu_span[b->op] = std::chrono::steady_clock::now() - b->t_enq;
-                cv_work.notify_all();
+                poke();
                 lk.unlock();
                 if (!k_ok) b->st = SPF_ERR_HIP;
                 // all chunks but the last: their waiters copy out while the rest is still on its way.  (A failure from here on
@@ -915,21 +1208,14 @@ struct spf_pool {
                 (void)hipStreamSynchronize(sets[b->set].sk);
             }
             if (b->by_handle) {
-                // the results become visible, the operands are let go (outside the lock: the last reference to a value gives its
-                // block back to the arena)
-                const int state = b->st == SPF_OK ? spf_value_impl::READY : spf_value_impl::FAILED;
-                for (size_t i = 0; i < b->n; i++) {
-                    Slot& sl = b->slots[i];
-                    sl.vout->state.store(state, std::memory_order_release);
-                    sl.vout->release();
-                    sl.vout = nullptr;
-                    for (spf_value*& v : sl.vin)
-                        if (v) { v->release(); v = nullptr; }
-                }
-                b->out_blk.reset();
+                lk.lock();
+                flying[si].reset();
+                lk.unlock();
+                finish_handle_batch(b);
+                lk.lock();
+                continue;
             }
             lk.lock();
-            if (b->by_handle) last_gpu_span[b->op] = b->t_sync - b->t_enq;
             b->kernels_done = true;
             for (auto it = in_flight.begin(); it != in_flight.end(); ++it)
                 if (it->get() == b.get()) { in_flight.erase(it); break; }
@@ -947,22 +1233,13 @@ struct spf_pool {
                         us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), gpu_ms * 1e3f, us(b->t_done - b->t_sync));
             }
 #endif
-            if (b->by_handle) {
-                // nothing to collect: the staging set is free again
-                sets[b->set].busy = false;
-                b->destroy_events();
-                if (set_waiters) cv_set.notify_all();
-                n_handle_launches++;
-                n_handle_ops += b->n;
-            } else {
-                collecting.push_back(b);
-            }
+            collecting.push_back(b);
             outstanding[b->lane]--;
             n_launches++;
             n_ops += b->n;
             for (int w = 0; w < spf_pool_impl::Batch::kMaxWords; w++) // the last chunk — or, for a batch that failed, all of them
                 if (b->chunk_word[w].load(std::memory_order_relaxed) == 0) b->wake_word(w);
-            cv_work.notify_all(); // the launcher closes the batch that filled meanwhile
+            poke(); // the launcher closes the batch that filled meanwhile
         }
     }
     bool launcher_gone = false;

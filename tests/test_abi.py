@@ -147,3 +147,47 @@ def test_generate_lut_matches_the_oracle_and_rejects_out_of_range_maps():
         assert np.array_equal(got, O.trivial_lut_glwe(O.generate_lut(P.N, fns, bits), P)), (bits, len(fns))
     with pytest.raises(spf_amd.SpfError):
         spf_amd.generate_lut([lambda x: 8], 3)
+
+
+def test_generated_rust_binding_covers_the_header(lib):
+    """tools/gen_rust_ffi.py (VERDICT r05 task 4): the committed include/spf_hip.rs is what the generator makes of the header
+    today, holds every function, struct and constant the header declares with pointer constness carried over, and the library
+    exports exactly the header's functions (`make -C spf_amd/csrc check`)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    hdr_path = os.path.join(ROOT, "include", "spf_hip.h")
+    h = gen.Header(hdr_path)
+    rust = h.rust()
+    assert rust == open(os.path.join(ROOT, "include", "spf_hip.rs")).read(), "include/spf_hip.rs is stale: make -C spf_amd/csrc rust-ffi"
+    hdr = re.sub(r"/\*.*?\*/", "", open(hdr_path).read(), flags=re.S)
+    declared = set(re.findall(r"\b(spf_[a-z0-9_]+)\s*\(", hdr))
+    assert {n for n, _, _ in h.functions} == declared
+    for name in declared:
+        assert re.search(rf"pub fn {name}\(", rust), name
+    for const in re.findall(r"\b(SPF_[A-Z0-9_]+)\b", hdr):
+        if const != "SPF_HIP_H":
+            assert f"pub const {const}:" in rust, const
+    # spot checks of the type mapping
+    assert "pub fn spf_create(params: *const spf_params, device_id: c_int, out: *mut *mut spf_ctx) -> spf_status;" in rust
+    assert "pub fn spf_destroy(ctx: *mut spf_ctx);" in rust
+    assert "pub fn spf_cmux_scattered_dev(ctx: *mut spf_ctx, stream: *mut c_void, units: usize, d_ptrs: *const *const c_void) -> spf_status;" in rust
+    assert "pub fn spf_pool_submit_cmux_v(pool: *mut spf_pool, sel_ggsw: *const spf_value, a: *const spf_value, b: *const spf_value, out: *mut *mut spf_value, ticket: *mut u64) -> spf_status;" in rust
+    assert "pub bootstrap_launches_by_shape: [u64; 3]," in rust
+    assert gen.exported_symbols(spf_amd.lib_path()) == sorted(declared)
+
+
+def test_makefile_describes_the_same_build():
+    """spf_amd/csrc/Makefile (the build a non-Python host uses) compiles the same translation unit with the same flags as
+    spf_amd/build.py; `make -n` resolves (hipcc need not run here)."""
+    import subprocess
+    from spf_amd import build
+    mk = os.path.join(ROOT, "spf_amd", "csrc", "Makefile")
+    out = subprocess.run(["make", "-n", "-B", "-f", mk, "all"], capture_output=True, text=True, check=True).stdout
+    line = next(l for l in out.splitlines() if "hipcc" in l)
+    for flag in build.HIPCC_FLAGS:
+        assert flag in line.split(), flag
+    assert line.rstrip().endswith("spf_hip.hip") and "libspf_hip.so.tmp" in line
+    pc = subprocess.run(["make", "-n", "-f", mk, "install", "PREFIX=/tmp/spf_prefix"], capture_output=True, text=True, check=True).stdout
+    assert "spf_hip.pc" in pc and "/tmp/spf_prefix/include" in pc and "spf_evaluation.hpp" in pc

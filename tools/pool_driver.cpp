@@ -74,9 +74,11 @@ long spf_pool_drive_collect(spf_pool* pool, submit_fn submit, wait_fn wait, int 
 
 // ---- r06: the same scenario BY HANDLE (device-resident values, include/spf_hip.h "device-resident values") --------------------
 
-#include <condition_variable>
+#include <climits>
 #include <deque>
-#include <mutex>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 extern "C" {
 
@@ -199,24 +201,40 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
             if (op[src] >= 0) { deps[i].fetch_add(1); dependents[src].push_back(i); }
         }
     }
-    std::mutex mu;
-    std::condition_variable cv;
+    // (the ready queue is touched for a few hundred nanoseconds at a time by dozens of workers at once: a spin lock; idle workers
+    // sleep on a futex word that counts queue pushes.  A worker that makes operations ready runs one of them itself — the
+    // critical path of a circuit never waits for another thread to wake up, as with rayon's local deques.)
+    std::atomic_flag qlock = ATOMIC_FLAG_INIT;
+    auto lock = [&] { while (qlock.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause(); };
+    auto unlock = [&] { qlock.clear(std::memory_order_release); };
     std::deque<uint32_t> ready;
-    uint32_t finished = 0;
+    std::atomic<uint32_t> finished{0};
+    std::atomic<uint32_t> bell{0}; // futex word: bumped whenever the queue gets something or everything has finished
+    std::atomic<int> sleepers{0};
     std::atomic<int> error{0};
     for (uint32_t i = 0; i < n_nodes; i++)
         if (op[i] >= 0 && deps[i].load() == 0) ready.push_back(i);
+    auto ring = [&](int n) {
+        bell.fetch_add(1, std::memory_order_release);
+        if (sleepers.load(std::memory_order_acquire) > 0) (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&bell), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+    };
     const auto t0 = std::chrono::steady_clock::now();
     auto worker = [&] {
+        bool have = false;
+        uint32_t node = 0;
         for (;;) {
-            uint32_t node;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !ready.empty() || finished == n_tasks; });
-                if (ready.empty()) return;
-                node = ready.front();
-                ready.pop_front();
+            while (!have) {
+                const uint32_t seen = bell.load(std::memory_order_acquire);
+                lock();
+                if (!ready.empty()) { node = ready.front(); ready.pop_front(); have = true; }
+                unlock();
+                if (have) break;
+                if (finished.load(std::memory_order_acquire) == n_tasks) return;
+                sleepers.fetch_add(1);
+                (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&bell), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+                sleepers.fetch_sub(1);
             }
+            have = false;
             if (!error.load()) { // (after an error the remaining tasks only retire)
                 const spf_value* args[3] = {nullptr, nullptr, nullptr};
                 for (uint32_t k = 0; k < n_in[node]; k++) args[k] = values[in[3 * node + k]];
@@ -235,17 +253,20 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
                 if (users[src].fetch_sub(1) == 1 && !keep[src] && values[src]) { release(values[src]); values[src] = nullptr; }
             }
             if (users[node].load() == 0 && !keep[node] && values[node]) { release(values[node]); values[node] = nullptr; }
-            std::vector<uint32_t> now_ready;
+            uint32_t mine = 0;
+            int pushed = 0;
             for (uint32_t d : dependents[node])
-                if (deps[d].fetch_sub(1) == 1) now_ready.push_back(d);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                for (uint32_t d : now_ready) ready.push_back(d);
-                finished++;
-                if (finished == n_tasks) cv.notify_all();
-                else if (now_ready.size() == 1) cv.notify_one();
-                else if (!now_ready.empty()) cv.notify_all();
-            }
+                if (deps[d].fetch_sub(1) == 1) {
+                    if (!have) { have = true; mine = d; continue; } // this thread goes on with the first one itself
+                    lock();
+                    ready.push_back(d);
+                    unlock();
+                    pushed++;
+                }
+            const uint32_t done = finished.fetch_add(1, std::memory_order_acq_rel) + 1;
+            if (done == n_tasks) ring(INT32_MAX);
+            else if (pushed) ring(pushed);
+            node = mine;
         }
     };
     std::vector<std::thread> th;
