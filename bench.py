@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 # The HIP runtime reads this when it initialises (torch.cuda.is_available() below does that, before the library — whose loader
 # sets the same default — is opened): streams that share a hardware queue run their kernels one after the other, and the pool
 # keeps several batches resident on the GPU, each on its own stream (profiles/r05_pool.md).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 FLOP_PER_PBS = 263.5e6          # 637 x 413 696 f64 flop
 FP64_PEAK_TFLOPS = 78.6         # MI355X dense FP64 (vector == matrix): 256 CU x 128 flop/clk x 2.4 GHz
@@ -399,6 +399,10 @@ def main() -> int:
     # multiplier graph — 16 GB of arena, a Python heap of a million objects — it read 0.81 / 0.72 / 0.66 of the device-resident
     # rate where the same function alone in a process reads 0.90 / 0.82 / 0.73)
     evpool = leg("evaluation_pool", lambda: _bench_evaluation_pool(eng, P, dev, torch)) if (extras and rank == 0) else None
+    # the same callers with device-resident values (r06): pool CMux host-pointer against by handle, circuit bootstrap by handle,
+    # the 32-bit adder walked node by node by handles
+    byhandle = leg("evaluation_pool_by_handle", lambda: _bench_pool_by_handle(eng, P, dev, torch)) if (extras and rank == 0) else None
+    add32h = leg("add32_by_handles", lambda: _bench_add32_by_handles(eng, P)) if (extras and rank == 0 and world == 1) else None
     add32 = None
     if args.with_add32 > 0 and rank == 0:
         add32 = leg("add32", lambda: _bench_add32(eng, P, args.with_add32, dev, g, _DevArray, torch, True))
@@ -558,6 +562,10 @@ def main() -> int:
             line["circuit_bootstrap"] = cbs
         if evpool:
             line["evaluation_pool"] = evpool
+        if byhandle:
+            line["evaluation_pool_by_handle"] = byhandle
+        if add32h:
+            line["add32_by_handles"] = add32h
         if devgroup:
             line["device_group"] = devgroup
         if add32:
@@ -951,7 +959,9 @@ def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), sec
     """The drop-in scenario BY HANDLE (r06, include/spf_hip.h "device-resident values"): the same T native callers, one operation
     per call, operands and results device-resident values — nothing crosses PCIe per call.
       cmux            T callers loop one CMux gate each (the reference's `FheOp::CMux` task, circuit_processor/mod.rs:391-421):
-                      host-pointer submits (256 KiB + 2 x 32 KiB up, 32 KiB down per gate) against submits by handle
+                      host-pointer submits (256 KiB + 2 x 32 KiB up, 32 KiB down per gate) against submits by handle — with
+                      one ticket open per thread (submit, wait: the synchronous call of the reference, bounded by a thread
+                      sleep and wake-up per gate) and with 64 tickets open per thread (the pool's asynchronous use)
       circuit_bootstrap  T callers loop KeyswitchL1toL0 -> CircuitBootstrap by handle (the GGSW stays in HBM), against the
                       device-resident rate of the same kernels at a batch of T"""
     import ctypes as C
@@ -969,23 +979,22 @@ def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), sec
     b = rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64)
     lwe1 = rng.integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
     with _pinned_to_quota():
-        for T in (64, 256):
-            row = {"threads": T}
+        for T, window in ((64, 1), (256, 1), (16, 64)):
+            row = {"threads": T, "tickets_open_per_thread": window}
             pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
             try:
                 el = C.c_double()
-                args = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux"), wait, T)
+                args = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux"), wait, T, window)
                 drv.spf_pool_drive_cmux(*args, 0.3, sel.ctypes.data, sel.size, a.ctypes.data, b.ctypes.data, a.size, C.byref(el))
                 n = drv.spf_pool_drive_cmux(*args, seconds, sel.ctypes.data, sel.size, a.ctypes.data, b.ctypes.data, a.size, C.byref(el))
                 if n < 0:
                     raise RuntimeError("pool driver: a host-pointer CMux failed")
                 row["host_pointer_gates_per_s"] = round(n / el.value, 1)
-                c0 = pool.counters()
-                vs = [pool.upload(3, sel.view(np.complex128)) for _ in range(T)]
-                va = [pool.upload(2, a) for _ in range(T)]
-                vb = [pool.upload(2, b) for _ in range(T)]
+                vs = pool.upload_batch(3, np.tile(sel.view(np.complex128), (T, 1)))
+                va = pool.upload_batch(2, np.tile(a, (T, 1)))
+                vb = pool.upload_batch(2, np.tile(b, (T, 1)))
                 hs, ha, hb = drvmod.handles(vs), drvmod.handles(va), drvmod.handles(vb)
-                argv = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux_v"), wait, release, T)
+                argv = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux_v"), wait, release, T, window)
                 drv.spf_pool_drive_cmux_v(*argv, 0.3, hs, ha, hb, C.byref(el))
                 c1 = pool.counters()
                 n = drv.spf_pool_drive_cmux_v(*argv, seconds, hs, ha, hb, C.byref(el))
@@ -1063,7 +1072,7 @@ def _bench_add32_by_handles(eng, P, threads=64, reps=5):
         g.run()
         best_g = min(best_g, time.perf_counter() - t0)
     with _pinned_to_quota():
-        pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
+        pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=5)
         try:
             outs, _, _ = drvmod.run_circuit_by_handles(pool, rec, threads=threads)
             same = all(np.array_equal(x, y) for x, y in zip(outs, g_outs))

@@ -278,11 +278,12 @@ typedef enum spf_graph_op {
  *     batch is back, or when nobody has joined it for max_wait_us (stretched to an eighth of the last batch's GPU time, at most
  *     twenty such quiet times after its first member) — but not on the timer while the group's previous batch is still out.
  *     The groups' batches run on the GPU side by side, each on its own stream (profiles/r05_pool.md).
- *   Asynchronous use: a thread may hold many tickets; eight staging sets exist, so a caller that keeps more than eight batches
- *     uncollected waits in submit until a set is collected (or 200 ms old).
+ *   Asynchronous use: a thread may hold many tickets; sixteen staging sets exist (spf_pool_counters.staging_sets), so a caller
+ *     that keeps more than sixteen host-pointer batches uncollected waits in submit until a set is collected (or 200 ms old).
+ *     Batches by handle give their set back when they complete.
  *   spf_pool_wait returns the status of the batch the operation ran in (first-error-wins per batch, as
  *     circuit_processor/mod.rs:214-223 does per graph).
- *   The library asks the HIP runtime for more hardware queues when it is loaded (GPU_MAX_HW_QUEUES=16 unless set): streams that
+ *   The library asks the HIP runtime for more hardware queues when it is loaded (GPU_MAX_HW_QUEUES=24 unless set): streams that
  *   share a hardware queue run their kernels one after the other. */
 typedef struct spf_pool spf_pool;
 spf_status spf_pool_create(spf_ctx *ctx, size_t max_batch, uint32_t max_wait_us, spf_pool **out);
@@ -365,6 +366,12 @@ typedef struct spf_value spf_value;
 /* host -> HBM: `host` holds one ciphertext of `kind` in the layout of the conventions above (spf_ciphertext_words(kind) u64
  * words; SPF_VAL_GGSW1: (k+1)*l_cbs*(k+1)*N/2 complex) */
 spf_status spf_value_upload(spf_pool *pool, int member, spf_value_kind kind, const void *host, spf_value **out);
+/* n ciphertexts of one kind (the bits of an encrypted integer: `host` holds them consecutively) into ONE block with one copy;
+ * out receives n values.  Operations that take them in order find them consecutive in HBM (no packing pass). */
+spf_status spf_value_upload_batch(spf_pool *pool, int member, spf_value_kind kind, size_t n, const void *host, spf_value **out);
+/* n valid values of one kind on one member -> `host`, consecutively (blocking): one copy when they lie consecutively in one block
+ * (the results of one batch in slot order, or of spf_value_upload_batch), one copy each otherwise */
+spf_status spf_value_download_batch(size_t n, const spf_value *const *values, void *host);
 /* FheOp::{Zero,One}{Lwe0,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116; also LWE1) as values: the trivial encryption of `bit`; the
  * GGSW constants are `Evaluation::l1ggsw_zero / l1ggsw_one` (crypto/evaluation.rs:254-262) and need all four keys */
 spf_status spf_value_trivial(spf_pool *pool, int member, spf_value_kind kind, uint64_t bit, spf_value **out);

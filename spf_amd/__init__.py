@@ -10,7 +10,7 @@ import os as _os
 
 # read by the HIP runtime when it initialises; the library's loader sets the same default, but a process may touch the GPU (torch)
 # between importing this package and opening the library (spf_amd/csrc/spf_hip.hip, spf_ask_for_hw_queues)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .params import Params, DEFAULT_128  # noqa: F401,E402
 from ._ffi import (Engine, Group, Pool, SpfError, Value, ciphertext_from_bincode, ciphertext_to_bincode, ciphertext_words,  # noqa: F401

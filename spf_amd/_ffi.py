@@ -158,6 +158,8 @@ SYMBOLS = [
     # device-resident values and the pool's submits by handle
     ("spf_pool_counters_get", _I, [_P, C.POINTER(_U64 * 10)]),
     ("spf_value_upload", _I, [_P, _I, _I, _P, C.POINTER(_P)]),
+    ("spf_value_upload_batch", _I, [_P, _I, _I, _SZ, _P, C.POINTER(_P)]),
+    ("spf_value_download_batch", _I, [_SZ, C.POINTER(_P), _P]),
     ("spf_value_trivial", _I, [_P, _I, _I, _U64, C.POINTER(_P)]),
     ("spf_value_download", _I, [_P, _P]),
     ("spf_value_retain", _I, [_P]),
@@ -838,6 +840,30 @@ class Pool:
         h = C.c_void_p()
         self._ck(self._lib.spf_value_upload(self._h, member, int(kind), _ptr(a), C.byref(h)), "spf_value_upload")
         return Value(self, h)
+
+    def _words(self, kind: int) -> int:
+        P = self.engine.params
+        return {0: P.lwe0_words, 1: P.lwe1_words, 2: P.glwe_words, 3: 2 * P.cbs_ggsw_complex, 4: P.cbs_radix_count * P.glwe_words}[int(kind)]
+
+    def upload_batch(self, kind: int, arrays: np.ndarray, member: int = -1):
+        """`spf_value_upload_batch`: arrays is [n, words of the kind]; one block, one copy -> list of n values"""
+        a = np.ascontiguousarray(arrays)
+        n = a.shape[0]
+        if a.nbytes != n * self._words(kind) * 8:
+            raise SpfError(1, f"{n} values of kind {int(kind)} must have {n * self._words(kind) * 8} bytes, got {a.nbytes}")
+        hs = (C.c_void_p * n)()
+        self._ck(self._lib.spf_value_upload_batch(self._h, member, int(kind), n, _ptr(a), hs), "spf_value_upload_batch")
+        return [Value(self, C.c_void_p(h)) for h in hs]
+
+    def download_batch(self, values) -> np.ndarray:
+        """`spf_value_download_batch`: -> [n, words] (complex128 for GGSW)"""
+        i = values[0].info()
+        n = len(values)
+        dtype = np.complex128 if i["kind"] == 3 else np.uint64
+        out = np.empty((n, i["bytes"] // np.dtype(dtype).itemsize), dtype=dtype)
+        hs = (C.c_void_p * n)(*[v._h for v in values])
+        self._ck(self._lib.spf_value_download_batch(n, hs, _ptr(out)), "spf_value_download_batch")
+        return out
 
     def trivial(self, kind: int, bit: int, member: int = -1) -> "Value":
         h = C.c_void_p()

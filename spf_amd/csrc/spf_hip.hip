@@ -26,11 +26,12 @@ using namespace spf;
 
 // HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
 // run their kernels one after the other: with the default, two bootstrap launches on two streams took 7.45 ms, with more queues
-// 3.76 (tools/concurrency_probe.py).  The pool keeps several batches resident on the GPU at once, each on its own stream, beside
+// 3.76 (tools/concurrency_probe.py; r06: sixteen staging sets, 24 queues — a 32-bit adder by handles 10.4 ms against 11.5 with 16).
+// The pool keeps several batches resident on the GPU at once, each on its own stream, beside
 // the streams of the context and of the caller — so the library asks for more queues, unless the environment already says
 // otherwise.  The runtime reads the variable when it initialises (first HIP call of the process); this runs when the library is
 // loaded.  A process that has initialised HIP before loading the library keeps its setting: export GPU_MAX_HW_QUEUES there.
-__attribute__((constructor(101))) static void spf_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor(101))) static void spf_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 #if defined(SPF_ABL) && SPF_ABL != 0
 // a timing-only ablation build (spf_kernels.hpp, SPF_ABL) computes WRONG results on purpose: it says so when it is loaded
 __attribute__((constructor(102))) static void spf_ablation_banner()
@@ -1885,6 +1886,7 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     p->max_wait = std::chrono::microseconds(max_wait_us);
     if (const char* e = getenv("SPF_POOL_GROUPS")) p->groups = (size_t)std::min(std::max(1, atoi(e)), spf_pool_impl::kMaxGroups);
     if (const char* e = getenv("SPF_POOL_PACE")) p->pace_div = atoi(e); // (experiments: -1 = no pacing)
+    if (const char* e = getenv("SPF_POOL_SETS")) p->n_sets = std::min(std::max(1, atoi(e)), (int)spf_pool_impl::kSets);
     if (const char* e = getenv("SPF_POOL_SPLIT")) p->split = (size_t)std::min(std::max(1, atoi(e)), 16);
     if (const char* e = getenv("SPF_POOL_SPIN_US")) p->spin_us = std::max(0, atoi(e));
     if (const char* e = getenv("SPF_POOL_HOT_US")) p->hot_us = std::max(0, atoi(e)); // (0: the launcher never polls; completers complete every batch)
@@ -2195,6 +2197,80 @@ spf_status spf_value_upload(spf_pool* p, int member, spf_value_kind kind, const 
     return SPF_OK;
 }
 
+// n ciphertexts of one kind in ONE block and one copy (the bits of an encrypted integer): what spf_value_upload does n times,
+// without n copies from pageable memory — and operations that take them in order find them consecutive (no gather pass)
+spf_status spf_value_upload_batch(spf_pool* p, int member, spf_value_kind kind, size_t n, const void* host, spf_value** out)
+{
+    if (!p || !host || !out || n == 0) return SPF_ERR_INVALID_ARGUMENT;
+    int which = 0;
+    spf_pool* leaf = value_pool(p, member, &which);
+    if (!leaf) return fail(p->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_upload_batch: no such member (or none in rotation)");
+    const size_t bytes = value_bytes(leaf->prm, kind);
+    if (!bytes) return fail(leaf->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_upload_batch: unknown ciphertext kind");
+    if (n > ((size_t)1 << 40) / bytes) return fail(leaf->ctx, SPF_ERR_INVALID_ARGUMENT, "spf_value_upload_batch: too many values");
+    std::shared_ptr<spf_value_impl::Block> blk = spf_value_impl::Block::make(leaf->arena, n * bytes);
+    if (!blk) return fail(leaf->ctx, SPF_ERR_HIP, "spf_value_upload_batch: out of device memory");
+    {
+        spf_value_impl::Arena::DeviceScope ds(leaf->ctx->device);
+        const hipError_t e = ds.ok ? hipMemcpy(blk->p, host, n * bytes, hipMemcpyHostToDevice) : hipErrorInvalidDevice;
+        if (e != hipSuccess) return fail(leaf->ctx, SPF_ERR_HIP, std::string("spf_value_upload_batch: ") + hipGetErrorString(e));
+    }
+    for (size_t i = 0; i < n; i++) {
+        spf_value* v = spf_value::make(leaf->arena, leaf, which, kind, bytes);
+        if (!v) {
+            for (size_t j = 0; j < i; j++) { out[j]->release(); out[j] = nullptr; }
+            return fail(leaf->ctx, SPF_ERR_HIP, "out of host memory");
+        }
+        v->blk = blk;
+        v->off = i * bytes;
+        v->state.store(spf_value_impl::READY, std::memory_order_release);
+        out[i] = v;
+    }
+    return SPF_OK;
+}
+
+// n valid values of one kind and one context -> host, consecutive; ONE copy when they lie consecutively in one block (the
+// results of one batch, or of spf_value_upload_batch), one copy each otherwise
+spf_status spf_value_download_batch(size_t n, const spf_value* const* values, void* host)
+{
+    if (!values || !host || n == 0) return SPF_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; i++)
+        if (!values[i] || !values[i]->ready() || values[i]->kind != values[0]->kind || values[i]->arena != values[0]->arena) return SPF_ERR_INVALID_ARGUMENT;
+    const size_t bytes = values[0]->bytes;
+    bool consecutive = true;
+    for (size_t i = 1; i < n && consecutive; i++)
+        consecutive = values[i]->blk == values[0]->blk && values[i]->off == values[0]->off + i * bytes;
+    spf_value_impl::Arena::DeviceScope ds(values[0]->arena->device);
+    if (!ds.ok) return SPF_ERR_HIP;
+    if (consecutive) return hipMemcpy(host, values[0]->ptr(), n * bytes, hipMemcpyDeviceToHost) == hipSuccess ? SPF_OK : SPF_ERR_HIP;
+    if (n >= 4 && values[0]->home) {
+        // scattered (the outputs of a circuit come from different batches): packed on the device into one scratch block
+        // (gather_rows_kernel reading a pointer table at the block's end), then ONE copy — a copy to pageable memory costs ~25 us
+        // per call whatever its size
+        spf_ctx* c = values[0]->home->ctx;
+        const size_t table_at = (n * bytes + 255) / 256 * 256;
+        std::shared_ptr<spf_value_impl::Block> tmp = spf_value_impl::Block::make(values[0]->arena, table_at + n * sizeof(void*));
+        std::vector<const void*> ptrs;
+        try {
+            for (size_t i = 0; i < n; i++) ptrs.push_back(values[i]->ptr());
+        } catch (const std::exception&) {
+            tmp.reset();
+        }
+        if (tmp) {
+            char* base = static_cast<char*>(tmp->p);
+            std::lock_guard<std::recursive_mutex> g(c->mu);
+            if (hipMemcpyAsync(base + table_at, ptrs.data(), n * sizeof(void*), hipMemcpyHostToDevice, c->stream) != hipSuccess) return SPF_ERR_HIP;
+            spf_status st = spf_gather_rows_dev(c, c->stream, n, bytes / 8, (const uint64_t* const*)(base + table_at), (uint64_t*)base);
+            if (st != SPF_OK) return st;
+            if (hipMemcpyAsync(host, base, n * bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return SPF_ERR_HIP;
+            return hipStreamSynchronize(c->stream) == hipSuccess ? SPF_OK : SPF_ERR_HIP;
+        }
+    }
+    for (size_t i = 0; i < n; i++)
+        if (hipMemcpy(static_cast<char*>(host) + i * bytes, values[i]->ptr(), bytes, hipMemcpyDeviceToHost) != hipSuccess) return SPF_ERR_HIP;
+    return SPF_OK;
+}
+
 // FheOp::{Zero,One}{Lwe0,Lwe1,Glwe1,Glev1,Ggsw1} (fhe_circuit.rs:96-116) as values
 spf_status spf_value_trivial(spf_pool* p, int member, spf_value_kind kind, uint64_t bit, spf_value** out)
 {
@@ -2346,7 +2422,7 @@ spf_status spf_pool_counters_get(spf_pool* p, spf_pool_counters* out)
         out->handle_ops += q->n_handle_ops; out->handle_launches += q->n_handle_launches;
         out->reclaimed += q->n_reclaimed;
         for (int i = 0; i < 3; i++) out->bootstrap_launches_by_shape[i] += q->n_shape[i];
-        out->staging_sets = spf_pool_impl::kSets;
+        out->staging_sets = (uint64_t)q->n_sets;
         out->value_mallocs += q->arena->n_malloc.load();
     };
     if (p->members.empty()) add(p);

@@ -23,7 +23,7 @@
 //     time per 1.9 s of wall time (a wake storm per batch, then a convoy on the mutex) and ran the process into its CPU
 //     quota (tools/pool_probe.py: 15 of 18 scheduler periods throttled); the pool's mutex is held for a few hundred
 //     nanoseconds at a time (slot bookkeeping), never across a copy, a sleep or a HIP call;
-//   * six staging sets (pinned host + device buffers, grown on demand), each with its own kernel stream and its own
+//   * sixteen staging sets (r04: six; pinned host + device buffers, grown on demand), each with its own kernel stream and its own
 //     intermediates.  A set returns to the pool when every ticket of its batch has been collected; tickets nobody waits for
 //     are delivered by the launcher after a grace period, so that abandoned tickets cannot wedge the pipeline.
 // r05: several batches RESIDENT on the GPU at once.  Synchronous callers make throughput = callers / (kernel latency + host
@@ -304,8 +304,10 @@ struct spf_pool {
     std::condition_variable_any cv_fly[spf_pool_impl::kSets];
     uint64_t n_reclaimed = 0;             // outputs delivered on their owners' behalf (reclaim)
     uint64_t n_handle_ops = 0, n_handle_launches = 0;
+    int n_sets = spf_pool_impl::kSets;    // staging sets in use (SPF_POOL_SETS: tests fill every set with three)
     size_t split = 4;                     // by handle a bootstrap batch goes as soon as it holds 1 / split of the callers (SPF_POOL_SPLIT; see submit_impl)
-    int spin_us = 40;                     // how long a waiter of a cheap operation by handle looks before it sleeps (SPF_POOL_SPIN_US)
+    int spin_us = 0;                      // how long a waiter of a cheap operation by handle looks before it sleeps (SPF_POOL_SPIN_US; measured on
+                                          // the bench's host — 64 callers on 16 CPUs — any spinning loses: 9.7-10.8 ms per 32-bit adder at 0, 10.7-16 at 40-200 us)
     int hot_us = 300;                     // how long the launcher keeps polling after its last piece of work (SPF_POOL_HOT_US)
     std::atomic<uint64_t> work_epoch{0};  // bumped whenever the launcher has something new to look at
     std::atomic<bool> launcher_asleep{false};
@@ -524,7 +526,7 @@ struct spf_pool {
             // open a batch on a free staging set
             int set = -1;
             if (!preparing[lane]) // (somebody is allocating a set for this lane right now: its batch is about to appear)
-                for (int i = 0; i < kSets; i++) if (!sets[i].busy) { set = i; break; }
+                for (int i = 0; i < n_sets; i++) if (!sets[i].busy) { set = i; break; }
             if (set < 0) {
                 // all sets held: wait for collectors; past the grace period deliver the oldest done batch's leftovers here
                 set_waiters++;
@@ -598,10 +600,11 @@ struct spf_pool {
         if (b->n == b->cap) {
             cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(lane);
-        } else if (by_handle && heavy(op) && b->n * split >= heavy_population(b->t_last)) {
+        } else if (by_handle && heavy(op) && b->n * split >= std::max(heavy_population(b->t_last), n_open.load())) {
             // By handle a caller is back microseconds after its result (nothing to copy out), so the callers need no dealing into
             // groups that meet again: a bootstrap batch simply goes as soon as it holds a quarter of the callers in the pool
-            // (or nobody has joined it for max_wait), on the workgroup shape of the whole population — up to four or five
+            // (all callers count, whatever they are waiting for: the conversions of a circuit's inputs arrive out of its keyswitch
+            // batches; or nobody has joined it for max_wait), on the workgroup shape of the whole population — up to four or five
             // batches tile the CUs side by side, each on its set's stream, and whoever comes back meanwhile is the next one.
             // A 32-bit adder's 64 conversions are four launches within the time the callers take to arrive, not four paced
             // quarter batches; 1 024 synchronous callers keep four batches of 256 in flight.
@@ -1013,8 +1016,9 @@ struct spf_pool {
 #ifdef SPF_POOL_TRACE
             {
                 auto us = [](auto d) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(d).count(); };
-                fprintf(stderr, "[pool] batch op %d (by handle) n %zu: filled %ld us, closed->ready %ld us, enqueue %ld us, enqueued->event %ld us, event->marked %ld us\n", b->op, b->n,
-                        us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), us(b->t_done - b->t_sync));
+                static const auto epoch = std::chrono::steady_clock::now();
+                fprintf(stderr, "[pool] batch op %d (by handle) n %zu: first member at %ld us, filled %ld us, closed->ready %ld us, enqueue %ld us, enqueued->event %ld us, event->marked %ld us\n", b->op, b->n,
+                        us(b->t0 - epoch), us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), us(b->t_done - b->t_sync));
             }
 #endif
             sets[b->set].busy = false; // nothing to collect: the staging set is free again

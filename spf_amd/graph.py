@@ -161,6 +161,15 @@ class RecordedCircuit:
 
     def arrays(self) -> dict:
         n = len(self.op)
+        cached = getattr(self, "_arrays", None)
+        if cached is not None and cached[0] == (n, len(self.outputs)):
+            return cached[1]
+        out = self._build_arrays()
+        self._arrays = ((n, len(self.outputs)), out)
+        return out
+
+    def _build_arrays(self) -> dict:
+        n = len(self.op)
         ins = np.zeros((n, 3), dtype=np.uint32)
         for i, t in enumerate(self.inputs):
             ins[i, :len(t)] = t

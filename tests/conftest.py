@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises HIP (see spf_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # before anything initialises HIP (see spf_amd/__init__.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

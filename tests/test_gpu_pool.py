@@ -225,14 +225,16 @@ def test_mismatched_batches_raise(rig):
         eng.multiply_glwe_ggsw(a, g)
 
 
-def test_pool_survives_tickets_nobody_collects_in_time(rig):
+def test_pool_survives_tickets_nobody_collects_in_time(rig, monkeypatch):
     """r04 pipeline: a batch's pinned staging set returns to the pool when all its tickets are collected.  Tickets nobody
     waits for must not wedge it: with every set held by uncollected batches a further submit delivers the oldest batch's
     outputs itself after the grace period and goes on; the late waits still return the right status, the outputs are in the
     callers' buffers, and a pool destroyed with uncollected tickets cleans up."""
     ks, eng = rig
     P = ks.params
+    monkeypatch.setenv("SPF_POOL_SETS", "3")                 # (sixteen by default: the test would never run out of sets)
     pool = spf_amd.Pool(eng, max_batch=2, max_wait_us=100)   # batches of two: three staging sets hold six tickets
+    assert pool.counters()["staging_sets"] == 3
     pool.set_max_inflight(64)
     n = 10
     lwe1 = random_lwe_batch(31, n, P.N * P.k)
@@ -247,10 +249,11 @@ def test_pool_survives_tickets_nobody_collects_in_time(rig):
         assert np.array_equal(outs[i], exp[i]), i
     ops, launches = pool.stats()
     assert ops >= n - 2 and launches >= (n - 2) // 2
+    assert pool.counters()["reclaimed"] >= 2                 # reclaim() really ran: outputs were delivered on their owners' behalf
     pool.close()                                             # tickets n-2, n-1 never collected
 
 
-def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig):
+def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig, monkeypatch):
     """reclaim() copies an uncollected output to the caller's buffer with the pool's lock dropped; a wait() for
     that ticket arriving DURING the copy must not return before the copy has ended (the caller may read or free `out` the
     moment wait returns).  Circuit bootstraps (256 KiB outputs, the longest copies); every set held by uncollected batches;
@@ -261,6 +264,8 @@ def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig):
     P = ks.params
     lwe0 = random_lwe_batch(41, 8, SMALL_N)
     exp = eng.circuit_bootstrap(lwe0)
+    monkeypatch.setenv("SPF_POOL_SETS", "3")
+    reclaimed = 0
     for rnd in range(4):
         pool = spf_amd.Pool(eng, max_batch=2, max_wait_us=100)
         pool.set_max_inflight(64)
@@ -291,7 +296,9 @@ def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig):
             t.join()
         assert not bad, (rnd, bad)
         assert np.array_equal(outs[6].view(np.float64), exp[6].view(np.float64))
+        reclaimed += pool.counters()["reclaimed"]
         pool.close()
+    assert reclaimed > 0                                     # the delivered 0 / 1 / 2 hand-over was exercised
 
 
 def test_pool_under_native_load_every_caller_gets_its_own_output(rig):

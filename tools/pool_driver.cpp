@@ -119,15 +119,18 @@ long spf_pool_drive_v(spf_pool* pool, submit_v1_fn submit, wait_fn wait, release
     return failed.load() ? -1 : done.load();
 }
 
-// CMUX gates one per call from `threads` callers: host-pointer form (every operand and result crosses PCIe) ...
-long spf_pool_drive_cmux(spf_pool* pool, submit_cmux_fn submit, wait_fn wait, int threads, double seconds, const double* sel,
+// CMUX gates one per call from `threads` callers, each keeping up to `window` tickets open (window 1: the synchronous caller —
+// submit, wait, submit; larger: a task that has several independent gates submits them all before it waits for the first, as
+// the pool's asynchronous use allows): host-pointer form (every operand and result crosses PCIe) ...
+long spf_pool_drive_cmux(spf_pool* pool, submit_cmux_fn submit, wait_fn wait, int threads, int window, double seconds, const double* sel,
                          size_t ggsw_doubles, const uint64_t* a, const uint64_t* b, size_t glwe_words, double* elapsed_s)
 {
     std::atomic<long> done{0};
     std::atomic<int> failed{0};
     std::vector<std::thread> th;
+    if (window < 1) window = 1;
     std::vector<std::vector<uint64_t>> out((size_t)threads);
-    for (auto& o : out) o.assign(glwe_words, 0);
+    for (auto& o : out) o.assign(glwe_words * (size_t)window, 0);
     // (every caller owns its operands, as every task of the reference owns its ciphertexts)
     std::vector<std::vector<double>> sels((size_t)threads, std::vector<double>(sel, sel + ggsw_doubles));
     std::vector<std::vector<uint64_t>> as((size_t)threads, std::vector<uint64_t>(a, a + glwe_words)), bs((size_t)threads, std::vector<uint64_t>(b, b + glwe_words));
@@ -135,14 +138,27 @@ long spf_pool_drive_cmux(spf_pool* pool, submit_cmux_fn submit, wait_fn wait, in
     const auto until = t0 + std::chrono::duration<double>(seconds);
     for (int t = 0; t < threads; t++)
         th.emplace_back([&, t] {
-            while (std::chrono::steady_clock::now() < until && !failed.load()) {
-                uint64_t ticket = 0;
-                if (submit(pool, sels[(size_t)t].data(), as[(size_t)t].data(), bs[(size_t)t].data(), out[(size_t)t].data(), &ticket) != SPF_OK ||
-                    wait(pool, ticket) != SPF_OK) {
-                    failed.store(1);
-                    return;
+            std::vector<uint64_t> tickets((size_t)window, 0);
+            long n = 0; // submitted so far; ticket i of the ring is slot i % window
+            long collected = 0;
+            bool stop = false;
+            while (!stop || collected < n) {
+                stop = stop || std::chrono::steady_clock::now() >= until || failed.load();
+                if (!stop && n - collected < window) {
+                    const size_t k = (size_t)(n % window);
+                    if (submit(pool, sels[(size_t)t].data(), as[(size_t)t].data(), bs[(size_t)t].data(), out[(size_t)t].data() + k * glwe_words, &tickets[k]) != SPF_OK) {
+                        failed.store(1);
+                        stop = true;
+                        continue;
+                    }
+                    n++;
+                    continue;
                 }
-                done.fetch_add(1);
+                if (collected < n) {
+                    if (wait(pool, tickets[(size_t)(collected % window)]) != SPF_OK) failed.store(1);
+                    collected++;
+                    done.fetch_add(1);
+                }
             }
         });
     for (auto& x : th) x.join();
@@ -150,25 +166,42 @@ long spf_pool_drive_cmux(spf_pool* pool, submit_cmux_fn submit, wait_fn wait, in
     return failed.load() ? -1 : done.load();
 }
 
-// ... and by handle: sel / a / b are `threads` values each (caller t uses sel[t], a[t], b[t]); the result is released at once
-long spf_pool_drive_cmux_v(spf_pool* pool, submit_cmux_v_fn submit, wait_fn wait, release_fn release, int threads, double seconds,
+// ... and by handle: sel / a / b are `threads` values each (caller t uses sel[t], a[t], b[t]); a result is released when collected
+long spf_pool_drive_cmux_v(spf_pool* pool, submit_cmux_v_fn submit, wait_fn wait, release_fn release, int threads, int window, double seconds,
                            spf_value* const* sel, spf_value* const* a, spf_value* const* b, double* elapsed_s)
 {
     std::atomic<long> done{0};
     std::atomic<int> failed{0};
     std::vector<std::thread> th;
+    if (window < 1) window = 1;
     const auto t0 = std::chrono::steady_clock::now();
     const auto until = t0 + std::chrono::duration<double>(seconds);
     for (int t = 0; t < threads; t++)
         th.emplace_back([&, t] {
-            while (std::chrono::steady_clock::now() < until && !failed.load()) {
-                uint64_t ticket = 0;
-                spf_value* out = nullptr;
-                if (submit(pool, sel[t], a[t], b[t], &out, &ticket) != SPF_OK) { failed.store(1); return; }
-                const spf_status st = wait(pool, ticket);
-                release(out);
-                if (st != SPF_OK) { failed.store(1); return; }
-                done.fetch_add(1);
+            std::vector<uint64_t> tickets((size_t)window, 0);
+            std::vector<spf_value*> outs((size_t)window, nullptr);
+            long n = 0, collected = 0;
+            bool stop = false;
+            while (!stop || collected < n) {
+                stop = stop || std::chrono::steady_clock::now() >= until || failed.load();
+                if (!stop && n - collected < window) {
+                    const size_t k = (size_t)(n % window);
+                    if (submit(pool, sel[t], a[t], b[t], &outs[k], &tickets[k]) != SPF_OK) {
+                        failed.store(1);
+                        stop = true;
+                        continue;
+                    }
+                    n++;
+                    continue;
+                }
+                if (collected < n) {
+                    const size_t k = (size_t)(collected % window);
+                    if (wait(pool, tickets[k]) != SPF_OK) failed.store(1);
+                    release(outs[k]);
+                    outs[k] = nullptr;
+                    collected++;
+                    done.fetch_add(1);
+                }
             }
         });
     for (auto& x : th) x.join();
@@ -218,8 +251,13 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
         bell.fetch_add(1, std::memory_order_release);
         if (sleepers.load(std::memory_order_acquire) > 0) (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&bell), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
     };
-    const auto t0 = std::chrono::steady_clock::now();
+    // (the reference's workers exist before the circuit arrives — a rayon pool: the clock starts when all of them are up)
+    std::atomic<int> up{0};
+    std::atomic<uint32_t> gate{0};
+    std::chrono::steady_clock::time_point t0;
     auto worker = [&] {
+        up.fetch_add(1);
+        while (gate.load(std::memory_order_acquire) == 0) (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gate), FUTEX_WAIT_PRIVATE, 0, nullptr, nullptr, 0);
         bool have = false;
         uint32_t node = 0;
         for (;;) {
@@ -271,6 +309,10 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
     };
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    while (up.load() < threads) std::this_thread::yield();
+    t0 = std::chrono::steady_clock::now();
+    gate.store(1, std::memory_order_release);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gate), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     for (auto& x : th) x.join();
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return error.load();

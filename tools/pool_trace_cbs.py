@@ -24,7 +24,7 @@ drv = drvmod.load()
 lib = eng._lib
 lwe1 = np.random.default_rng(1).integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
 with bench._pinned_to_quota():
-    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=200)
+    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=int(os.environ.get('WAIT_US', '200')))
     ins = [pool.upload(1, lwe1 + np.uint64(t)) for t in range(T)]
     el = C.c_double()
     n = drv.spf_pool_drive_v(pool._h, drvmod.fn(lib, "spf_pool_submit_keyswitch_circuit_bootstrap_v"), drvmod.fn(lib, "spf_pool_wait"),
