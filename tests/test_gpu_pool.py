@@ -266,7 +266,7 @@ def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig, monkeypatch):
     exp = eng.circuit_bootstrap(lwe0)
     monkeypatch.setenv("SPF_POOL_SETS", "3")
     reclaimed = 0
-    for rnd in range(4):
+    for rnd in range(6):
         pool = spf_amd.Pool(eng, max_batch=2, max_wait_us=100)
         pool.set_max_inflight(64)
         outs = [np.zeros(eng.params.cbs_ggsw_complex, dtype=np.complex128) for _ in range(8)]
@@ -289,9 +289,14 @@ def test_pool_wait_during_a_delivery_on_the_callers_behalf(rig, monkeypatch):
         def submitter():
             pool.circuit_bootstrap(outs[6], lwe0[6])         # no set free: reclaim() runs inside this submit
 
+        # the submitter first: no set is free, its 20 ms look-out passes, reclaim() starts delivering — the waiters arrive around
+        # that moment, spread over the copies
         th = [threading.Thread(target=submitter)] + [threading.Thread(target=waiter, args=(i,)) for i in range(6)]
-        for t in th:
+        th[0].start()
+        time.sleep(0.018 + 0.001 * rnd)
+        for t in th[1:]:
             t.start()
+            time.sleep(0.0005)
         for t in th:
             t.join()
         assert not bad, (rnd, bad)
