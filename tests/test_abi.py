@@ -191,3 +191,12 @@ def test_makefile_describes_the_same_build():
     assert line.rstrip().endswith("spf_hip.hip") and "libspf_hip.so.tmp" in line
     pc = subprocess.run(["make", "-n", "-f", mk, "install", "PREFIX=/tmp/spf_prefix"], capture_output=True, text=True, check=True).stdout
     assert "spf_hip.pc" in pc and "/tmp/spf_prefix/include" in pc and "spf_evaluation.hpp" in pc
+
+
+def test_integration_md_mentions_every_entry_point():
+    """VERDICT r05 weak #3: the integration guide names every function of the header (its §6 index is generated)."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "spf_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(spf_[a-z0-9_]+)\s*\(", hdr))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in declared if f"`{n}`" not in text)
+    assert not missing, missing

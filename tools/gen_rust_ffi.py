@@ -181,7 +181,41 @@ def exported_symbols(lib: str):
     return sorted(l.split()[-1] for l in txt.splitlines() if " T " in l and l.split()[-1].startswith("spf_"))
 
 
+FAMILIES = [
+    ("context and keys", r"spf_(default_params|create|destroy|last_error|version|load_|key_blob)"),
+    ("hot path, host pointers (`_batch`)", r"spf_(?!group_|pool_).*_batch$"),
+    ("hot path, device pointers (`_dev`) and device buffers", r"spf_((?!group_).*_dev$|device_)"),
+    ("call coalescing: the pool, host pointers", r"spf_pool_(?!.*_v$)(?!value_|trim|create_group)"),
+    ("device-resident values and the pool by handle", r"spf_(value_|pool_.*_v$|pool_value_stats|pool_trim)"),
+    ("gate graphs", r"spf_graph_"),
+    ("device group (every GPU, one process)", r"spf_(group_|pool_create_group)"),
+    ("measurement, LUT, wire formats, constants", r"spf_"),
+]
+
+
+def index_markdown(h: "Header", header_path: str) -> str:
+    """every function of the header by family, with the line it is declared on"""
+    lines = open(header_path).read().splitlines()
+    where = {}
+    for name, _, _ in h.functions:
+        for i, l in enumerate(lines, 1):
+            if re.search(rf"\b{name}\s*\(", l) and not l.lstrip().startswith(("*", "/*")):
+                where[name] = i
+                break
+    left = [n for n, _, _ in h.functions]
+    out = []
+    for title, pat in FAMILIES:
+        mine = [n for n in left if re.match(pat, n)]
+        left = [n for n in left if n not in mine]
+        if mine:
+            out.append(f"- **{title}** ({len(mine)}): " + ", ".join(f"`{n}` (:{where.get(n, 0)})" for n in mine))
+    return "\n".join(out) + "\n"
+
+
 def main(argv):
+    if len(argv) == 2 and argv[0] == "--index":
+        sys.stdout.write(index_markdown(Header(argv[1]), argv[1]))
+        return 0
     if len(argv) >= 3 and argv[0] == "--check-library":
         h = Header(argv[2])
         want = sorted(n for n, _, _ in h.functions)
