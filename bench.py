@@ -655,11 +655,13 @@ def _single_process_main(args) -> int:
     sync()
     for m in members:
         m.set_timing(True)
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
+    cpu_headline = time.process_time() - cpu0
     kms = []
     for m in members:
         ms, launches = m.last_kernel_ms("pbs")
@@ -675,10 +677,12 @@ def _single_process_main(args) -> int:
     out_h = np.zeros((G * B, P.glwe_words), dtype=np.uint64)
     grp.circuit_bootstrap_pbs(lwe_h, out=out_h)
     reps = 2
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(reps):
         grp.circuit_bootstrap_pbs(lwe_h, out=out_h)
     t_h = (time.perf_counter() - t0) / reps
+    cpu_host = (time.process_time() - cpu0) / reps
     same = all(bool(np.array_equal(out_h[i * B:(i + 1) * B], out[i].cpu().numpy().view(np.uint64))) for i in range(G))
 
     cpu = None
@@ -720,12 +724,115 @@ def _single_process_main(args) -> int:
         "pcie_inclusive": {"pbs_per_s": round(G * B / t_h, 1), "ms_per_batch": round(t_h * 1e3, 3),
                            "note": "spf_group_circuit_bootstrap_pbs_batch: one pageable host batch of G x B ciphertexts cut into G "
                                    "contiguous ranges, each member's H2D / kernels / sliced D2H on its own thread and stream",
-                           "same_words_as_device_path": same},
+                           "same_words_as_device_path": same,
+                           "host_cpu_s_per_batch": round(cpu_host, 3), "host_cpu_s_per_member_per_batch": round(cpu_host / G, 4)},
+        "host_cpu": {"headline_cpu_s_per_step": round(cpu_headline / args.steps, 5),
+                     "note": "process CPU time (all threads): the device-pointer headline only enqueues; the host-pointer call "
+                             "stages every member's range through its own thread"},
         "setup_s": round(time.time() - t_keys0, 2),
     }
+    if len(set(devices)) < G:
+        line["rehearsal"] = ("members share a device: a rehearsal of the host path (replication, split, dealing, reassembly, host "
+                             "CPU per member), NOT a scaling figure")
+    if not args.no_extras:
+        for name, fn in (("mul8_gate_pool", lambda: _group_gate_pool(grp, P, G, "mul8", 8)),
+                         ("add32", lambda: _group_gate_pool(grp, P, G, "add32", 4)),
+                         ("mul32_gate_pool", lambda: _group_gate_pool(grp, P, G, "mul32", 1)),
+                         ("evaluation_pool_by_handle", lambda: _group_pool_by_handle(grp, P, G))):
+            t_leg = time.time()
+            try:
+                line[name] = fn()
+                line[name]["leg_s"] = round(time.time() - t_leg, 1)
+            except Exception as e:   # a failing leg is recorded, never hidden
+                line.setdefault("leg_errors", {})[name] = f"{type(e).__name__}: {e}"
     print(json.dumps(line))
     grp.close()
     return 0
+
+
+def _group_gate_pool(grp, P, G, what, per_member):
+    """BASELINE config 5's shape from ONE process: `per_member` x G independent circuits as jobs of the device group
+    (spf_group_graph_create), dealt by cost and run side by side by spf_group_run_graphs; the same jobs on member 0 alone for
+    comparison.  Synthetic ciphertexts (timing is value-independent; correctness: tests/test_gpu_group.py)."""
+    import spf_amd
+    from spf_amd import ValueKind
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph
+    from spf_amd.mux_circuits import GraphBuilder, append_uint_multiply, parse_mux_circuit, ripple_carry_adder
+    rng = np.random.default_rng(0x6A0B)
+    n_jobs = per_member * G
+
+    def make(engine):
+        if what == "mul8":
+            c = parse_mux_circuit(open(os.path.join(DATA_DIR, "mux_multiplier_n8_m8.bincode"), "rb").read())
+            return circuit_jobs_as_one_graph(engine, c, rng.integers(0, 1 << 64, size=(1, 16, P.glwe_words), dtype=np.uint64))[0]
+        if what == "add32":
+            return circuit_jobs_as_one_graph(engine, ripple_carry_adder(32, 32, False),
+                                             rng.integers(0, 1 << 64, size=(1, 64, P.glwe_words), dtype=np.uint64))[0]
+        blk16 = parse_mux_circuit(open(os.path.join(DATA_DIR, "mux_multiplier_n16_m16.bincode"), "rb").read())
+        g = spf_amd.FheCircuit(engine)
+        b = GraphBuilder(g)
+        sel = [b.to_ggsw(g.add_input(ValueKind.GLWE1, rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64))) for _ in range(64)]
+        for n in append_uint_multiply(b, sel[:32], sel[32:], lambda x, y: {(16, 16): blk16}[(x, y)]):
+            g.add_output(n, ValueKind.GLWE1)
+        return g
+
+    t_build = time.perf_counter()
+    jobs = [make(grp) for _ in range(n_jobs)]
+    t_build = time.perf_counter() - t_build
+    grp.run_graphs(jobs)            # deals, merges, plans, warms up
+    reps = 2
+    cpu0 = time.process_time()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        grp.run_graphs(jobs)
+    dt = (time.perf_counter() - t0) / reps
+    cpu = (time.process_time() - cpu0) / reps
+    placement = [0] * G
+    for j in jobs:
+        placement[j.member()] += 1
+    st = jobs[0].stats()
+    out = {"jobs": n_jobs, "per_member": per_member, "members": G, "placement": placement,
+           "ms_per_pool_run": round(dt * 1e3, 3), "jobs_per_s": round(n_jobs / dt, 2),
+           "host_cpu_s_per_pool_run": round(cpu, 4), "graph_build_s": round(t_build, 2),
+           "nodes_per_job": st["nodes"], "levels": st["levels"], "launches_per_member": st["launches"]}
+    for j in jobs:
+        j.close()
+    return out
+
+
+def _group_pool_by_handle(grp, P, G, threads_per_member=64, seconds=2.0):
+    """The per-operation drop-in over the group from one process: threads_per_member x G native callers loop
+    KeyswitchL1toL0 -> CircuitBootstrap by handle; caller t's input lives on member t mod G (a value stays on its member, an
+    operation runs where its operands live)."""
+    import ctypes as C
+    import spf_amd
+    import tools.driver as drvmod
+    drv = drvmod.load()
+    lib = grp._raw
+    T = threads_per_member * G
+    lwe1 = np.random.default_rng(0x9003).integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
+    with _pinned_to_quota():
+        pool = spf_amd.Pool(grp, max_batch=4096, max_wait_us=200)
+        try:
+            ins = [pool.upload(1, lwe1 + np.uint64(t), member=t % G) for t in range(T)]
+            el = C.c_double()
+            argv = (pool._h, drvmod.fn(lib, "spf_pool_submit_keyswitch_circuit_bootstrap_v"), drvmod.fn(lib, "spf_pool_wait"),
+                    drvmod.fn(lib, "spf_value_release"), T)
+            drv.spf_pool_drive_v(*argv, 0.5, drvmod.handles(ins), C.byref(el), None)
+            c0 = pool.counters()
+            cpu0 = time.process_time()
+            n = drv.spf_pool_drive_v(*argv, seconds, drvmod.handles(ins), C.byref(el), None)
+            cpu = time.process_time() - cpu0
+            c1 = pool.counters()
+            for v in ins:
+                v.release()
+        finally:
+            pool.close()
+    if n < 0:
+        raise RuntimeError("pool driver: a circuit bootstrap by handle failed")
+    return {"threads": T, "threads_per_member": threads_per_member, "circuit_bootstraps_per_s": round(n / el.value, 1),
+            "achieved_batch": round((c1["handle_ops"] - c0["handle_ops"]) / max(1, c1["handle_launches"] - c0["handle_launches"]), 1),
+            "host_cpu_s_per_s": round(cpu / el.value, 2)}
 
 
 DATA_DIR = os.path.join(ROOT, "spf_amd", "data")
@@ -1153,7 +1260,20 @@ def _bench_mul32_pool(eng, P, rank, world, per_gpu=4):
     st = g.stats()
     g.close()
     cmux = 4 * blk16.metrics()["mux_gates"] + 9104
-    return {"_seconds": dt, "_units": per_gpu, "_rate_key": "multiplications_per_s", "_gates": per_gpu * (cmux + 192),
+    one = None
+    if per_gpu > 1 and rank == 0:   # ONE multiplication alone on the GPU (the latency of config 5's circuit)
+        g1 = FheCircuit(eng)
+        b1 = GraphBuilder(g1)
+        sel = [b1.to_ggsw(g1.add_input(ValueKind.GLWE1, rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64))) for _ in range(64)]
+        for n in append_uint_multiply(b1, sel[:32], sel[32:], lambda a, b: {(16, 16): blk16}[(a, b)]):
+            g1.add_output(n, ValueKind.GLWE1)
+        g1.run()
+        t0 = time.perf_counter()
+        g1.run()
+        one = {"ms_per_graph_run": round((time.perf_counter() - t0) * 1e3, 3), "launches": g1.stats()["launches"]}
+        g1.close()
+    return {"one_multiplication_per_graph": one,
+            "_seconds": dt, "_units": per_gpu, "_rate_key": "multiplications_per_s", "_gates": per_gpu * (cmux + 192),
             "multiplications": n_jobs, "per_gpu": per_gpu,
             "cmux_per_multiplication": cmux, "circuit_bootstraps_per_multiplication": 192,
             "nodes": st["nodes"], "levels": st["levels"], "launches_per_rank": st["launches"],
@@ -1189,10 +1309,19 @@ def _bench_add32(eng, P, K, dev, gen, DevArray, torch, keys_loaded):
     g, _ = circuit_jobs_as_one_graph(eng, adder, cts)
     dt, st = timed(g)
     gates = adder.metrics()["mux_gates"] + 64
+    # what the chip does with config 3 when it is USED: 4 and 16 additions per graph (64 conversions fill a quarter of the CUs)
+    by_k = {str(K): {"ms_per_graph_run": round(dt * 1e3, 3), "adds_per_s": round(K / dt, 2)}}
+    for k2 in (4, 16):
+        if k2 == K:
+            continue
+        g2, _ = circuit_jobs_as_one_graph(eng, adder, rng.integers(0, 1 << 64, size=(k2, 64, P.glwe_words), dtype=np.uint64))
+        d2, s2 = timed(g2, reps=2)
+        by_k[str(k2)] = {"ms_per_graph_run": round(d2 * 1e3, 3), "adds_per_s": round(k2 / d2, 2), "launches": s2["launches"]}
     out = {"adds_per_graph": K, "circuit": f"mux_circuits ripple_carry_adder(32,32,false): {adder.metrics()['mux_gates']} CMUX, "
                                              f"depth {adder.depth()}, 64 circuit bootstraps",
            "ms_per_graph_run": round(dt * 1e3, 3), "adds_per_s": round(K / dt, 2), "gates_per_s": round(K * gates / dt, 1),
            "nodes": st["nodes"], "levels": st["levels"], "launches": st["launches"],
+           "by_adds_per_graph": by_k,
            "note": "wall time of spf_graph_run: H2D of 64 GLWE inputs per add, all levels, D2H of 33 GLWE outputs per add"}
 
     g = spf_amd.FheCircuit(eng)

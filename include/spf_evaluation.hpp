@@ -176,10 +176,27 @@ class Evaluation {
 class FheCircuit {
   public:
     using Node = uint32_t;
+    // a circuit of the Evaluation's FIRST device ...
     explicit FheCircuit(const Evaluation& ev) : ctx_(ev.raw())
     {
         Evaluation::check(spf_graph_create(ctx_, &g_), ctx_);
     }
+    // ... or a JOB of the whole Evaluation (every GPU it owns): placed on a device when it is run — `run_all` deals a pool of
+    // jobs over the devices by cost (spf_group_run_graphs; the reference: one CircuitProcessor fed whole FheCircuits,
+    // circuit_processor/mod.rs:573-623)
+    struct Job {};
+    FheCircuit(const Evaluation& ev, Job) : ctx_(ev.raw()), grp_(ev.group())
+    {
+        if (spf_group_graph_create(grp_, &g_) != SPF_OK) throw Error(SPF_ERR_HIP, spf_group_last_error(grp_));
+    }
+    static void run_all(const Evaluation& ev, const std::vector<FheCircuit*>& jobs)
+    {
+        std::vector<spf_graph*> raw;
+        for (FheCircuit* j : jobs) raw.push_back(j->g_);
+        const spf_status s = spf_group_run_graphs(ev.group(), raw.data(), raw.size());
+        if (s != SPF_OK) throw Error(s, spf_group_last_error(ev.group()));
+    }
+    int device_member() const { return spf_graph_member(g_); }
     FheCircuit(const FheCircuit&) = delete;
     FheCircuit& operator=(const FheCircuit&) = delete;
     ~FheCircuit() { spf_graph_destroy(g_); }
@@ -210,6 +227,7 @@ class FheCircuit {
 
   private:
     spf_ctx* ctx_ = nullptr;
+    spf_group* grp_ = nullptr;
     spf_graph* g_ = nullptr;
 };
 

@@ -601,6 +601,24 @@ spf_status spf_group_keyswitch_circuit_bootstrap_batch(spf_group *grp, size_t B,
 /* `Evaluation::l1ggsw_zero` / `l1ggsw_one` (identical on every member: same keys, same kernels; taken from member 0) */
 spf_status spf_group_l1ggsw_constant(spf_group *grp, int bit, double *ggsw_fft_out);
 
+/* Gate-graph jobs over the group — `CircuitProcessor::run_graph_blocking` for a POOL of independent circuits on a multi-GPU node
+ * (circuit_processor/mod.rs:573-623; the multiplier circuits of circuits/mul.rs:90-200; BASELINE config 5).  The unit dealt to a
+ * device is the job (one graph): cutting one graph across GPUs would ship a 256 KiB GGSW per selector crossing the cut,
+ * independent graphs need nothing.
+ *   spf_group_graph_create: a graph that is not bound to a device yet; built with spf_graph_add_* as usual (same validation).
+ *   spf_group_run_graphs:   deals the n jobs over the members in rotation by cost, longest processing time first (cost =
+ *       50 x circuit bootstraps + other operations of the job; ties by position: deterministic), lowers every member's jobs
+ *       into ONE graph on its device — the level-batching executor then sees K jobs x gates per level — runs the members side
+ *       by side on their worker threads and returns when every output of every job has been written.  The merged graphs are
+ *       kept while the same jobs come again (new input contents, same DAGs).  A member that fails with SPF_ERR_HIP leaves the
+ *       rotation and its jobs are dealt again over the others.  Results are word-identical to spf_graph_run of each job on one
+ *       context.  spf_graph_run / spf_graph_stats / spf_graph_destroy work on such a graph (run = a pool of one; stats = of
+ *       the job as built: levels and launches are those of the merged graph it last ran in).
+ *   spf_graph_member:       the member a group's graph last ran on (-1 before its first run; 0 for an ordinary graph). */
+spf_status spf_group_graph_create(spf_group *grp, spf_graph **out);
+spf_status spf_group_run_graphs(spf_group *grp, spf_graph *const *graphs, size_t n);
+int spf_graph_member(const spf_graph *graph);
+
 /* Call coalescing over the group: one pool per member; a calling thread is dealt to a member on its first submit
  * (round-robin over the members in rotation) and stays there, so that the callers of one device keep coming back to the
  * same batch.  The handle is used with the spf_pool_submit_*, spf_pool_wait, spf_pool_stats (sums), spf_pool_set_max_inflight

@@ -155,6 +155,9 @@ SYMBOLS = [
     ("spf_group_keyswitch_circuit_bootstrap_batch", _I, [_P, _SZ, _P, _P]),
     ("spf_group_l1ggsw_constant", _I, [_P, _I, _P]),
     ("spf_pool_create_group", _I, [_P, _SZ, _U32, C.POINTER(_P)]),
+    ("spf_group_graph_create", _I, [_P, C.POINTER(_P)]),
+    ("spf_group_run_graphs", _I, [_P, C.POINTER(_P), _SZ]),
+    ("spf_graph_member", _I, [_P]),
     # device-resident values and the pool's submits by handle
     ("spf_pool_counters_get", _I, [_P, C.POINTER(_U64 * 10)]),
     ("spf_value_upload", _I, [_P, _I, _I, _P, C.POINTER(_P)]),
@@ -653,6 +656,12 @@ class Group(Engine):
 
     def debug_fail_next(self, member: int, count: int = 1):
         self._ck(self._raw.spf_group_debug_fail_next(self._h, member, count))
+
+    def run_graphs(self, graphs):
+        """`spf_group_run_graphs`: graphs are `spf_amd.FheCircuit`s made over this group; dealt to the members by cost,
+        every member's jobs lowered into one graph, all members side by side"""
+        arr = (C.c_void_p * len(graphs))(*[g._g for g in graphs])
+        self._ck(self._raw.spf_group_run_graphs(self._h, arr, len(graphs)))
 
     # the per-context hooks have no group form
     def key_blob(self, which):

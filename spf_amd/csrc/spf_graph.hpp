@@ -70,6 +70,8 @@ struct spf_graph {
     };
     spf_ctx* ctx = nullptr;
     spf_params prm{};
+    struct spf_group* grp = nullptr; // a graph of a device group (spf_group_graph_create): placed on a member when it is run
+    int member = -1;                 // ... the member its most recent run took place on
     std::vector<Node> nodes;
     std::vector<std::pair<uint32_t, void*>> outputs;
     bool planned = false;
@@ -545,6 +547,9 @@ inline spf_status run(spf_graph* g)
 
 } // namespace spf_graph_impl
 
+static spf_status group_run_graphs(struct spf_group* grp, spf_graph* const* graphs, size_t n); // spf_group.hpp
+static void group_forget_graph(struct spf_group* grp, spf_graph* graph);
+
 spf_status spf_graph_create(spf_ctx* c, spf_graph** out)
 {
     if (!c || !out) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
@@ -560,6 +565,7 @@ spf_status spf_graph_create(spf_ctx* c, spf_graph** out)
 void spf_graph_destroy(spf_graph* g)
 {
     if (!g) return;
+    if (g->grp) group_forget_graph(g->grp, g); // (a merged graph of the group may still read this job's buffers)
     (void)hipSetDevice(g->ctx->device);
     g->release();
     g->h_inputs.free_buf();
@@ -625,9 +631,11 @@ spf_status spf_graph_add_output(spf_graph* g, uint32_t node, void* host)
     return SPF_OK;
 }
 
+
 spf_status spf_graph_run(spf_graph* g)
 {
     if (!g) return SPF_ERR_INVALID_ARGUMENT;
+    if (g->grp) return group_run_graphs(g->grp, &g, 1); // a group's graph: placed and run by the group
     return spf_graph_impl::run(g);
 }
 

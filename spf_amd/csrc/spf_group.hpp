@@ -155,6 +155,15 @@ struct spf_group {
     double wire_seconds = 0.0, comm_init_seconds = 0.0;
     size_t bytes_per_member = 0;
     int rccl_world = 0;
+    // gate-graph jobs (spf_group_run_graphs): per member the merged graph of the jobs it was dealt last time, kept while the same
+    // jobs come again (a pool of circuits is usually run more than once: new input contents, same DAGs)
+    struct Merged {
+        std::vector<spf_graph*> jobs;
+        std::vector<std::pair<size_t, size_t>> shape; // (nodes, outputs) of every job when it was merged
+        spf_graph* graph = nullptr;
+    };
+    std::vector<Merged> merged; // [member]
+    std::mutex graph_mu;        // one spf_group_run_graphs at a time
 };
 
 namespace {
@@ -463,6 +472,8 @@ void spf_group_destroy(spf_group* g)
 {
     if (!g) return;
     for (auto& mem : g->m) mem->worker.finish();
+    for (auto& mg : g->merged)
+        if (mg.graph) spf_graph_destroy(mg.graph);
     if (g->rccl.handle)
         for (ncclComm_t c : g->rccl.comms)
             if (c) (void)g->rccl.CommDestroy(c);
@@ -691,6 +702,167 @@ spf_status spf_group_l1ggsw_constant(spf_group* g, int bit, double* out)
     if (st[0] != SPF_OK) return gfail(g, st[0], std::string("member ") + std::to_string(rot[0]) + ": " + spf_last_error(g->m[rot[0]]->ctx));
     return SPF_OK;
 }
+
+// ---- gate-graph jobs over the group (SURVEY.md §8 e / f3; BASELINE config 5: "32x32-bit encrypted multiply ... 8xMI355X gate pool")
+//
+// The reference's processor is one per machine and is fed whole `FheCircuit`s (circuit_processor/mod.rs:573-623; the multiplier
+// circuits of circuits/mul.rs:90-200).  A gate graph is a chain of dependent CMUX levels hanging off one wide level of
+// conversions: cutting ONE graph across GPUs would put a 256 KiB GGSW on the wire for every selector that crosses the cut,
+// independent graphs need nothing.  So the unit dealt to a device is the JOB (one graph): longest-processing-time first over
+// the members in rotation (the rule of spf_amd/gate_pool.py, here behind the C ABI for a one-process host), every member's
+// jobs are lowered into ONE graph on its device — the level-batching executor then sees K jobs x gates per level — and the
+// members run side by side on their worker threads.  No data-path collective.
+
+} // extern "C"
+
+namespace {
+
+// relative cost of a job: what its launches are made of (a circuit bootstrap is ~60 us per ciphertext of a batch, a CMUX level
+// ~20 us per launch: what matters is only that equal jobs weigh the same and bigger jobs more)
+double graph_cost(const spf_graph* g)
+{
+    double c = 0;
+    for (const auto& n : g->nodes)
+        c += n.op == SPF_OP_CIRCUIT_BOOTSTRAP ? 50.0 : (n.op >= 0 ? 1.0 : 0.0);
+    return c;
+}
+
+// `jobs` appended into one graph on `c`, node ids shifted; inputs and outputs keep pointing at the jobs' own host buffers
+spf_status merge_jobs(spf_ctx* c, const std::vector<spf_graph*>& jobs, spf_graph** out)
+{
+    spf_graph* m = nullptr;
+    spf_status st = spf_graph_create(c, &m);
+    if (st != SPF_OK) return st;
+    try {
+        for (const spf_graph* j : jobs) {
+            const uint32_t base = (uint32_t)m->nodes.size();
+            for (spf_graph::Node n : j->nodes) {
+                for (uint32_t i = 0; i < n.n_in; i++) n.in[i] += base;
+                m->nodes.push_back(n);
+            }
+            for (const auto& o : j->outputs) m->outputs.emplace_back(o.first + base, o.second);
+        }
+    } catch (const std::exception&) {
+        spf_graph_destroy(m);
+        return fail(c, SPF_ERR_HIP, "out of host memory");
+    }
+    *out = m;
+    return SPF_OK;
+}
+
+} // namespace
+
+static spf_status group_run_graphs(spf_group* g, spf_graph* const* graphs, size_t n)
+{
+    if (!g || (n && !graphs)) return gfail(g, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    for (size_t i = 0; i < n; i++)
+        if (!graphs[i] || graphs[i]->grp != g) return gfail(g, SPF_ERR_INVALID_ARGUMENT, "spf_group_run_graphs: a graph that was not made by spf_group_graph_create of this group");
+    if (n == 0) return SPF_OK;
+    std::lock_guard<std::mutex> whole(g->graph_mu);
+    const int G = (int)g->m.size();
+    try {
+        g->merged.resize((size_t)G);
+    } catch (const std::exception&) {
+        return gfail(g, SPF_ERR_HIP, "out of host memory");
+    }
+    std::vector<size_t> todo(n);
+    for (size_t i = 0; i < n; i++) todo[i] = i;
+    while (!todo.empty()) {
+        const std::vector<int> rot = members_in_rotation(g);
+        if (rot.empty()) return gfail(g, SPF_ERR_HIP, "no member of the group is in rotation");
+        // longest processing time first: the jobs by falling cost (ties by index: deterministic), each to the member with
+        // the least load so far
+        std::vector<double> cost(todo.size());
+        for (size_t k = 0; k < todo.size(); k++) cost[k] = graph_cost(graphs[todo[k]]);
+        std::vector<size_t> order(todo.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+        std::vector<double> load(rot.size(), 0.0);
+        std::vector<std::vector<size_t>> dealt(rot.size()); // per member in rotation: indices into `graphs`
+        for (size_t k : order) {
+            size_t best = 0;
+            for (size_t r = 1; r < rot.size(); r++)
+                if (load[r] < load[best]) best = r;
+            dealt[best].push_back(todo[k]);
+            load[best] += cost[k];
+        }
+        std::vector<int> who;
+        std::vector<size_t> slot_of; // index into dealt for who[k]
+        for (size_t r = 0; r < rot.size(); r++)
+            if (!dealt[r].empty()) {
+                std::sort(dealt[r].begin(), dealt[r].end()); // (the jobs of a member in the caller's order: a stable merged graph)
+                who.push_back(rot[r]);
+                slot_of.push_back(r);
+            }
+        const std::vector<spf_status> st = on_members(g, who, [&](int member) -> spf_status {
+            size_t r = 0;
+            for (size_t k = 0; k < who.size(); k++)
+                if (who[k] == member) r = slot_of[k];
+            spf_group::Member* mem = g->m[member].get();
+            int f = mem->fail_next.load();
+            if (f > 0 && mem->fail_next.compare_exchange_strong(f, f - 1))
+                return fail(mem->ctx, SPF_ERR_HIP, "injected device failure (spf_group_debug_fail_next)");
+            std::vector<spf_graph*> jobs;
+            std::vector<std::pair<size_t, size_t>> shape;
+            for (size_t i : dealt[r]) {
+                jobs.push_back(graphs[i]);
+                shape.emplace_back(graphs[i]->nodes.size(), graphs[i]->outputs.size());
+            }
+            spf_group::Merged& mg = g->merged[(size_t)member];
+            if (!mg.graph || mg.jobs != jobs || mg.shape != shape) { // other jobs than last time (or a job changed): lower them again
+                if (mg.graph) spf_graph_destroy(mg.graph);
+                mg.graph = nullptr;
+                spf_status s = merge_jobs(mem->ctx, jobs, &mg.graph);
+                if (s != SPF_OK) return s;
+                mg.jobs = jobs;
+                mg.shape = shape;
+            }
+            const spf_status s = spf_graph_impl::run(mg.graph);
+            if (s == SPF_OK)
+                for (spf_graph* j : jobs) { j->member = member; j->n_levels = mg.graph->n_levels; j->n_launches = mg.graph->n_launches; }
+            return s;
+        });
+        todo.clear();
+        for (size_t k = 0; k < who.size(); k++) {
+            if (st[k] == SPF_OK) continue;
+            spf_group::Member* mem = g->m[who[k]].get();
+            const std::string why = "member " + std::to_string(who[k]) + " (device " + std::to_string(mem->device) + "): " + spf_last_error(mem->ctx);
+            if (st[k] != SPF_ERR_HIP) return gfail(g, st[k], why);
+            mem->failed.store(true); // out of rotation; its jobs are dealt again over the others
+            gfail(g, SPF_ERR_HIP, why);
+            for (size_t i : dealt[slot_of[k]]) todo.push_back(i);
+        }
+    }
+    return SPF_OK;
+}
+
+// a job is going away: no merged graph may keep its node list or its buffers
+static void group_forget_graph(spf_group* g, spf_graph* graph)
+{
+    std::lock_guard<std::mutex> whole(g->graph_mu);
+    for (auto& mg : g->merged)
+        if (std::find(mg.jobs.begin(), mg.jobs.end(), graph) != mg.jobs.end()) {
+            if (mg.graph) spf_graph_destroy(mg.graph);
+            mg.graph = nullptr;
+            mg.jobs.clear();
+            mg.shape.clear();
+        }
+}
+
+extern "C" {
+
+spf_status spf_group_graph_create(spf_group* g, spf_graph** out)
+{
+    if (!g || !out) return gfail(g, SPF_ERR_INVALID_ARGUMENT, "null argument");
+    spf_status s = spf_graph_create(g->m[0]->ctx, out); // (member 0's context: parameters and build-time validation only)
+    if (s != SPF_OK) return gfail(g, s, std::string("member 0: ") + spf_last_error(g->m[0]->ctx));
+    (*out)->grp = g;
+    return SPF_OK;
+}
+
+spf_status spf_group_run_graphs(spf_group* g, spf_graph* const* graphs, size_t n) { return group_run_graphs(g, graphs, n); }
+
+int spf_graph_member(const spf_graph* graph) { return graph ? (graph->grp ? graph->member : 0) : -1; }
 
 // ---- call coalescing over the group: one pool per member, threads dealt round-robin on their first submit
 

@@ -890,7 +890,10 @@ struct spf_pool {
         b.out_blk = spf_value_impl::Block::make(arena, B * out);
         if (!b.out_blk) return SPF_ERR_HIP;
         char* d_out = static_cast<char*>(b.out_blk->p);
-        if (hipEventCreateWithFlags(&b.ev_k, hipEventDefault) != hipSuccess) return SPF_ERR_HIP;
+        // (a bootstrap batch is milliseconds on the GPU: its completer sleeps in the driver — hipEventBlockingSync — instead of
+        // polling the event from a CPU; the cheap batches are polled by the launcher itself.  SPF_POOL_EVENT_FLAGS overrides.)
+        static const unsigned heavy_flags = [] { const char* e = getenv("SPF_POOL_EVENT_FLAGS"); return e ? (unsigned)atoi(e) : (unsigned)hipEventBlockingSync; }();
+        if (hipEventCreateWithFlags(&b.ev_k, heavy(b.op) ? heavy_flags : hipEventDefault) != hipSuccess) return SPF_ERR_HIP;
         hipStream_t sk = s.sk;
         spf_status st = SPF_OK;
         if (scattered_cmux(b.op)) {

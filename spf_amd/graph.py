@@ -45,7 +45,12 @@ class FheCircuit:
         self._eng = engine
         self._lib = engine._lib
         h = C.c_void_p()
-        engine._ck(self._lib.spf_graph_create(engine._h, C.byref(h)))
+        from ._ffi import Group
+        if isinstance(engine, Group):   # a job of the group: placed on a member when it is run (Group.run_graphs / run())
+            engine._ck(engine._raw.spf_group_graph_create(engine._h, C.byref(h)))
+            self._lib = engine._raw
+        else:
+            engine._ck(self._lib.spf_graph_create(engine._h, C.byref(h)))
         self._g = h
         self._keep: List[np.ndarray] = []   # input / output buffers the library reads and writes at run()
 
@@ -99,6 +104,10 @@ class FheCircuit:
     # CircuitProcessor::run_graph_blocking
     def run(self):
         self._eng._ck(self._lib.spf_graph_run(self._g))
+
+    def member(self) -> int:
+        """the member of the group the graph last ran on (0 for a graph of one engine)"""
+        return int(self._lib.spf_graph_member(self._g))
 
     def stats(self):
         n, lv, la = C.c_uint32(), C.c_uint32(), C.c_uint32()

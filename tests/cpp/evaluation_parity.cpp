@@ -12,6 +12,7 @@ extern "C" {
 #include <complex>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -138,6 +139,30 @@ int main()
             ev.gate_bootstrap(g1.data(), l1b.data(), B);
             ev2.gate_bootstrap(g2.data(), l1b.data(), B);
             expect(ev2.devices() == 2 && same(g1, g2), "Evaluation over a device group [0, 0]: same words as one device");
+
+            // gate-graph jobs over the group: four copies of the chain above as four jobs, dealt 2 + 2, same words as the one-device graph
+            std::vector<std::vector<uint64_t>> jout(4, std::vector<uint64_t>((k + 1) * N));
+            std::vector<std::unique_ptr<spf::FheCircuit>> jobs;
+            std::vector<spf::FheCircuit*> raw;
+            for (int j = 0; j < 4; j++) {
+                jobs.emplace_back(new spf::FheCircuit(ev2, spf::FheCircuit::Job{}));
+                spf::FheCircuit& q = *jobs.back();
+                auto jx = q.input(SPF_VAL_GLWE1, bit.data());
+                auto ja = q.input(SPF_VAL_GLWE1, a.data());
+                auto jb = q.input(SPF_VAL_GLWE1, b.data());
+                auto js = q.op(SPF_OP_CIRCUIT_BOOTSTRAP, {q.op(SPF_OP_KEYSWITCH_L1_TO_L0, {q.op(SPF_OP_SAMPLE_EXTRACT, {jx}, 0)})});
+                q.output(q.op(SPF_OP_CMUX, {js, ja, q.op(SPF_OP_NOT, {jb})}), jout[(size_t)j].data());
+                raw.push_back(&q);
+            }
+            spf::FheCircuit::run_all(ev2, raw);
+            int on0 = 0, on1 = 0;
+            bool all_same = true;
+            for (int j = 0; j < 4; j++) {
+                on0 += raw[(size_t)j]->device_member() == 0;
+                on1 += raw[(size_t)j]->device_member() == 1;
+                all_same = all_same && same(jout[(size_t)j], gref);
+            }
+            expect(on0 == 2 && on1 == 2 && all_same, "FheCircuit jobs over the group: dealt 2 + 2, oracle's words");
         }
 
         // malformed graph: wrong operand type must throw when the node is added (task.rs:26-31)

@@ -29,7 +29,9 @@ with bench._pinned_to_quota():
     el = C.c_double()
     n = drv.spf_pool_drive_v(pool._h, drvmod.fn(lib, "spf_pool_submit_keyswitch_circuit_bootstrap_v"), drvmod.fn(lib, "spf_pool_wait"),
                              drvmod.fn(lib, "spf_value_release"), T, seconds, drvmod.handles(ins), C.byref(el), None)
-    print(f"{n} operations in {el.value:.3f} s = {n / el.value:.0f} per second", file=sys.stderr)
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    print(f"{n} operations in {el.value:.3f} s = {n / el.value:.0f} per second; process CPU so far {ru.ru_utime + ru.ru_stime:.1f} s", file=sys.stderr)
     for v in ins:
         v.release()
     pool.close()
