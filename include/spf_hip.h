@@ -333,6 +333,11 @@ typedef struct spf_pool_counters {
                                               * (blind_rotate8), two ciphertexts per workgroup (2p2), four (2p) */
     uint64_t staging_sets;                   /* staging sets per pool (a caller may leave that many batches uncollected) */
     uint64_t value_mallocs;                  /* hipMalloc calls of the value arena so far (steady state: no growth) */
+    uint64_t stream_concurrency;             /* how many of the pool's streams ran side by side in the probe spf_pool_create makes
+                                              * (a 200 us spin kernel on every set's stream at once; minimum over the members).
+                                              * Below 8 the resident batches take turns: GPU_MAX_HW_QUEUES took effect too late
+                                              * (a host that touched HIP before loading the library) — spf_pool_create then
+                                              * still returns SPF_OK and leaves a WARNING in spf_last_error(ctx) */
 } spf_pool_counters;
 spf_status spf_pool_counters_get(spf_pool *pool, spf_pool_counters *out);
 
@@ -536,8 +541,10 @@ const char *spf_last_cmux_kernel(spf_ctx *ctx);
  * further members on an already served device take a device-to-device copy; every member then derives its own images
  * (keyswitch byte planes, scaled bootstrap key).  librccl.so is loaded on first use (dlopen); transport can be forced with
  * the environment variable SPF_GROUP_TRANSPORT = "rccl" (default whenever the group has more than one member; also taken
- * for a one-member group when set explicitly) or "peer" (hipMemcpyPeerAsync, no RCCL).  A missing librccl.so with
- * transport rccl is SPF_ERR_HIP, never a silent change of transport.
+ * for a one-member group when set explicitly) or "peer" (hipMemcpyPeerAsync, no RCCL).  A transport NAMED there is never
+ * replaced: a missing librccl.so with SPF_GROUP_TRANSPORT=rccl is SPF_ERR_HIP.  When rccl is only the default and librccl.so
+ * cannot be loaded the group falls back to peer copies and says so (spf_group_replication_stats: transport
+ * "peer (librccl.so could not be loaded)").
  *
  * Failures: a member whose call fails with SPF_ERR_HIP is taken out of rotation and its range is re-queued over the
  * remaining members ("a failed GPU's shard is re-queued by host"); the call fails only when no member is
@@ -625,7 +632,8 @@ int spf_graph_member(const spf_graph *graph);
  * (per member) and spf_pool_destroy entry points above. */
 spf_status spf_pool_create_group(spf_group *grp, size_t max_batch, uint32_t max_wait_us, spf_pool **out);
 
-/* Library / kernel build information, e.g. "spf_hip 0.1 gfx950". */
+/* Library / kernel build information: version, target, the compile-time options of the blind rotation — and "ABLATION(n: timing
+ * only, results are WRONG)" right after the target when the library is a timing-only ablation build (-DSPF_ABL=n). */
 const char *spf_version(void);
 
 #ifdef __cplusplus

@@ -159,7 +159,7 @@ SYMBOLS = [
     ("spf_group_run_graphs", _I, [_P, C.POINTER(_P), _SZ]),
     ("spf_graph_member", _I, [_P]),
     # device-resident values and the pool's submits by handle
-    ("spf_pool_counters_get", _I, [_P, C.POINTER(_U64 * 10)]),
+    ("spf_pool_counters_get", _I, [_P, C.POINTER(_U64 * 11)]),
     ("spf_value_upload", _I, [_P, _I, _I, _P, C.POINTER(_P)]),
     ("spf_value_upload_batch", _I, [_P, _I, _I, _SZ, _P, C.POINTER(_P)]),
     ("spf_value_download_batch", _I, [_SZ, C.POINTER(_P), _P]),
@@ -826,11 +826,11 @@ class Pool:
         return ops.value, launches.value
 
     def counters(self) -> dict:
-        a = (C.c_uint64 * 10)()
+        a = (C.c_uint64 * 11)()
         self._ck(self._lib.spf_pool_counters_get(self._h, C.byref(a)), "spf_pool_counters_get")
         return {"ops": a[0], "launches": a[1], "handle_ops": a[2], "handle_launches": a[3], "reclaimed": a[4],
                 "bootstrap_launches_by_shape": {"blind_rotate8": a[5], "blind_rotate2p2": a[6], "blind_rotate2p": a[7]},
-                "staging_sets": a[8], "value_mallocs": a[9]}
+                "staging_sets": a[8], "value_mallocs": a[9], "stream_concurrency": a[10]}
 
     # -- device-resident values (spf_value_*): the operands and results of the `_v` submits ---------------------------------
     def _ck(self, st: int, what: str):

@@ -152,6 +152,8 @@ struct spf_group {
     spf_group_impl::Rccl rccl;
     std::vector<int> leaders; // member index of each communicator rank
     enum Transport { T_NONE = 0, T_RCCL = 1, T_PEER = 2 } transport = T_NONE;
+    bool transport_forced = false; // SPF_GROUP_TRANSPORT named it: a missing librccl.so is then an error, never a change of transport
+    std::string transport_note;    // why the default transport was changed (librccl.so not loadable)
     double wire_seconds = 0.0, comm_init_seconds = 0.0;
     size_t bytes_per_member = 0;
     int rccl_world = 0;
@@ -301,8 +303,15 @@ spf_status ensure_rccl(spf_group* g)
 }
 
 // member 0's blob `which` -> every other member's blob, then every member derives its own images (commit)
+struct CallerDevice { // the calling thread's current device is put back when a group call that switches devices returns
+    int prev = -1;
+    CallerDevice() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~CallerDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 spf_status replicate_blob(spf_group* g, int which)
 {
+    CallerDevice restore;
     const int G = (int)g->m.size();
     if (G == 1 && g->transport != spf_group::T_RCCL) return SPF_OK;
     std::vector<void*> ptr(G, nullptr);
@@ -317,7 +326,16 @@ spf_status replicate_blob(spf_group* g, int which)
     auto hipfail = [&](const char* what, hipError_t e) { return gfail(g, SPF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
     if (g->transport == spf_group::T_RCCL) {
         spf_status s = ensure_rccl(g); // (communicator set-up is timed by itself: comm_init_seconds)
-        if (s != SPF_OK) return s;
+        if (s != SPF_OK) {
+            // RCCL was only the DEFAULT for a group of several members: without a loadable librccl.so plain peer copies do the same
+            // job (said in the replication stats).  A transport the environment asked for by name is never replaced.
+            if (g->transport_forced || g->rccl.handle) return s;
+            g->transport = spf_group::T_PEER;
+            {
+                std::lock_guard<std::mutex> lk(g->err_mu);
+                g->transport_note = g->err;
+            }
+        }
     }
     const auto t0 = std::chrono::steady_clock::now();
     if (g->transport == spf_group::T_RCCL) {
@@ -340,6 +358,10 @@ spf_status replicate_blob(spf_group* g, int which)
         }
     } else {
         // plain peer copies from member 0's HBM to each other leader (runtime picks xGMI P2P when the devices allow it)
+        {
+            hipError_t e0 = hipSetDevice(g->m[0]->device); // (the copies are enqueued on member 0's stream: its device is current)
+            if (e0 != hipSuccess) return hipfail("hipSetDevice", e0);
+        }
         for (int i : g->leaders) {
             if (i == 0) continue;
             hipError_t e = hipMemcpyPeerAsync(ptr[i], g->m[i]->device, ptr[0], g->m[0]->device, bytes, g->m[0]->ctx->stream);
@@ -447,6 +469,7 @@ spf_status spf_group_create(const spf_params* params, const int* device_ids, int
         g->m.push_back(std::move(mem));
     }
     const char* t = getenv("SPF_GROUP_TRANSPORT");
+    g->transport_forced = t && *t;
     if (t && !strcmp(t, "peer")) g->transport = spf_group::T_PEER;
     else if (t && !strcmp(t, "rccl")) g->transport = spf_group::T_RCCL;
     else if (t && *t) {
@@ -547,7 +570,9 @@ spf_status spf_group_replication_stats(spf_group* g, double* wire_seconds, doubl
     if (comm_init_seconds) *comm_init_seconds = g->comm_init_seconds;
     if (bytes_per_member) *bytes_per_member = g->bytes_per_member;
     if (rccl_world_size) *rccl_world_size = g->rccl_world;
-    if (transport) *transport = g->transport == spf_group::T_RCCL ? "rccl" : g->transport == spf_group::T_PEER ? "peer" : "none";
+    if (transport)
+        *transport = g->transport == spf_group::T_RCCL ? "rccl"
+                     : g->transport == spf_group::T_PEER ? (g->transport_note.empty() ? "peer" : "peer (librccl.so could not be loaded)") : "none";
     return SPF_OK;
 }
 

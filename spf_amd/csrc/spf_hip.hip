@@ -488,7 +488,26 @@ void spf_default_params(spf_params* o)
     *o = spf_params{637, 2048, 1, 16, 2, 4, 4, 2, 6, 7, 6, 3, 15};
 }
 
-const char* spf_version(void) { return "spf_hip 0.2 (gfx950: two-wave blind rotation, int8-MFMA keyswitch, cbs_radix cmux)"; }
+// the build's identity: version, target, the compile-time options of the blind rotation as built — and, first of all, whether
+// this is a TIMING-ONLY ablation build whose results are wrong by construction (SPF_ABL, spf_kernels.hpp)
+#define SPF_VSTR2(x) #x
+#define SPF_VSTR(x) SPF_VSTR2(x)
+const char* spf_version(void)
+{
+    return "spf_hip 0.6 gfx950"
+#if defined(SPF_ABL) && SPF_ABL != 0
+           " ABLATION(" SPF_VSTR(SPF_ABL) ": timing only, results are WRONG)"
+#endif
+           " (blind rotation: BR_OPT=" SPF_VSTR(SPF_BR_OPT) " BR_OPT_MIX=" SPF_VSTR(SPF_BR_OPT_MIX) " BR2_OPT=" SPF_VSTR(SPF_BR2_OPT)
+           " BR_NEG=" SPF_VSTR(SPF_BR_NEG) " BSK_PRESCALED=" SPF_VSTR(SPF_BSK_PRESCALED) " TRIO_SHAPE=" SPF_VSTR(SPF_TRIO_SHAPE)
+#ifdef SPF_STAMPS
+           " STAMPS"
+#endif
+#ifdef SPF_POOL_TRACE
+           " POOL_TRACE"
+#endif
+           "; int8-MFMA keyswitch; cbs_radix CMUX; values by handle)";
+}
 
 // The text is copied into storage of the calling thread, so the pointer stays valid while other
 // threads keep using (and failing on) the same context.
@@ -1899,6 +1918,44 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         delete p;
         return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the pool's streams");
     }
+    // Do the sets' streams really run side by side?  The library asks for GPU_MAX_HW_QUEUES=24 when it is loaded, but a host that
+    // initialised HIP earlier keeps the runtime's default (4): the pool's resident batches then take turns (0.35-0.50 of the
+    // device-resident rate instead of 0.8-0.97, profiles/r05_pool.md).  Measured, not guessed: a 200 us spin kernel on every
+    // set's stream at once; streams that share a hardware queue run them one after the other.
+    {
+        const int n = spf_pool_impl::kSets;
+        const uint64_t ticks = 20000; // 200 us of the 100 MHz constant-rate counter
+        hipEvent_t e0 = nullptr, e1[spf_pool_impl::kSets] = {};
+        bool ok = hipEventCreate(&e0) == hipSuccess;
+        for (int i = 0; ok && i < n; i++) ok = hipEventCreate(&e1[i]) == hipSuccess;
+        if (ok) {
+            for (int i = 0; i < n; i++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, p->sets[i].sk, (uint64_t)100); // (code object loaded, queues created)
+            for (int i = 0; i < n; i++) (void)hipStreamSynchronize(p->sets[i].sk);
+            (void)hipEventRecord(e0, p->sets[0].sk);
+            (void)hipStreamSynchronize(p->sets[0].sk);
+            for (int i = 0; i < n; i++) {
+                hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, p->sets[i].sk, ticks);
+                (void)hipEventRecord(e1[i], p->sets[i].sk);
+            }
+            float worst = 0.f;
+            for (int i = 0; i < n; i++) {
+                float ms = 0.f;
+                if (hipEventSynchronize(e1[i]) == hipSuccess && hipEventElapsedTime(&ms, e0, e1[i]) == hipSuccess) worst = std::max(worst, ms);
+            }
+            if (worst > 0.f) p->stream_concurrency = (int)std::min<double>(n, std::max(1.0, std::round(n * 0.2 / worst)));
+        }
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        for (hipEvent_t e : e1)
+            if (e) (void)hipEventDestroy(e);
+        if (p->stream_concurrency > 0 && p->stream_concurrency < 8) {
+            const char* q = getenv("GPU_MAX_HW_QUEUES");
+            fail(c, SPF_OK, std::string("spf_pool_create: WARNING: only ~") + std::to_string(p->stream_concurrency) + " of the pool's " + std::to_string(n) +
+                                " streams run concurrently (GPU_MAX_HW_QUEUES=" + (q ? q : "unset") +
+                                " took effect too late or is too small: export GPU_MAX_HW_QUEUES=24 before the process first touches HIP); "
+                                "resident batches will take turns");
+        }
+    }
     try {
         p->arena = std::make_shared<spf_value_impl::Arena>();
         p->arena->device = c->device;
@@ -2423,6 +2480,7 @@ spf_status spf_pool_counters_get(spf_pool* p, spf_pool_counters* out)
         out->reclaimed += q->n_reclaimed;
         for (int i = 0; i < 3; i++) out->bootstrap_launches_by_shape[i] += q->n_shape[i];
         out->staging_sets = (uint64_t)q->n_sets;
+        out->stream_concurrency = out->stream_concurrency ? std::min<uint64_t>(out->stream_concurrency, (uint64_t)q->stream_concurrency) : (uint64_t)q->stream_concurrency;
         out->value_mallocs += q->arena->n_malloc.load();
     };
     if (p->members.empty()) add(p);

@@ -1987,6 +1987,13 @@ __global__ void copy_words_kernel(const uint64_t* __restrict__ src, uint64_t* __
 }
 
 
+// spins for `ticks` of the 100 MHz constant-rate counter: the pool's probe of how many of its streams really run side by side
+__global__ void spin_kernel(uint64_t ticks)
+{
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // Row gather for the graph executor: dst row r = the `words` u64 at src[r] (operands of one level of
 // a gate graph live wherever their producers wrote them; the batched kernels want them contiguous).
 __global__ void gather_rows_kernel(const uint64_t* const* src, uint64_t* dst, uint32_t rows, uint32_t words)

@@ -304,6 +304,7 @@ struct spf_pool {
     std::condition_variable_any cv_fly[spf_pool_impl::kSets];
     uint64_t n_reclaimed = 0;             // outputs delivered on their owners' behalf (reclaim)
     uint64_t n_handle_ops = 0, n_handle_launches = 0;
+    int stream_concurrency = 0;           // how many of the sets' streams were seen running at once when the pool was made (0: not measured)
     int n_sets = spf_pool_impl::kSets;    // staging sets in use (SPF_POOL_SETS: tests fill every set with three)
     size_t split = 4;                     // by handle a bootstrap batch goes as soon as it holds 1 / split of the callers (SPF_POOL_SPLIT; see submit_impl)
     int spin_us = 0;                      // how long a waiter of a cheap operation by handle looks before it sleeps (SPF_POOL_SPIN_US; measured on
@@ -682,11 +683,26 @@ struct spf_pool {
     // Four groups, except around the population that exactly fills the chip at four ciphertexts per CU (1 024 on 256 CUs): there
     // the bootstraps of four resident batches subscribe every CU and each group's keyswitch, trace and copy kernels queue behind
     // them — three groups leave the fourth quarter of the callers in their host phase.
+    // (hysteresis: around 3.5 / 6 times the CU count the population oscillates as callers pass through wait and submit; the count
+    // only changes when the other value has been wanted for 50 ms, so that the callers stay in their groups — ADVICE r05)
+    mutable size_t groups_cur = 4;
+    mutable std::chrono::steady_clock::time_point groups_other_since{};
     size_t groups_now() const
     {
         if (groups) return groups;
         const size_t pop = population(), n_cu = (size_t)ctx->n_cu;
-        return (2 * pop > 7 * n_cu && pop <= 6 * n_cu) ? 3 : 4;
+        const size_t want = (2 * pop > 7 * n_cu && pop <= 6 * n_cu) ? 3 : 4;
+        if (want == groups_cur) {
+            groups_other_since = {};
+            return groups_cur;
+        }
+        const auto now = std::chrono::steady_clock::now();
+        if (groups_other_since == std::chrono::steady_clock::time_point{}) groups_other_since = now;
+        else if (now - groups_other_since > std::chrono::milliseconds(50)) {
+            groups_cur = want;
+            groups_other_since = {};
+        }
+        return groups_cur;
     }
     // ciphertexts per workgroup the bootstrap of a batch should use at least: the shape the whole population would get in one
     // launch, so that the resident batches tile the CUs (one batch of a quarter of 1 024 callers takes 64 CUs, not 256)

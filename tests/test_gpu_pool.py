@@ -406,3 +406,20 @@ def test_pool_every_exec_op_kind_against_the_oracle(rig):
             exp = O.cmux(ga[i, j], gb[i, j], ggsw[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)
             assert np.array_equal(out_gc[i].reshape(P.cbs_count, P.glwe_len)[j], exp), (i, j)
         assert np.array_equal(out_ss[i].view(np.float64), O.scheme_switch_fft(ga[i], ssk, P).view(np.float64)), i
+
+
+def test_pool_reports_how_many_streams_run_side_by_side(rig):
+    """spf_pool_create measures whether its streams really run concurrently (a host that touched HIP
+    before the library was loaded keeps 4 hardware queues and the resident batches take turns) and says so: the counter is
+    filled, and with the library's own GPU_MAX_HW_QUEUES=24 in effect most of the sixteen streams overlap."""
+    ks, eng = rig
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=100)
+    try:
+        c = pool.counters()
+        assert c["staging_sets"] == 16
+        assert 8 <= c["stream_concurrency"] <= 16, c
+        assert b"WARNING" not in (eng._lib.spf_last_error(eng._h) or b"")
+    finally:
+        pool.close()
+    v = eng._lib.spf_version().decode()
+    assert v.startswith("spf_hip 0.6 gfx950 (blind rotation: BR_OPT=") and "ABLATION" not in v
