@@ -471,6 +471,16 @@ def main() -> int:
         "counters": live, "stored_profile": stored, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 3),
         "kernel_ms_min_max_over_ranks": [round(x, 3) for x in kernel_ms_minmax], "launches": launches,
         "flop_per_unit": FLOP_PER_PBS, "units_per_launch": B,
+        # what the kernel's own instruction mix allows: of the 2 112 f64 instructions a wave issues per CMUX step 1 700 are
+        # v_add_f64 / v_mul_f64 (one flop per lane-slot) and 412 v_fma_f64 (two): 12.0 of the 16 lane-results per cycle the
+        # FMA roof counts (profiles/r05_mfma_valu_coexec.md) -> a cap of 0.375 on the nominal flop count at full issue, 0.45
+        # counting the executed flops; `frac` stands beside it
+        "mix_cap": {"frac_low": 0.375, "frac_high": 0.45, "frac_of_cap": [round(achieved_tflops / FP64_PEAK_TFLOPS / 0.45, 3),
+                                                                         round(achieved_tflops / FP64_PEAK_TFLOPS / 0.375, 3)],
+                    "note": "ceiling of the transform DAG's add / multiply mix on the FMA roof (1 700 of 2 112 f64 instructions per "
+                            "wave-step are one-flop adds or multiplies); r06 microbenchmark: an FMA-folded radix-8 (DAG-II) runs the "
+                            "pair's arithmetic 19 % faster (profiles/r06_experiments_blind_rotate.md) — not built: oracle, every "
+                            "transform variant and the golden files would have to move together"},
         "note": "the f64 butterflies and MADs run on the VALU (v_fma_f64 / v_add_f64 / v_mul_f64, zero MFMA instructions); "
                 "MI355X dense FP64 peak is 78.6 TFLOP/s for VALU and MFMA alike; issue_bound_frac = share of the kernel's "
                 "time the VALU is issuing (SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles of the profiled dispatch, GRBM_GUI_ACTIVE / 8); "

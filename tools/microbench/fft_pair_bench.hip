@@ -51,6 +51,68 @@ __device__ __forceinline__ void pair_arith_only(c64 (&A)[8], c64 (&B)[8], const 
     sched_fence();
 }
 
+// r06, the gate of "DAG-II" (VERDICT r05 task 3 ii): the FMA-folded radix-8 — the previous pass's twiddles applied at the INPUT of
+// the first butterfly stage (t = w a; s = t + w' b as two FMAs per component; d = 2 t - s as one), and the W8 rotations' 1/sqrt(2)
+// folded into the last stage's additions (v = b0 +- c q as FMAs).  Timing only (the twiddle each lane would need after the
+// exchange is taken from the same table rows): 72 f64 instructions per twiddled radix-8 instead of 84, 52 instead of 56 untwiddled.
+template <int DIR> __device__ __forceinline__ void radix8_folded(c64 (&v)[8], const c64* w /* 7 input twiddles, or null */)
+{
+    c64 s[4], t[4];
+    if (w) {
+        // pair (0, 4): only v4 carries a twiddle
+        s[0].re = __builtin_fma(-v[4].im, w[3].im, __builtin_fma(v[4].re, w[3].re, v[0].re));
+        s[0].im = __builtin_fma(v[4].im, w[3].re, __builtin_fma(v[4].re, w[3].im, v[0].im));
+        t[0].re = __builtin_fma(2.0, v[0].re, -s[0].re);
+        t[0].im = __builtin_fma(2.0, v[0].im, -s[0].im);
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            const c64 a = cmul_tw<DIR>(v[j], w[j - 1]);
+            s[j].re = __builtin_fma(-v[j + 4].im, w[j + 3].im, __builtin_fma(v[j + 4].re, w[j + 3].re, a.re));
+            s[j].im = __builtin_fma(v[j + 4].im, w[j + 3].re, __builtin_fma(v[j + 4].re, w[j + 3].im, a.im));
+            t[j].re = __builtin_fma(2.0, a.re, -s[j].re);
+            t[j].im = __builtin_fma(2.0, a.im, -s[j].im);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s[j] = cadd(v[j], v[j + 4]); t[j] = csub(v[j], v[j + 4]); }
+    }
+    // the W8 rotations without their 1/sqrt(2): q = the unscaled sum / difference of the two rotated terms
+    const double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re, p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
+    const c64 qb = {p1 + m3, m1 - p3}, qe = {p1 - m3, m1 + p3};
+    c64 a0 = cadd(s[0], s[2]), a1 = cadd(s[1], s[3]), a2 = csub(s[0], s[2]), d = csub(s[1], s[3]);
+    v[0] = cadd(a0, a1);
+    v[4] = csub(a0, a1);
+    v[2] = {a2.re + d.im, a2.im - d.re};
+    v[6] = {a2.re - d.im, a2.im + d.re};
+    const c64 b0 = {t[0].re + t[2].im, t[0].im - t[2].re}, b2 = {t[0].re - t[2].im, t[0].im + t[2].re};
+    v[1] = {__builtin_fma(kSqrtHalf, qb.re, b0.re), __builtin_fma(kSqrtHalf, qb.im, b0.im)};
+    v[5] = {__builtin_fma(-kSqrtHalf, qb.re, b0.re), __builtin_fma(-kSqrtHalf, qb.im, b0.im)};
+    v[3] = {__builtin_fma(kSqrtHalf, qe.im, b2.re), __builtin_fma(-kSqrtHalf, qe.re, b2.im)};
+    v[7] = {__builtin_fma(-kSqrtHalf, qe.im, b2.re), __builtin_fma(kSqrtHalf, qe.re, b2.im)};
+}
+
+template <int DIR>
+__device__ __forceinline__ void pair_arith_only_folded(c64 (&A)[8], c64 (&B)[8], const c64* tab, int lane)
+{
+    const int hi3 = lane >> 3;
+    c64 w[7];
+    radix8_folded<DIR>(A, nullptr);
+    sched_fence();
+    radix8_folded<DIR>(B, nullptr);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 7; k++) w[k] = tab[kT1Off + k * 64 + lane];
+    radix8_folded<DIR>(A, w);
+    sched_fence();
+    radix8_folded<DIR>(B, w);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 7; k++) w[k] = tab[kT2Off + k * 8 + hi3];
+    radix8_folded<DIR>(A, w);
+    radix8_folded<DIR>(B, w);
+    sched_fence();
+}
+
 // the LDS traffic of fft512_pair1<., 2> without the butterflies
 __device__ __forceinline__ void pair_lds_only(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane)
 {
@@ -134,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned 
         else if constexpr (V == 2) fft512_pair1<+1, 1>(A, B, buf, tab, lane);
         else if constexpr (V == 3) pair_arith_only<+1>(A, B, tab, lane);
         else if constexpr (V == 4) pair_lds_only(A, B, buf, tab, lane);
+        else if constexpr (V == 13) pair_arith_only_folded<+1>(A, B, tab, lane);
         else if constexpr (V == 5) fft512_pair1s<+1>(A, B, buf, tab, lane);
         else if constexpr (V == 6) fft512_pair1e<+1, 2>(A, B, buf, tab, lane);
         else if constexpr (V == 7) fft512_pair1e<+1, 1>(A, B, buf, tab, lane);
@@ -246,6 +309,8 @@ int main(int argc, char** argv)
     run<2, 1>("2 fft512_pair1<+1,1> exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
     run<3, 0>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
     run<3, 1>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
+    run<13, 0>("13 arithmetic only, FMA-folded radix-8 (DAG-II gate)", d_tab, d_out, n_cu, iters);
+    run<13, 1>("13 arithmetic only, FMA-folded radix-8 (DAG-II gate)", d_tab, d_out, n_cu, iters);
     run<4, 0>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
     run<4, 1>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
     run<5, 0>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
