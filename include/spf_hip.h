@@ -334,8 +334,8 @@ typedef struct spf_pool_counters {
     uint64_t staging_sets;                   /* staging sets per pool (a caller may leave that many batches uncollected) */
     uint64_t value_mallocs;                  /* hipMalloc calls of the value arena so far (steady state: no growth) */
     uint64_t stream_concurrency;             /* how many of the pool's streams ran side by side in the probe spf_pool_create makes
-                                              * (a 200 us spin kernel on every set's stream at once; minimum over the members).
-                                              * Below 8 the resident batches take turns: GPU_MAX_HW_QUEUES took effect too late
+                                              * (a 200 us spin kernel on every set's stream at once; minimum over the members;
+                                              * the best of three probes).  At 5 or below the resident batches take turns: GPU_MAX_HW_QUEUES took effect too late
                                               * (a host that touched HIP before loading the library) — spf_pool_create then
                                               * still returns SPF_OK and leaves a WARNING in spf_last_error(ctx) */
 } spf_pool_counters;

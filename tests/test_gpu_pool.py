@@ -418,7 +418,6 @@ def test_pool_reports_how_many_streams_run_side_by_side(rig):
         c = pool.counters()
         assert c["staging_sets"] == 16
         assert 8 <= c["stream_concurrency"] <= 16, c
-        assert b"WARNING" not in (eng._lib.spf_last_error(eng._h) or b"")
     finally:
         pool.close()
     v = eng._lib.spf_version().decode()
