@@ -9,6 +9,7 @@
 // build's definition, so results are reproducible bit for bit.  Compile with
 // -ffp-contract=off: the only fused operations are the explicit __builtin_fma calls.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -74,49 +75,132 @@ template <int DIR> __device__ __forceinline__ c64 cmul_tw(c64 a, c64 w)
 
 constexpr double kSqrtHalf = 0.70710678118654752440; // 0x3FE6A09E667F3BCD
 
-// 8-point DFT, decimation in frequency, in place.  DIR=+1: e^{-2 pi i jk/8}, DIR=-1: conjugate.
-template <int DIR> __device__ __forceinline__ void radix8(c64 (&v)[8])
+// ---- the canonical transform, DAG-II (r06; the CPU checker restates it operation for operation) ---------------
+// DAG-I (r01-r05) issued 2 112 f64 instructions per wave and blind-rotation step of which 1 700 were one-flop adds or multiplies:
+// the instruction mix alone capped the kernel at 0.375-0.45 of the FMA roof.  DAG-II is the same 8 x 8 x 8 transform re-associated:
+//   * the twiddle factors between the passes enter at the INPUT of the next pass's first butterfly stage
+//       a = w_j v_j;   s = a + w_{j+4} v_{j+4}  (two FMAs per component);   t = 2 a - s  (one FMA per component)
+//     — the pass-1 factor W512^{(8a+b) k1} = W64^{a k1} W512^{b k1}: the first part is pass 2's input factor (table T2, indexed by
+//     the lane's LOW three bits = k1), the second is common to the eight operands of a pass-2 butterfly, commutes with it and joins
+//     pass 2's own W64^{b c} as pass 3's input factor W512^{b (k1 + 8c)} = W512^{b lane} (table T1, as before);
+//   * the 1/sqrt(2) of the two W8 rotations multiplies their sum / difference in the last stage (v = b0 +- c q as FMAs).
+// 52 f64 instructions per radix-8 without input factors (was 56), 72 with (was 84): 196 per 512-point transform (was 224), and
+// the seven twiddle products that used to trail every pass are gone (tools/microbench/fft_pair_bench.hip: the pair's arithmetic
+// 4 728 -> 3 812 cycles).  Same tables, same exchange images.
+
+// acc + a * w (DIR > 0) or acc + a * conj(w) (DIR < 0): two fused multiply-adds per component
+template <int DIR> __device__ __forceinline__ c64 cfma_tw(c64 acc, c64 a, c64 w)
 {
-    c64 s0 = cadd(v[0], v[4]), s1 = cadd(v[1], v[5]), s2 = cadd(v[2], v[6]), s3 = cadd(v[3], v[7]);
-    c64 t0 = csub(v[0], v[4]), t1 = csub(v[1], v[5]), t2 = csub(v[2], v[6]), t3 = csub(v[3], v[7]);
-    c64 t1w, t3w;
+    c64 o;
     if (DIR > 0) {
-        double p1 = t1.re + t1.im, m1 = t1.im - t1.re;
-        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
-        double p3 = t3.re + t3.im, m3 = t3.im - t3.re;
-        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
+        o.re = __builtin_fma(-a.im, w.im, __builtin_fma(a.re, w.re, acc.re));
+        o.im = __builtin_fma(a.im, w.re, __builtin_fma(a.re, w.im, acc.im));
     } else {
-        double p1 = t1.re + t1.im, m1 = t1.re - t1.im;
-        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
-        double p3 = t3.re + t3.im, m3 = t3.re - t3.im;
-        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
+        o.re = __builtin_fma(a.im, w.im, __builtin_fma(a.re, w.re, acc.re));
+        o.im = __builtin_fma(a.im, w.re, __builtin_fma(-a.re, w.im, acc.im));
     }
-    c64 a0 = cadd(s0, s2), a1 = cadd(s1, s3), a2 = csub(s0, s2), d = csub(s1, s3);
-    v[0] = cadd(a0, a1);
-    v[4] = csub(a0, a1);
-    c64 b0, b2;
-    if (DIR > 0) {
-        v[2] = {a2.re + d.im, a2.im - d.re};
-        v[6] = {a2.re - d.im, a2.im + d.re};
-        b0 = {t0.re + t2.im, t0.im - t2.re};
-        b2 = {t0.re - t2.im, t0.im + t2.re};
-    } else {
-        v[2] = {a2.re - d.im, a2.im + d.re};
-        v[6] = {a2.re + d.im, a2.im - d.re};
-        b0 = {t0.re - t2.im, t0.im + t2.re};
-        b2 = {t0.re + t2.im, t0.im - t2.re};
-    }
-    c64 b1 = cadd(t1w, t3w), e = csub(t1w, t3w);
-    v[1] = cadd(b0, b1);
-    v[5] = csub(b0, b1);
-    if (DIR > 0) {
-        v[3] = {b2.re + e.im, b2.im - e.re};
-        v[7] = {b2.re - e.im, b2.im + e.re};
-    } else {
-        v[3] = {b2.re - e.im, b2.im + e.re};
-        v[7] = {b2.re + e.im, b2.im - e.re};
+    return o;
+}
+__device__ __forceinline__ c64 twice_minus(c64 a, c64 s) // 2 a - s
+{
+    return {__builtin_fma(2.0, a.re, -s.re), __builtin_fma(2.0, a.im, -s.im)};
+}
+
+// the three stages of the 8-point DFT (decimation in frequency; DIR=+1: e^{-2 pi i jk/8}, DIR=-1: conjugate), cut apart so that
+// callers can issue LDS operations between them.  s / t: sums and differences of operands (j, j + 4); u: second-stage values,
+// u[6] / u[7] the W8-rotated pair's sum / difference WITHOUT its 1/sqrt(2).
+template <int DIR> __device__ __forceinline__ void radix8_stage1(const c64 (&v)[8], c64 (&s)[4], c64 (&t)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = cadd(v[i], v[i + 4]); t[i] = csub(v[i], v[i + 4]); }
+}
+// ... with the input factors of operands 1..7: tw(k) = the factor of operand k + 1 (operand 0 has none)
+#ifndef SPF_STAGE1_FENCE
+#define SPF_STAGE1_FENCE 0
+#endif
+template <int DIR, class TW> __device__ __forceinline__ void radix8_stage1_in(const c64 (&v)[8], TW tw, c64 (&s)[4], c64 (&t)[4])
+{
+    s[0] = cfma_tw<DIR>(v[0], v[4], tw(3));
+    t[0] = twice_minus(v[0], s[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+        if constexpr (SPF_STAGE1_FENCE) __builtin_amdgcn_sched_barrier(0); // (keeps the factor reads of the later pairs behind this one: registers)
+        const c64 a = cmul_tw<DIR>(v[j], tw(j - 1));
+        s[j] = cfma_tw<DIR>(a, v[j + 4], tw(j + 3));
+        t[j] = twice_minus(a, s[j]);
     }
 }
+template <int DIR> __device__ __forceinline__ void radix8_stage2(const c64 (&s)[4], const c64 (&t)[4], c64 (&u)[8])
+{
+    if (DIR > 0) {
+        const double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;
+        const double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
+        u[6] = {p1 + m3, m1 - p3};
+        u[7] = {p1 - m3, m1 + p3};
+    } else {
+        const double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;
+        const double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;
+        u[6] = {m1 - p3, p1 + m3};
+        u[7] = {m1 + p3, p1 - m3};
+    }
+    u[0] = cadd(s[0], s[2]); u[1] = cadd(s[1], s[3]); u[2] = csub(s[0], s[2]); u[3] = csub(s[1], s[3]);
+    if (DIR > 0) {
+        u[4] = {t[0].re + t[2].im, t[0].im - t[2].re};
+        u[5] = {t[0].re - t[2].im, t[0].im + t[2].re};
+    } else {
+        u[4] = {t[0].re - t[2].im, t[0].im + t[2].re};
+        u[5] = {t[0].re + t[2].im, t[0].im - t[2].re};
+    }
+}
+template <int DIR> __device__ __forceinline__ void radix8_stage3(c64 (&v)[8], const c64 (&u)[8])
+{
+    constexpr double c = kSqrtHalf;
+    v[0] = cadd(u[0], u[1]);
+    v[4] = csub(u[0], u[1]);
+    if (DIR > 0) {
+        v[2] = {u[2].re + u[3].im, u[2].im - u[3].re};
+        v[6] = {u[2].re - u[3].im, u[2].im + u[3].re};
+    } else {
+        v[2] = {u[2].re - u[3].im, u[2].im + u[3].re};
+        v[6] = {u[2].re + u[3].im, u[2].im - u[3].re};
+    }
+    v[1] = {__builtin_fma(c, u[6].re, u[4].re), __builtin_fma(c, u[6].im, u[4].im)};
+    v[5] = {__builtin_fma(-c, u[6].re, u[4].re), __builtin_fma(-c, u[6].im, u[4].im)};
+    if (DIR > 0) {
+        v[3] = {__builtin_fma(c, u[7].im, u[5].re), __builtin_fma(-c, u[7].re, u[5].im)};
+        v[7] = {__builtin_fma(-c, u[7].im, u[5].re), __builtin_fma(c, u[7].re, u[5].im)};
+    } else {
+        v[3] = {__builtin_fma(-c, u[7].im, u[5].re), __builtin_fma(c, u[7].re, u[5].im)};
+        v[7] = {__builtin_fma(c, u[7].im, u[5].re), __builtin_fma(-c, u[7].re, u[5].im)};
+    }
+}
+
+// 8-point DFT in place, no input factors (pass 1)
+template <int DIR> __device__ __forceinline__ void radix8(c64 (&v)[8])
+{
+    c64 s[4], t[4], u[8];
+    radix8_stage1<DIR>(v, s, t);
+    radix8_stage2<DIR>(s, t, u);
+    radix8_stage3<DIR>(v, u);
+}
+// 8-point DFT in place with the input factors tw(0..6) of operands 1..7 (passes 2 and 3)
+template <int DIR, class TW> __device__ __forceinline__ void radix8_in(c64 (&v)[8], TW tw)
+{
+    c64 s[4], t[4], u[8];
+    radix8_stage1_in<DIR>(v, tw, s, t);
+    radix8_stage2<DIR>(s, t, u);
+    radix8_stage3<DIR>(v, u);
+}
+// the factors of a pass as table reads (entry k at base[stride * k]) or as a register array fetched earlier
+struct tw_table {
+    const c64* base;
+    int stride;
+    __device__ __forceinline__ c64 operator()(int k) const { return base[stride * k]; }
+};
+struct tw_regs {
+    const c64 (&w)[7];
+    __device__ __forceinline__ c64 operator()(int k) const { return w[k]; }
+};
 
 // ---- LDS image of the twiddle tables (one copy per workgroup), in 16-byte complex entries.
 //   T1[k1-1][lane]   = W512^{lane*k1}, k1 = 1..7          (7*64 entries)
@@ -164,40 +248,49 @@ __device__ __forceinline__ void fft512_single(c64 (&V)[8], char* buf, const c64*
 {
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
-    {
-        c64 tw[PRE > 0 ? PRE : 1];
-#pragma unroll
-        for (int k = 0; k < PRE; k++) tw[k] = tab[kT1Off + k * 64 + lane];
-        if constexpr (PRE > 0) compiler_fence();
-        radix8<DIR>(V);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++)
-            V[k1] = cmul_tw<DIR>(V[k1], (k1 - 1 < PRE) ? tw[k1 - 1 < PRE ? k1 - 1 : 0] : tab[kT1Off + (k1 - 1) * 64 + lane]);
-    }
+    // pass 1 (no input factors), exchange 1
+    radix8<DIR>(V);
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++)
         *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = V[k1];
     wave_lds_fence();
     {
-        c64 tw[PRE > 0 ? PRE : 1];
+        // pass 2: operand a enters with W64^{a k1}, k1 = the lane's low three bits after the exchange
+        c64 tw[7];
+        if constexpr (PRE > 0) {
 #pragma unroll
-        for (int k = 0; k < PRE; k++) tw[k] = tab[kT2Off + k * 8 + hi3];
+            for (int k = 0; k < 7; k++) tw[k] = tab[kT2Off + k * 8 + lo3];
+        }
 #pragma unroll
         for (int a = 0; a < 8; a++) V[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
-        if constexpr (PRE > 0) compiler_fence();
-        radix8<DIR>(V);
-#pragma unroll
-        for (int c = 1; c < 8; c++)
-            V[c] = cmul_tw<DIR>(V[c], (c - 1 < PRE) ? tw[c - 1 < PRE ? c - 1 : 0] : tab[kT2Off + (c - 1) * 8 + hi3]);
+        if constexpr (PRE > 0) {
+            compiler_fence();
+            radix8_in<DIR>(V, tw_regs{tw});
+        } else {
+            radix8_in<DIR>(V, tw_table{tab + kT2Off + lo3, 8});
+        }
     }
     compiler_fence();
 #pragma unroll
     for (int c = 0; c < 8; c++)
         *reinterpret_cast<c64*>(buf + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = V[c];
     wave_lds_fence();
+    {
+        // pass 3: operand b enters with W512^{b lane}
+        c64 tw[7];
+        if constexpr (PRE > 0) {
 #pragma unroll
-    for (int b = 0; b < 8; b++) V[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
-    radix8<DIR>(V);
+            for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) V[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd);
+        if constexpr (PRE > 0) {
+            compiler_fence();
+            radix8_in<DIR>(V, tw_regs{tw});
+        } else {
+            radix8_in<DIR>(V, tw_table{tab + kT1Off + lane, 64});
+        }
+    }
     compiler_fence();
 }
 
@@ -222,44 +315,31 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
     // pass 1 + exchange-1 writes: writer lane = 8a + b holds reg k1 -> slot 64a + 8k1 + (b ^ k1)
-    {
-        c64 tw[7];
+    radix8<DIR>(E);
 #pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) tw[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
-        radix8<DIR>(E);
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = E[k1];
+    radix8<DIR>(O);
 #pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) E[k1] = cmul_tw<DIR>(E[k1], tw[k1 - 1]);
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++)
-            *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = E[k1];
-        radix8<DIR>(O);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) O[k1] = cmul_tw<DIR>(O[k1], tw[k1 - 1]);
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++)
-            *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = O[k1];
-    }
+    for (int k1 = 0; k1 < 8; k1++)
+        *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = O[k1];
     wave_lds_fence();
     // exchange-1 reads: reader lane = 8b + k1 wants reg a <- slot 64a + 8k1 + (b ^ k1)
 #pragma unroll
     for (int a = 0; a < 8; a++) E[a] = *reinterpret_cast<const c64*>(bufE + 1024 * a + rd);
 #pragma unroll
     for (int a = 0; a < 8; a++) O[a] = *reinterpret_cast<const c64*>(bufO + 1024 * a + rd);
-    // pass 2 + exchange-2 writes: writer lane = 8b + k1 holds reg c -> slot 64b + 8k1 + (c ^ k1)
+    // pass 2 (input factors W64^{a k1}, k1 = lo3) + exchange-2 writes: writer lane = 8b + k1 holds reg c -> slot 64b + 8k1 + (c ^ k1)
     {
         c64 tw[7];
 #pragma unroll
-        for (int c = 1; c < 8; c++) tw[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT2Off + k * 8 + lo3];
         compiler_fence();
-        radix8<DIR>(E);
-#pragma unroll
-        for (int c = 1; c < 8; c++) E[c] = cmul_tw<DIR>(E[c], tw[c - 1]);
+        radix8_in<DIR>(E, tw_regs{tw});
 #pragma unroll
         for (int c = 0; c < 8; c++)
             *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
-        radix8<DIR>(O);
-#pragma unroll
-        for (int c = 1; c < 8; c++) O[c] = cmul_tw<DIR>(O[c], tw[c - 1]);
+        radix8_in<DIR>(O, tw_regs{tw});
 #pragma unroll
         for (int c = 0; c < 8; c++)
             *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
@@ -270,9 +350,14 @@ __device__ __forceinline__ void fft512_pair(c64 (&E)[8], c64 (&O)[8], char* bufE
     for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
 #pragma unroll
     for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
-    // pass 3
-    radix8<DIR>(E);
-    radix8<DIR>(O);
+    // pass 3 (input factors W512^{b lane})
+    {
+        c64 tw[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+        radix8_in<DIR>(E, tw_regs{tw});
+        radix8_in<DIR>(O, tw_regs{tw});
+    }
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 
@@ -351,17 +436,15 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
 {
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int rd = 16 * (8 * lo3 + (hi3 ^ lo3));
-    c64 tw1[7], tw2[7];
+    c64 tw2[7], tw3[7]; // the input factors of pass 2 (W64^{a k1}, k1 = lo3) and of pass 3 (W512^{b lane})
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) tw1[k1 - 1] = tab[kT1Off + (k1 - 1) * 64 + lane];
+    for (int k = 0; k < 7; k++) tw2[k] = tab[kT2Off + k * 8 + lo3];
 #pragma unroll
-    for (int c = 1; c < 8; c++) tw2[c - 1] = tab[kT2Off + (c - 1) * 8 + hi3];
+    for (int k = 0; k < 7; k++) tw3[k] = tab[kT1Off + k * 64 + lane];
     compiler_fence(); // all fourteen requested HERE (r04: without the fence hipcc sank them to their uses, two at a time, each
                       // waited for on the spot — at one wave per SIMD every such round trip is lost time)
     // E pass 1 -> exchange-1 image
     radix8<DIR>(E);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) E[k1] = cmul_tw<DIR>(E[k1], tw1[k1 - 1]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++)
         *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = E[k1];
@@ -372,8 +455,6 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     compiler_fence();
     radix8<DIR>(O);
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) O[k1] = cmul_tw<DIR>(O[k1], tw1[k1 - 1]);
-#pragma unroll
     for (int k1 = 0; k1 < 8; k1++)
         *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * k1 + (lo3 ^ k1))) = O[k1];
     compiler_fence();
@@ -381,9 +462,7 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     for (int a = 0; a < 8; a++) O[a] = *reinterpret_cast<const c64*>(bufO + 1024 * a + rd);
     compiler_fence();
     // E pass 2 (O's reads in flight) -> exchange-2 image
-    radix8<DIR>(E);
-#pragma unroll
-    for (int c = 1; c < 8; c++) E[c] = cmul_tw<DIR>(E[c], tw2[c - 1]);
+    radix8_in<DIR>(E, tw_regs{tw2});
 #pragma unroll
     for (int c = 0; c < 8; c++)
         *reinterpret_cast<c64*>(bufE + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = E[c];
@@ -392,9 +471,7 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     for (int b = 0; b < 8; b++) E[b] = *reinterpret_cast<const c64*>(bufE + 1024 * b + rd);
     compiler_fence();
     // O pass 2 (E's reads in flight)
-    radix8<DIR>(O);
-#pragma unroll
-    for (int c = 1; c < 8; c++) O[c] = cmul_tw<DIR>(O[c], tw2[c - 1]);
+    radix8_in<DIR>(O, tw_regs{tw2});
 #pragma unroll
     for (int c = 0; c < 8; c++)
         *reinterpret_cast<c64*>(bufO + 16 * (64 * hi3 + 8 * lo3 + (c ^ lo3))) = O[c];
@@ -403,8 +480,8 @@ __device__ __forceinline__ void fft512_pair_pipelined(c64 (&E)[8], c64 (&O)[8], 
     for (int b = 0; b < 8; b++) O[b] = *reinterpret_cast<const c64*>(bufO + 1024 * b + rd);
     compiler_fence();
     // pass 3
-    radix8<DIR>(E);
-    radix8<DIR>(O);
+    radix8_in<DIR>(E, tw_regs{tw3});
+    radix8_in<DIR>(O, tw_regs{tw3});
     compiler_fence(); // the tile's next writer stays behind these reads
 }
 
@@ -439,16 +516,14 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     char* wr[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
+    const tw_table t2{tab + kT2Off + lo3, 8};   // pass 2: W64^{a k1}, k1 = lo3
+    const tw_table t3{tab + kT1Off + lane, 64}; // pass 3: W512^{b lane}
     // pass 1
     radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
     sched_fence();
     radix8<DIR>(B);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
     sched_fence();
 #pragma unroll
     for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
@@ -457,9 +532,7 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
     sched_fence();
     // pass 2 of A; B's exchange-1 reads travel under it
-    radix8<DIR>(A);
-#pragma unroll
-    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    radix8_in<DIR>(A, t2);
     sched_fence();
     mid();
 #pragma unroll
@@ -467,15 +540,13 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     sched_fence();
     if constexpr (XA) {
         lane_transpose_hi3(A);
-        radix8<DIR>(A); // pass 3 of A
+        radix8_in<DIR>(A, t3); // pass 3 of A
     } else {
 #pragma unroll
         for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
     }
     sched_fence();
-    radix8<DIR>(B);
-#pragma unroll
-    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
+    radix8_in<DIR>(B, t2);
     sched_fence();
     if constexpr (!XA) {
 #pragma unroll
@@ -484,18 +555,18 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
     }
     if constexpr (XB) {
         lane_transpose_hi3(B);
-        if constexpr (!XA) radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
-        radix8<DIR>(B);
+        if constexpr (!XA) radix8_in<DIR>(A, t3); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
+        radix8_in<DIR>(B, t3);
     } else {
 #pragma unroll
         for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = B[c];
         sched_fence();
         // pass 3
-        radix8<DIR>(A);
+        radix8_in<DIR>(A, t3);
         sched_fence();
 #pragma unroll
         for (int b = 0; b < 8; b++) B[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
-        radix8<DIR>(B);
+        radix8_in<DIR>(B, t3);
     }
     sched_fence(); // the image's next writer stays behind these reads
 }
@@ -504,218 +575,105 @@ __device__ __forceinline__ void fft512_pair1(c64 (&A)[8], c64 (&B)[8], char* buf
 // tools/microbench/fft_pair_bench.hip (r04): eight waves per CU running transform pairs in lockstep need 7.9 k cycles per pair,
 // the butterflies alone 4.7 k and the LDS traffic alone 4.2 k — the two hardly overlap, because each exchange leaves the wave as
 // a burst of eight `ds_write_b128` (13 cycles of the CU's store path each, all eight waves bursting at once) and the other
-// transform's table reads queue behind it.  Here the eight stores of one transform are issued two at a time between the
-// three butterfly stages and the twiddle products of the OTHER transform (7.4 k cycles per pair in the same probe).  radix8 is
-// cut into its three stages for that; the operations and their order per value are those of `radix8`: same words.
-template <int DIR> __device__ __forceinline__ void radix8_stage1(const c64 (&v)[8], c64 (&s)[4], c64 (&t)[4])
-{
-#pragma unroll
-    for (int i = 0; i < 4; i++) { s[i] = cadd(v[i], v[i + 4]); t[i] = csub(v[i], v[i + 4]); }
-}
-template <int DIR> __device__ __forceinline__ void radix8_stage2(const c64 (&s)[4], const c64 (&t)[4], c64 (&u)[8])
-{
-    c64 t1w, t3w;
-    if (DIR > 0) {
-        double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;
-        t1w.re = p1 * kSqrtHalf; t1w.im = m1 * kSqrtHalf;
-        double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;
-        t3w.re = m3 * kSqrtHalf; t3w.im = -(p3 * kSqrtHalf);
-    } else {
-        double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;
-        t1w.re = m1 * kSqrtHalf; t1w.im = p1 * kSqrtHalf;
-        double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;
-        t3w.re = -(p3 * kSqrtHalf); t3w.im = m3 * kSqrtHalf;
-    }
-    u[0] = cadd(s[0], s[2]); u[1] = cadd(s[1], s[3]); u[2] = csub(s[0], s[2]); u[3] = csub(s[1], s[3]);
-    if (DIR > 0) {
-        u[4] = {t[0].re + t[2].im, t[0].im - t[2].re};
-        u[5] = {t[0].re - t[2].im, t[0].im + t[2].re};
-    } else {
-        u[4] = {t[0].re - t[2].im, t[0].im + t[2].re};
-        u[5] = {t[0].re + t[2].im, t[0].im - t[2].re};
-    }
-    u[6] = cadd(t1w, t3w); u[7] = csub(t1w, t3w);
-}
-template <int DIR> __device__ __forceinline__ void radix8_stage3(c64 (&v)[8], const c64 (&u)[8])
-{
-    v[0] = cadd(u[0], u[1]);
-    v[4] = csub(u[0], u[1]);
-    if (DIR > 0) {
-        v[2] = {u[2].re + u[3].im, u[2].im - u[3].re};
-        v[6] = {u[2].re - u[3].im, u[2].im + u[3].re};
-    } else {
-        v[2] = {u[2].re - u[3].im, u[2].im + u[3].re};
-        v[6] = {u[2].re + u[3].im, u[2].im - u[3].re};
-    }
-    v[1] = cadd(u[4], u[6]);
-    v[5] = csub(u[4], u[6]);
-    if (DIR > 0) {
-        v[3] = {u[5].re + u[7].im, u[5].im - u[7].re};
-        v[7] = {u[5].re - u[7].im, u[5].im + u[7].re};
-    } else {
-        v[3] = {u[5].re - u[7].im, u[5].im + u[7].re};
-        v[7] = {u[5].re + u[7].im, u[5].im - u[7].re};
-    }
-}
-// radix-8 of X, then its seven twiddle products (table entries tw_base[stride * (k - 1)]), with the eight LDS operations
-// op(0) .. op(7) of the caller issued two at a time between the stages
-template <int DIR, class OP>
-__device__ __forceinline__ void radix8_tw_spread(c64 (&X)[8], const c64* tw_base, int stride, OP op)
+// transform's table reads queue behind it.  The spread forms issue the eight stores of one transform between the three
+// butterfly stages of the OTHER transform; the operations and their order per value are those of `radix8` / `radix8_in`: same
+// words.  (r04-r05 also carried fft512_pair1s / pair1e / pair1te — spread stores with per-transform table reads, early reads —
+// measured slower than the forms below and removed with DAG-I.)
+
+// radix-8 of X (with the input factors tw, or without: TW = tw_none) with the eight LDS stores op(0) .. op(7) of the caller spread
+// through it and `after()` — the reads of the transform just stored — issued behind the last store.  SPF_SPREAD: where the stores
+// go — 0: three behind stage 1, three behind stage 2, two behind stage 3; 1: one behind each operand pair of stage 1 (ten f64
+// instructions apart: the CU's store path takes ~13 cycles per ds_write_b128), two behind stage 2, two behind stage 3;
+// 2: two behind the second and the fourth pair of stage 1, two behind stage 2, two behind stage 3
+#ifndef SPF_SPREAD
+#define SPF_SPREAD 1
+#endif
+struct tw_none {};
+template <int DIR, class TW, class OP, class AFTER>
+__device__ __forceinline__ void radix8_any_spread(c64 (&X)[8], TW tw, OP op, AFTER after)
 {
     c64 s[4], t[4], u[8];
-    radix8_stage1<DIR>(X, s, t);
-    sched_fence();
-    op(0); op(1);
-    sched_fence();
-    radix8_stage2<DIR>(s, t, u);
-    sched_fence();
-    op(2); op(3);
-    sched_fence();
-    radix8_stage3<DIR>(X, u);
-    sched_fence();
-    op(4); op(5);
-    sched_fence();
-#pragma unroll
-    for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
-    sched_fence();
-    op(6); op(7);
-    sched_fence();
-#pragma unroll
-    for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw_base[stride * (k - 1)]);
-    sched_fence();
-}
-template <int DIR, int XP = 2, class MID = no_hook>
-__device__ __forceinline__ void fft512_pair1s(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
-{
-    static_assert(XP == 1 || XP == 2, "exchange 2 of B (XP = 2) or of both transforms (XP = 1) in registers");
-    constexpr bool XA = XP == 1;
-    const int hi3 = lane >> 3, lo3 = lane & 7;
-    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
-    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
-    const uint32_t wbase = 16 * (64 * hi3 + lo3);
-    char* wr[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
-    const c64* t1 = tab + kT1Off + lane;
-    const c64* t2 = tab + kT2Off + hi3;
-    // pass 1 of A
-    radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], t1[64 * (k1 - 1)]);
-    sched_fence();
-    // pass 1 of B, A's exchange-1 stores spread through it
-    radix8_tw_spread<DIR>(B, t1, 64, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
-    // A's exchange-1 reads (ahead of B's stores to the same image: a wave's DS instructions execute in issue order), then
-    // pass 2 of A with B's exchange-1 stores spread through it
-#pragma unroll
-    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    radix8_tw_spread<DIR>(A, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = B[k]; });
-    mid();
-#pragma unroll
-    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    if constexpr (XA) {
-        lane_transpose_hi3(A);
-        radix8<DIR>(A); // pass 3 of A
+    constexpr bool IN = !std::is_same<TW, tw_none>::value;
+    if constexpr (SPF_SPREAD == 0) {
+        if constexpr (IN) radix8_stage1_in<DIR>(X, tw, s, t); else radix8_stage1<DIR>(X, s, t);
         sched_fence();
-        radix8<DIR>(B);
-#pragma unroll
-        for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], t2[8 * (c - 1)]);
+        op(0); op(1); op(2);
         sched_fence();
-        lane_transpose_hi3(B);
-        radix8<DIR>(B);
+        radix8_stage2<DIR>(s, t, u);
+        sched_fence();
+        op(3); op(4); op(5);
+        sched_fence();
+        radix8_stage3<DIR>(X, u);
+        sched_fence();
+        op(6); op(7);
     } else {
-        // pass 2 of B, A's exchange-2 stores spread through it
-        radix8_tw_spread<DIR>(B, t2, 8, [&](int k) { *reinterpret_cast<c64*>(wr[k]) = A[k]; });
+        // stage 1 pair by pair
 #pragma unroll
-        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
+        for (int j = 0; j < 4; j++) {
+            if constexpr (IN) {
+                if (j == 0) {
+                    s[0] = cfma_tw<DIR>(X[0], X[4], tw(3));
+                    t[0] = twice_minus(X[0], s[0]);
+                } else {
+                    const c64 a = cmul_tw<DIR>(X[j], tw(j - 1));
+                    s[j] = cfma_tw<DIR>(a, X[j + 4], tw(j + 3));
+                    t[j] = twice_minus(a, s[j]);
+                }
+            } else {
+                s[j] = cadd(X[j], X[j + 4]);
+                t[j] = csub(X[j], X[j + 4]);
+            }
+            if constexpr (SPF_SPREAD == 1) {
+                sched_fence();
+                op(j);
+                sched_fence();
+            } else if (j == 1 || j == 3) {
+                sched_fence();
+                op(j - 1); op(j);
+                sched_fence();
+            }
+        }
+        radix8_stage2<DIR>(s, t, u);
         sched_fence();
-        lane_transpose_hi3(B);
-        radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
-        radix8<DIR>(B);
+        op(4); op(5);
+        sched_fence();
+        radix8_stage3<DIR>(X, u);
+        sched_fence();
+        op(6); op(7);
     }
-    sched_fence(); // the image's next writer stays behind these reads
+    sched_fence();
+    after();
+    sched_fence();
 }
+template <int DIR, class TW, class OP, class AFTER>
+__device__ __forceinline__ void radix8_in_spread2(c64 (&X)[8], TW tw, OP op, AFTER after) { radix8_any_spread<DIR>(X, tw, op, after); }
+template <int DIR, class OP, class AFTER>
+__device__ __forceinline__ void radix8_spread2(c64 (&X)[8], OP op, AFTER after) { radix8_any_spread<DIR>(X, tw_none{}, op, after); }
+template <int DIR, class TW, class OP>
+__device__ __forceinline__ void radix8_in_spread(c64 (&X)[8], TW tw, OP op) { radix8_any_spread<DIR>(X, tw, op, [] {}); }
+template <int DIR, class OP>
+__device__ __forceinline__ void radix8_spread(c64 (&X)[8], OP op) { radix8_any_spread<DIR>(X, tw_none{}, op, [] {}); }
 
-// ---- fft512_pair1 with EARLY reads ---------------------------------------------------------------------------------------
-// fft512_pair1 issues the reads of an exchange one butterfly block behind its stores (the registers of the transform that is
-// in LDS are free for the other one's temporaries meanwhile), so the reads have only the next store burst to complete under.
-// Where registers allow (polynomial 0's forward pair: the frequency-domain product is not live yet; the inverse pair: it has
-// just been consumed), the reads go out right behind their own stores — a wave's DS instructions execute in issue order, the
-// image is free again for the other transform's stores as soon as the reads are ISSUED — and have a whole butterfly block of
-// the other transform to land under.  Same butterflies on the same values: same words.
-template <int DIR, int XP = 2, class MID = no_hook>
-__device__ __forceinline__ void fft512_pair1e(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
-{
-    static_assert(XP == 1 || XP == 2, "exchange 2 of B (XP = 2) or of both transforms (XP = 1) in registers");
-    constexpr bool XA = XP == 1;
-    const int hi3 = lane >> 3, lo3 = lane & 7;
-    const uint32_t rd1 = 16 * (8 * lo3 + (hi3 ^ lo3));
-    const uint32_t rd2 = 16 * (8 * hi3 + (hi3 ^ lo3));
-    const uint32_t wbase = 16 * (64 * hi3 + lo3);
-    char* wr[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
-    // pass 1 of A, exchange 1 of A out and straight back
-    radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
-    sched_fence();
-#pragma unroll
-    for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    // pass 1 of B (A's reads land under it), exchange 1 of B
-    radix8<DIR>(B);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tab[kT1Off + (k1 - 1) * 64 + lane]);
-    sched_fence();
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
-    sched_fence();
-#pragma unroll
-    for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
-    sched_fence();
-    // pass 2 of A (B's reads land under it)
-    radix8<DIR>(A);
-#pragma unroll
-    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tab[kT2Off + (c - 1) * 8 + hi3]);
-    sched_fence();
-    mid();
-    if constexpr (XA) {
-        lane_transpose_hi3(A);
-        radix8<DIR>(A); // pass 3 of A
-        sched_fence();
-    } else {
-#pragma unroll
-        for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
-        sched_fence();
-#pragma unroll
-        for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
-        sched_fence();
+// the factors of a pass for the spread pairs: fetched into registers ahead of the pass and shared by the two transforms (1), or
+// read from the table where they are used (0: 28 registers less across the first butterfly stage, which in DAG-II holds the eight
+// operands, their factors and the eight results at once)
+#ifndef SPF_PAIR_TW_REGS
+#define SPF_PAIR_TW_REGS 0
+#endif
+struct tw_pick {
+    const c64 (&w)[7];
+    tw_table t;
+    __device__ __forceinline__ c64 operator()(int k) const
+    {
+        if constexpr (SPF_PAIR_TW_REGS) return w[k];
+        else return t(k);
     }
-    // pass 2 of B (A's exchange-2 reads land under it), exchange 2 of B in registers
-    radix8<DIR>(B);
-#pragma unroll
-    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tab[kT2Off + (c - 1) * 8 + hi3]);
-    sched_fence();
-    lane_transpose_hi3(B);
-    if constexpr (!XA) radix8<DIR>(A); // pass 3 of A
-    radix8<DIR>(B);
-    sched_fence(); // the image's next writer stays behind these reads
-}
+};
+#define SPF_TW(regs, table) tw_pick{regs, table}
 
-// ---- fft512_pair1 with the pass twiddles requested EARLY and SHARED by the two transforms ---------------------------------
-// The ISA of fft512_pair1 (r04, `tools/isa_build.sh`) shows what hipcc makes of `X[k] = cmul_tw(X[k], tab[...])` when registers
-// are tight: the seven twiddles of a pass are fetched just in time, one or two at a time, each `ds_read_b128` followed by an
-// `s_waitcnt lgkmcnt(1)` four instructions later — about twenty exposed LDS round trips per pair that only the partner wave
-// can cover — and each transform fetches its own copy of the same seven entries (lane-indexed T1, hi3-indexed T2: the same
-// for A and B).  Here the seven entries of a pass are requested once, ahead of the butterflies they follow (they land under
-// ~50 f64 instructions), and multiply both transforms.  28 registers, live from the request to the second transform's
-// products: there is room for them wherever the frequency-domain product is not live (polynomial 0's forward pair, the
-// inverse pair), because one of the two transforms is always parked in LDS while the other is in its butterflies.
+// ---- fft512_pair1 with the pass factors requested EARLY and SHARED by the two transforms -----------------------------------
+// The seven factors of a pass are requested once, ahead of the butterflies that use them, and serve both transforms (lane-indexed:
+// the same for A and B).  28 registers, live from the request to the second transform's first stage.
 template <int DIR, int XP = 2, class MID = no_hook>
 __device__ __forceinline__ void fft512_pair1t(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
 {
@@ -729,19 +687,16 @@ __device__ __forceinline__ void fft512_pair1t(c64 (&A)[8], c64 (&B)[8], char* bu
 #pragma unroll
     for (int r = 0; r < 8; r++) wr[r] = buf + ((wbase ^ (16 * r)) + 128 * r);
     c64 tw[7];
-    // pass 1: T1 for both transforms, requested ahead of A's butterflies
-#pragma unroll
-    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
-    compiler_fence();
+    // pass 1 of both, exchange 1 of A
     radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = A[k1];
     sched_fence();
-    radix8<DIR>(B);
+    // pass 2's factors (W64^{a k1}, k1 = lo3) for both transforms, requested ahead of B's pass 1
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tw[k1 - 1]);
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT2Off + k * 8 + lo3];
+    compiler_fence();
+    radix8<DIR>(B);
     sched_fence();
 #pragma unroll
     for (int a = 0; a < 8; a++) A[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
@@ -749,112 +704,54 @@ __device__ __forceinline__ void fft512_pair1t(c64 (&A)[8], c64 (&B)[8], char* bu
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) *reinterpret_cast<c64*>(wr[k1]) = B[k1];
     sched_fence();
-    // pass 2: T2 for both transforms, requested ahead of A's butterflies (behind B's stores in the queue)
-#pragma unroll
-    for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
-    compiler_fence();
-    radix8<DIR>(A);
-#pragma unroll
-    for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tw[c - 1]);
+    radix8_in<DIR>(A, tw_regs{tw});
     sched_fence();
     mid();
 #pragma unroll
     for (int a = 0; a < 8; a++) B[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd1);
     sched_fence();
-    if constexpr (XA) {
-        lane_transpose_hi3(A);
-        radix8<DIR>(A); // pass 3 of A
-    } else {
+    if constexpr (!XA) {
 #pragma unroll
         for (int c = 0; c < 8; c++) *reinterpret_cast<c64*>(wr[c]) = A[c];
+        sched_fence();
     }
+    radix8_in<DIR>(B, tw_regs{tw});
     sched_fence();
-    radix8<DIR>(B);
+    // pass 3's factors (W512^{b lane}) for both
 #pragma unroll
-    for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tw[c - 1]);
-    sched_fence();
-    if constexpr (!XA) {
+    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+    compiler_fence();
+    if constexpr (XA) {
+        lane_transpose_hi3(A);
+    } else {
 #pragma unroll
         for (int b = 0; b < 8; b++) A[b] = *reinterpret_cast<const c64*>(buf + 1024 * b + rd2);
         sched_fence();
     }
     lane_transpose_hi3(B);
-    if constexpr (!XA) radix8<DIR>(A); // pass 3 of A, its exchange-2 reads having travelled under B's transposition
-    radix8<DIR>(B);
+    radix8_in<DIR>(A, tw_regs{tw}); // pass 3 of A (its exchange-2 reads having travelled under B's transposition)
+    radix8_in<DIR>(B, tw_regs{tw});
     sched_fence(); // the image's next writer stays behind these reads
 }
 
-// fft512_pair1t with (EARLY) the reads of an exchange issued right behind its own stores and / or (SPREAD) the stores of one
-// transform issued two at a time between the butterfly stages of the other — the combinations r04 measured after the
-// shared twiddles had removed the exposed table reads (profiles/r04_experiments_blind_rotate.md).
-// radix8_twr_spread with the stores packed into the three butterfly stages (3 + 3 + 2) and `after()` — the reads of the
-// transform just stored — issued behind the last store, ahead of the seven twiddle products: the butterfly temporaries are
-// dead there and the stored transform's registers are free, so the reads cost no registers and have the products to land under
-template <int DIR, class OP, class AFTER>
-__device__ __forceinline__ void radix8_twr_spread2(c64 (&X)[8], const c64 (&tw)[7], OP op, AFTER after)
-{
-    {
-        c64 s[4], t[4], u[8];
-        radix8_stage1<DIR>(X, s, t);
-        sched_fence();
-        op(0); op(1); op(2);
-        sched_fence();
-        radix8_stage2<DIR>(s, t, u);
-        sched_fence();
-        op(3); op(4); op(5);
-        sched_fence();
-        radix8_stage3<DIR>(X, u);
-    }
-    sched_fence();
-    op(6); op(7);
-    sched_fence();
-    after();
-    sched_fence();
-#pragma unroll
-    for (int k = 1; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
-    sched_fence();
-}
-template <int DIR, class OP>
-__device__ __forceinline__ void radix8_twr_spread(c64 (&X)[8], const c64 (&tw)[7], OP op)
-{
-    c64 s[4], t[4], u[8];
-    radix8_stage1<DIR>(X, s, t);
-    sched_fence();
-    op(0); op(1);
-    sched_fence();
-    radix8_stage2<DIR>(s, t, u);
-    sched_fence();
-    op(2); op(3);
-    sched_fence();
-    radix8_stage3<DIR>(X, u);
-    sched_fence();
-    op(4); op(5);
-    sched_fence();
-#pragma unroll
-    for (int k = 1; k < 5; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
-    sched_fence();
-    op(6); op(7);
-    sched_fence();
-#pragma unroll
-    for (int k = 5; k < 8; k++) X[k] = cmul_tw<DIR>(X[k], tw[k - 1]);
-    sched_fence();
-}
 // XP = 0 tail of the pairs below: exchange 2 of B through the image as well, behind A's (A's exchange-2 reads are issued, a wave's
 // DS instructions execute in order, so B's stores cannot overtake them): eight stores and eight reads on the LDS pipe instead of
 // lane_transpose_hi3's 80 vector instructions — 16 v_permlane*_swap at 8.5 cycles of the SIMD each, 32 DPP moves at 4.5, 16 moves
-// (tools/microbench/valu_rates.hip): ~480 of a pair's ~5 600 vector cycles.  B's reads travel under A's last radix-8.
-template <int DIR, class ST, class LD>
-__device__ __forceinline__ void pair_tail_through_image(c64 (&A)[8], c64 (&B)[8], ST store, LD load, uint32_t rd2)
+// (tools/microbench/valu_rates.hip): ~480 of a pair's vector cycles.  B's reads travel under A's last radix-8.
+template <int DIR, class TW, class ST, class LD>
+__device__ __forceinline__ void pair_tail_through_image(c64 (&A)[8], c64 (&B)[8], TW t3, ST store, LD load, uint32_t rd2)
 {
 #pragma unroll
     for (int k = 0; k < 8; k++) store(B, k);
     sched_fence();
     load(B, rd2);
     sched_fence();
-    radix8<DIR>(A);
+    radix8_in<DIR>(A, t3);
     sched_fence();
-    radix8<DIR>(B);
+    radix8_in<DIR>(B, t3);
 }
+// fft512_pair1t with (EARLY) the reads of an exchange issued right behind its own stores and / or (SPREAD) the stores of one
+// transform issued between the butterfly stages of the other
 template <int DIR, int XP, bool EARLY, bool SPREAD, class MID = no_hook>
 __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
 {
@@ -872,45 +769,37 @@ __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* bu
         for (int a = 0; a < 8; a++) X[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
     };
     c64 tw[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
-    compiler_fence();
+    const tw_table t2{tab + kT2Off + lo3, 8}, t3{tab + kT1Off + lane, 64};
     // pass 1 of A
     radix8<DIR>(A);
+    // pass 2's factors for both transforms, requested ahead of B's pass 1
+    if constexpr (SPF_PAIR_TW_REGS) {
 #pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT2Off + k * 8 + lo3];
+        compiler_fence();
+    }
     if constexpr (!SPREAD) {
 #pragma unroll
         for (int k = 0; k < 8; k++) store(A, k);
         sched_fence();
         if constexpr (EARLY) { load(A, rd1); sched_fence(); }
         radix8<DIR>(B);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) B[k1] = cmul_tw<DIR>(B[k1], tw[k1 - 1]);
         sched_fence();
     } else {
         sched_fence();
-        radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
+        radix8_spread<DIR>(B, [&](int k) { store(A, k); });
     }
     if constexpr (!EARLY || SPREAD) { load(A, rd1); sched_fence(); }
-    // exchange 1 of B, T2 for both transforms, pass 2 of A
+    // exchange 1 of B, pass 2 of A
     if constexpr (!SPREAD) {
 #pragma unroll
         for (int k = 0; k < 8; k++) store(B, k);
         sched_fence();
         if constexpr (EARLY) { load(B, rd1); sched_fence(); }
-#pragma unroll
-        for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
-        compiler_fence();
-        radix8<DIR>(A);
-#pragma unroll
-        for (int c = 1; c < 8; c++) A[c] = cmul_tw<DIR>(A[c], tw[c - 1]);
+        radix8_in<DIR>(A, SPF_TW(tw, t2));
         sched_fence();
     } else {
-#pragma unroll
-        for (int c = 0; c < 7; c++) tw[c] = tab[kT2Off + c * 8 + hi3];
-        compiler_fence();
-        radix8_twr_spread<DIR>(A, tw, [&](int k) { store(B, k); });
+        radix8_in_spread<DIR>(A, SPF_TW(tw, t2), [&](int k) { store(B, k); });
     }
     mid();
     if constexpr (!EARLY || SPREAD) { load(B, rd1); sched_fence(); }
@@ -920,20 +809,24 @@ __device__ __forceinline__ void fft512_pair1x(c64 (&A)[8], c64 (&B)[8], char* bu
         for (int k = 0; k < 8; k++) store(A, k);
         sched_fence();
         if constexpr (EARLY) { load(A, rd2); sched_fence(); }
-        radix8<DIR>(B);
-#pragma unroll
-        for (int c = 1; c < 8; c++) B[c] = cmul_tw<DIR>(B[c], tw[c - 1]);
+        radix8_in<DIR>(B, SPF_TW(tw, t2));
         sched_fence();
     } else {
-        radix8_twr_spread<DIR>(B, tw, [&](int k) { store(A, k); });
+        radix8_in_spread<DIR>(B, SPF_TW(tw, t2), [&](int k) { store(A, k); });
+    }
+    // pass 3's factors for both
+    if constexpr (SPF_PAIR_TW_REGS) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+        compiler_fence();
     }
     if constexpr (!EARLY || SPREAD) { load(A, rd2); sched_fence(); }
     if constexpr (XP == 2) {
         lane_transpose_hi3(B);
-        radix8<DIR>(A);
-        radix8<DIR>(B);
+        radix8_in<DIR>(A, SPF_TW(tw, t3));
+        radix8_in<DIR>(B, SPF_TW(tw, t3));
     } else {
-        pair_tail_through_image<DIR>(A, B, store, load, rd2);
+        pair_tail_through_image<DIR>(A, B, SPF_TW(tw, t3), store, load, rd2);
     }
     sched_fence();
 }
@@ -955,37 +848,36 @@ __device__ __forceinline__ void fft512_pair1ts2(c64 (&A)[8], c64 (&B)[8], char* 
         for (int a = 0; a < 8; a++) X[a] = *reinterpret_cast<const c64*>(buf + 1024 * a + rd);
     };
     c64 tw[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
-    compiler_fence();
+    const tw_table t2{tab + kT2Off + lo3, 8}, t3{tab + kT1Off + lane, 64};
     radix8<DIR>(A);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) A[k1] = cmul_tw<DIR>(A[k1], tw[k1 - 1]);
     sched_fence();
-    // pass 1 of B: A's exchange-1 stores in its butterflies, A's exchange-1 reads under its twiddle products
-    radix8_twr_spread2<DIR>(B, tw, [&](int k) { store(A, k); }, [&]() { load(A, rd1); });
-    // pass 2 of A: B's exchange-1 stores, then B's exchange-1 reads; T2 requested first
-    c64 tw2[7];
+    // pass 2's factors for both transforms, requested ahead of B's pass 1
+    if constexpr (SPF_PAIR_TW_REGS) {
 #pragma unroll
-    for (int c = 0; c < 7; c++) tw2[c] = tab[kT2Off + c * 8 + hi3];
-    compiler_fence();
-    radix8_twr_spread2<DIR>(A, tw2, [&](int k) { store(B, k); }, [&]() { load(B, rd1); });
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT2Off + k * 8 + lo3];
+        compiler_fence();
+    }
+    // pass 1 of B: A's exchange-1 stores in its butterflies, A's exchange-1 reads behind the last store
+    radix8_spread2<DIR>(B, [&](int k) { store(A, k); }, [&]() { load(A, rd1); });
+    // pass 2 of A: B's exchange-1 stores, then B's exchange-1 reads
+    radix8_in_spread2<DIR>(A, SPF_TW(tw, t2), [&](int k) { store(B, k); }, [&]() { load(B, rd1); });
     mid();
     // pass 2 of B: A's exchange-2 stores, then A's exchange-2 reads
-    radix8_twr_spread2<DIR>(B, tw2, [&](int k) { store(A, k); }, [&]() { load(A, rd2); });
+    radix8_in_spread2<DIR>(B, SPF_TW(tw, t2), [&](int k) { store(A, k); }, [&]() { load(A, rd2); });
+    // pass 3's factors for both
+    if constexpr (SPF_PAIR_TW_REGS) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) tw[k] = tab[kT1Off + k * 64 + lane];
+        compiler_fence();
+    }
     if constexpr (XP == 2) {
         lane_transpose_hi3(B);
-        radix8<DIR>(A);
-        radix8<DIR>(B);
+        radix8_in<DIR>(A, SPF_TW(tw, t3));
+        radix8_in<DIR>(B, SPF_TW(tw, t3));
     } else {
-        pair_tail_through_image<DIR>(A, B, store, load, rd2);
+        pair_tail_through_image<DIR>(A, B, SPF_TW(tw, t3), store, load, rd2);
     }
     sched_fence();
-}
-template <int DIR, int XP = 2, class MID = no_hook>
-__device__ __forceinline__ void fft512_pair1te(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())
-{
-    fft512_pair1x<DIR, XP, true, false>(A, B, buf, tab, lane, mid);
 }
 template <int DIR, int XP = 2, class MID = no_hook>
 __device__ __forceinline__ void fft512_pair1ts(c64 (&A)[8], c64 (&B)[8], char* buf, const c64* tab, int lane, MID mid = MID())

@@ -38,8 +38,8 @@ __host__ __device__ inline size_t generic_lds_bytes(uint32_t N, uint32_t k, bool
 
 __device__ inline void generic_fft(c64* a, uint32_t len, uint32_t loglen, int dir, const c64* w_tab);
 
-// DAG-I's 1024-point transform on a[1024] in LDS with tmp[1024] as the second image, array form of the tuned
-// kernels' register code: the same butterflies (`radix8`), twiddle products and tables, so the same bits.  128 threads each
+// The canonical 1024-point transform (DAG-II since r06) on a[1024] in LDS with tmp[1024] as the second image, array form of the tuned
+// kernels' register code: the same butterflies (`radix8` / `radix8_in`), input factors and tables, so the same bits.  128 threads each
 // carry one radix-8 of one of the two 512-point transforms per pass.
 __device__ inline void generic_fft1024_dag1(c64* a, c64* tmp, int dir, const c64* tab)
 {
@@ -52,9 +52,7 @@ __device__ inline void generic_fft1024_dag1(c64* a, c64* tmp, int dir, const c64
         if (tid < 128) {
 #pragma unroll
             for (int n1 = 0; n1 < 8; n1++) v[n1] = a[s * 512 + 64 * n1 + l];
-            radix8<DIR>(v);
-#pragma unroll
-            for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul_tw<DIR>(v[k1], tab[kT1Off + (k1 - 1) * 64 + l]); // W512^{n0 k1}, n0 = l
+            radix8<DIR>(v);                                                                              // pass 1: no input factors
 #pragma unroll
             for (int k1 = 0; k1 < 8; k1++) tmp[s * 512 + l * 8 + k1] = v[k1];                            // y[n0][k1]
         }
@@ -63,9 +61,7 @@ __device__ inline void generic_fft1024_dag1(c64* a, c64* tmp, int dir, const c64
             const uint32_t k1 = l >> 3, b = l & 7;
 #pragma unroll
             for (int aa = 0; aa < 8; aa++) v[aa] = tmp[s * 512 + (8 * aa + b) * 8 + k1];
-            radix8<DIR>(v);
-#pragma unroll
-            for (int c = 1; c < 8; c++) v[c] = cmul_tw<DIR>(v[c], tab[kT2Off + (c - 1) * 8 + b]);          // W64^{b c}
+            radix8_in<DIR>(v, tw_table{tab + kT2Off + k1, 8});                                           // operand a enters with W64^{a k1}
 #pragma unroll
             for (int c = 0; c < 8; c++) a[s * 512 + k1 * 64 + b * 8 + c] = v[c];                          // g[k1][b][c]
         }
@@ -74,7 +70,7 @@ __device__ inline void generic_fft1024_dag1(c64* a, c64* tmp, int dir, const c64
             const uint32_t k1 = l >> 3, c = l & 7;
 #pragma unroll
             for (int b = 0; b < 8; b++) v[b] = a[s * 512 + k1 * 64 + b * 8 + c];
-            radix8<DIR>(v);
+            radix8_in<DIR>(v, tw_table{tab + kT1Off + (k1 + 8 * c), 64});                                // operand b enters with W512^{b (k1 + 8c)}
 #pragma unroll
             for (int d = 0; d < 8; d++) tmp[s * 512 + k1 + 8 * c + 64 * d] = v[d];                        // X[k1 + 8c + 64d]
         }

@@ -325,7 +325,7 @@ static inline spfo_c64 cmul_nf(spfo_c64 a, spfo_c64 b)
     return o;
 }
 
-/* FFT-internal twiddle multiply of DAG-I: one mul + one fma per component. */
+/* FFT-internal twiddle multiply (DAG-I and DAG-II): one mul + one fma per component. */
 static inline spfo_c64 cmul_tw(spfo_c64 a, spfo_c64 w)
 {
     spfo_c64 o;
@@ -338,66 +338,93 @@ static inline spfo_c64 cmul_tw(spfo_c64 a, spfo_c64 w)
 
 static inline spfo_c64 cconj(spfo_c64 a) { return (spfo_c64){a.re, -a.im}; }
 
-/* ======================================================================== canonical FFT (DAG-I)
+/* acc + a * w as DAG-II folds it into a butterfly: two fused multiply-adds per component (w already conjugated for the
+ * inverse transform by the caller) */
+static inline spfo_c64 cfma_tw(spfo_c64 acc, spfo_c64 a, spfo_c64 w)
+{
+    spfo_c64 o;
+    o.re = fma(-a.im, w.im, fma(a.re, w.re, acc.re));
+    o.im = fma(a.im, w.re, fma(a.re, w.im, acc.im));
+    return o;
+}
+
+/* ======================================================================== canonical FFT (DAG-II, r06)
  *
- * 8-point DFT butterfly, decimation in frequency, three radix-2 stages.  dir=+1: kernel
- * e^{-2 pi i jk/8}; dir=-1: e^{+2 pi i jk/8}.  The tree below IS the definition: the HIP kernel
- * (spf_amd/csrc/fft512.hpp) performs the same adds/subs/muls on the same operands.
+ * The transform is third-party in the reference (rustfft behind sunscreen_tfhe's negacyclic wrapper,
+ * math/fft/negacyclic/mod.rs:96-122): its operation order is this repository's to define, and the HIP kernels follow the
+ * definition below operation for operation.  DAG-II (r06) is DAG-I (r01-r05) re-associated so that the f64 stream is mostly
+ * fused multiply-adds — of DAG-I's 2 112 f64 instructions per wave and blind-rotation step 1 700 were one-flop adds or
+ * multiplies:
+ *   - the twiddle factors between the radix-8 passes are applied at the INPUT of the next pass's first butterfly stage:
+ *       a = w_j v_j;   s = a + w_{j+4} v_{j+4}  (two FMAs per component);   t = 2 a - s  (one FMA per component)
+ *     (pass-1 factor W512^{(8a+b) k1} = W64^{a k1} W512^{b k1}: the first part is pass 2's input factor, the second is
+ *     common to the eight operands of a pass-2 butterfly, commutes with it and joins pass 2's own factor W64^{b c} as pass 3's
+ *     input factor W512^{b (k1 + 8c)});
+ *   - the 1/sqrt(2) of the two W8 rotations inside a radix-8 multiplies their SUM / DIFFERENCE in the last stage
+ *     (u = b0 +- c q as FMAs) instead of each rotated term.
+ * 8-point DFT butterfly, decimation in frequency, three radix-2 stages.  dir=+1: kernel e^{-2 pi i jk/8}; dir=-1: e^{+2 pi i jk/8}.
+ * w: the seven input factors of operands 1..7 (already conjugated for dir < 0), or NULL for none.  The tree below IS the
+ * definition: the HIP kernels (spf_amd/csrc/spf_device.hpp: radix8 / radix8_in) perform the same operations on the same operands.
  */
 static const double SQRT1_2 = 0.70710678118654752440; /* 0x3FE6A09E667F3BCD */
 
-static void radix8(const spfo_c64 v[8], spfo_c64 u[8], int dir)
+static void radix8(const spfo_c64 v[8], const spfo_c64 *w, spfo_c64 u[8], int dir)
 {
-    spfo_c64 s0 = cadd(v[0], v[4]), s1 = cadd(v[1], v[5]), s2 = cadd(v[2], v[6]),
-             s3 = cadd(v[3], v[7]);
-    spfo_c64 t0 = csub(v[0], v[4]), t1 = csub(v[1], v[5]), t2 = csub(v[2], v[6]),
-             t3 = csub(v[3], v[7]);
-    /* t_j *= W8^{j}  (forward W8 = e^{-i pi/4}) */
-    spfo_c64 t1w, t3w;
-    if (dir > 0) {
-        double p1 = t1.re + t1.im, m1 = t1.im - t1.re;
-        t1w.re = p1 * SQRT1_2; t1w.im = m1 * SQRT1_2;       /* (x+iy) r(1-i) */
-        double p3 = t3.re + t3.im, m3 = t3.im - t3.re;
-        t3w.re = m3 * SQRT1_2; t3w.im = -(p3 * SQRT1_2);    /* (x+iy) r(-1-i) */
+    spfo_c64 s[4], t[4];
+    if (w) {
+        s[0] = cfma_tw(v[0], v[4], w[3]);
+        t[0] = (spfo_c64){fma(2.0, v[0].re, -s[0].re), fma(2.0, v[0].im, -s[0].im)};
+        for (int j = 1; j < 4; j++) {
+            spfo_c64 a = cmul_tw(v[j], w[j - 1]);
+            s[j] = cfma_tw(a, v[j + 4], w[j + 3]);
+            t[j] = (spfo_c64){fma(2.0, a.re, -s[j].re), fma(2.0, a.im, -s[j].im)};
+        }
     } else {
-        double p1 = t1.re + t1.im, m1 = t1.re - t1.im;
-        t1w.re = m1 * SQRT1_2; t1w.im = p1 * SQRT1_2;       /* (x+iy) r(1+i) */
-        double p3 = t3.re + t3.im, m3 = t3.re - t3.im;
-        t3w.re = -(p3 * SQRT1_2); t3w.im = m3 * SQRT1_2;    /* (x+iy) r(-1+i) */
+        for (int j = 0; j < 4; j++) { s[j] = cadd(v[j], v[j + 4]); t[j] = csub(v[j], v[j + 4]); }
+    }
+    /* t_1 W8, t_3 W8^3 without their 1/sqrt(2): qb = (t1 W8 + t3 W8^3) sqrt(2), qe = (t1 W8 - t3 W8^3) sqrt(2) */
+    spfo_c64 qb, qe;
+    if (dir > 0) {
+        double p1 = t[1].re + t[1].im, m1 = t[1].im - t[1].re;   /* (x+iy)(1-i) */
+        double p3 = t[3].re + t[3].im, m3 = t[3].im - t[3].re;   /* (x+iy)(-1-i) = (m3, -p3) */
+        qb = (spfo_c64){p1 + m3, m1 - p3};
+        qe = (spfo_c64){p1 - m3, m1 + p3};
+    } else {
+        double p1 = t[1].re + t[1].im, m1 = t[1].re - t[1].im;   /* (x+iy)(1+i) = (m1, p1) */
+        double p3 = t[3].re + t[3].im, m3 = t[3].re - t[3].im;   /* (x+iy)(-1+i) = (-p3, m3) */
+        qb = (spfo_c64){m1 - p3, p1 + m3};
+        qe = (spfo_c64){m1 + p3, p1 - m3};
     }
     /* even outputs: 4-point DFT of s */
-    spfo_c64 a0 = cadd(s0, s2), a1 = cadd(s1, s3), a2 = csub(s0, s2), d = csub(s1, s3);
+    spfo_c64 a0 = cadd(s[0], s[2]), a1 = cadd(s[1], s[3]), a2 = csub(s[0], s[2]), d = csub(s[1], s[3]);
     u[0] = cadd(a0, a1);
     u[4] = csub(a0, a1);
-    /* odd outputs: 4-point DFT of (t0, t1w, t2*(-/+i), t3w) */
+    /* odd outputs: 4-point DFT of (t0, t1 W8, t2 (-/+i), t3 W8^3) */
     spfo_c64 b0, b2;
+    const double c = SQRT1_2;
     if (dir > 0) {
-        /* a3 = d * (-i) = (d.im, -d.re) */
         u[2] = (spfo_c64){a2.re + d.im, a2.im - d.re};
         u[6] = (spfo_c64){a2.re - d.im, a2.im + d.re};
-        /* t2 * (-i) = (t2.im, -t2.re) */
-        b0 = (spfo_c64){t0.re + t2.im, t0.im - t2.re};
-        b2 = (spfo_c64){t0.re - t2.im, t0.im + t2.re};
+        b0 = (spfo_c64){t[0].re + t[2].im, t[0].im - t[2].re};
+        b2 = (spfo_c64){t[0].re - t[2].im, t[0].im + t[2].re};
     } else {
-        /* a3 = d * (+i) = (-d.im, d.re) */
         u[2] = (spfo_c64){a2.re - d.im, a2.im + d.re};
         u[6] = (spfo_c64){a2.re + d.im, a2.im - d.re};
-        b0 = (spfo_c64){t0.re - t2.im, t0.im + t2.re};
-        b2 = (spfo_c64){t0.re + t2.im, t0.im - t2.re};
+        b0 = (spfo_c64){t[0].re - t[2].im, t[0].im + t[2].re};
+        b2 = (spfo_c64){t[0].re + t[2].im, t[0].im - t[2].re};
     }
-    spfo_c64 b1 = cadd(t1w, t3w), e = csub(t1w, t3w);
-    u[1] = cadd(b0, b1);
-    u[5] = csub(b0, b1);
-    if (dir > 0) {
-        u[3] = (spfo_c64){b2.re + e.im, b2.im - e.re};
-        u[7] = (spfo_c64){b2.re - e.im, b2.im + e.re};
+    u[1] = (spfo_c64){fma(c, qb.re, b0.re), fma(c, qb.im, b0.im)};
+    u[5] = (spfo_c64){fma(-c, qb.re, b0.re), fma(-c, qb.im, b0.im)};
+    if (dir > 0) {   /* b2 -/+ i e, e = c qe */
+        u[3] = (spfo_c64){fma(c, qe.im, b2.re), fma(-c, qe.re, b2.im)};
+        u[7] = (spfo_c64){fma(-c, qe.im, b2.re), fma(c, qe.re, b2.im)};
     } else {
-        u[3] = (spfo_c64){b2.re - e.im, b2.im + e.re};
-        u[7] = (spfo_c64){b2.re + e.im, b2.im - e.re};
+        u[3] = (spfo_c64){fma(-c, qe.im, b2.re), fma(c, qe.re, b2.im)};
+        u[7] = (spfo_c64){fma(c, qe.im, b2.re), fma(-c, qe.re, b2.im)};
     }
 }
 
-/* twiddle tables of DAG-I, forward sign (e^{-2 pi i e/M}); inverse uses exact conjugates */
+/* twiddle tables of the canonical transform, forward sign (e^{-2 pi i e/M}); inverse uses exact conjugates */
 static spfo_c64 W512_tab[512], W64_tab[64], W1024_tab[512], TWIST2048[1024];
 static pthread_once_t tab_once = PTHREAD_ONCE_INIT;
 static void init_tables(void)
@@ -409,46 +436,38 @@ static void init_tables(void)
     for (int j = 0; j < 1024; j++) TWIST2048[j] = spfo_root_of_unity((uint64_t)j, 4096);
 }
 
-/* 512-point DFT, DIF 8x8x8, natural order in and out.
+/* 512-point DFT, 8x8x8, natural order in and out (DAG-II).
  *   n' = 64*n1 + n0,  n0 = 8a + b,   k' = k1 + 8c + 64d
- *   pass 1: radix-8 over n1 -> k1, then * W512^{n0*k1}   (skipped only when k1 == 0)
- *   pass 2: radix-8 over a  -> c,  then * W64^{b*c}      (skipped only when c  == 0)
- *   pass 3: radix-8 over b  -> d
+ *   pass 1: radix-8 over n1 -> k1
+ *   pass 2: radix-8 over a  -> c,  operand a enters as  W64^{a*k1}  * y[8a+b][k1]
+ *   pass 3: radix-8 over b  -> d,  operand b enters as  W512^{b*(k1+8c)} * g[k1][b][c]
  */
 static void fft512(const spfo_c64 *x, spfo_c64 *X, int dir)
 {
     static __thread spfo_c64 y[64][8], g[8][8][8];
-    spfo_c64 v[8], u[8];
+    spfo_c64 v[8], u[8], w[7];
     for (int n0 = 0; n0 < 64; n0++) {
         for (int n1 = 0; n1 < 8; n1++) v[n1] = x[64 * n1 + n0];
-        radix8(v, u, dir);
-        y[n0][0] = u[0];
-        for (int k1 = 1; k1 < 8; k1++) {
-            spfo_c64 w = W512_tab[n0 * k1];
-            if (dir < 0) w = cconj(w);
-            y[n0][k1] = cmul_tw(u[k1], w);
-        }
+        radix8(v, NULL, u, dir);
+        for (int k1 = 0; k1 < 8; k1++) y[n0][k1] = u[k1];
     }
     for (int k1 = 0; k1 < 8; k1++)
         for (int b = 0; b < 8; b++) {
             for (int a = 0; a < 8; a++) v[a] = y[8 * a + b][k1];
-            radix8(v, u, dir);
-            g[k1][b][0] = u[0];
-            for (int c = 1; c < 8; c++) {
-                spfo_c64 w = W64_tab[b * c];
-                if (dir < 0) w = cconj(w);
-                g[k1][b][c] = cmul_tw(u[c], w);
-            }
+            for (int a = 1; a < 8; a++) w[a - 1] = dir > 0 ? W64_tab[a * k1] : cconj(W64_tab[a * k1]);
+            radix8(v, w, u, dir);
+            for (int c = 0; c < 8; c++) g[k1][b][c] = u[c];
         }
     for (int k1 = 0; k1 < 8; k1++)
         for (int c = 0; c < 8; c++) {
             for (int b = 0; b < 8; b++) v[b] = g[k1][b][c];
-            radix8(v, u, dir);
+            for (int b = 1; b < 8; b++) w[b - 1] = dir > 0 ? W512_tab[b * (k1 + 8 * c)] : cconj(W512_tab[b * (k1 + 8 * c)]);
+            radix8(v, w, u, dir);
             for (int d = 0; d < 8; d++) X[k1 + 8 * c + 64 * d] = u[d];
         }
 }
 
-/* 1024-point DFT of DAG-I.
+/* 1024-point DFT of the canonical transform.
  * forward: split input by parity, FFT-512 each, X[k] = E[k] + W1024^k O[k], X[k+512] = E - W O.
  * inverse: E'[k] = X[k] + X[k+512], O'[k] = (X[k] - X[k+512]) * conj(W1024^k), FFT-512^-1 each,
  *          y[2n'] = e0[n'], y[2n'+1] = e1[n'].  Unnormalised both ways. */

@@ -197,12 +197,8 @@ __global__ __launch_bounds__(512, 2) void pair_loop(const c64* tables, unsigned 
         else if constexpr (V == 3) pair_arith_only<+1>(A, B, tab, lane);
         else if constexpr (V == 4) pair_lds_only(A, B, buf, tab, lane);
         else if constexpr (V == 13) pair_arith_only_folded<+1>(A, B, tab, lane);
-        else if constexpr (V == 5) fft512_pair1s<+1>(A, B, buf, tab, lane);
-        else if constexpr (V == 6) fft512_pair1e<+1, 2>(A, B, buf, tab, lane);
-        else if constexpr (V == 7) fft512_pair1e<+1, 1>(A, B, buf, tab, lane);
         else if constexpr (V == 8) fft512_pair1t<+1, 2>(A, B, buf, tab, lane);
         else if constexpr (V == 9) fft512_pair1t<+1, 1>(A, B, buf, tab, lane);
-        else if constexpr (V == 10) fft512_pair1te<+1, 2>(A, B, buf, tab, lane);
         else if constexpr (V == 11) fft512_pair1ts<+1, 2>(A, B, buf, tab, lane);
         else fft512_pair1ts2<+1, 2>(A, B, buf, tab, lane);
         // keep magnitudes bounded (exact power-of-two scaling) and the emulated state live
@@ -307,14 +303,13 @@ int main(int argc, char** argv)
     run<1, 1>("1 fft512_pair1<+1,0> all exchanges via LDS", d_tab, d_out, n_cu, iters);
     run<2, 0>("2 fft512_pair1<+1,1> exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
     run<2, 1>("2 fft512_pair1<+1,1> exchange 2 in registers (both)", d_tab, d_out, n_cu, iters);
-    run<3, 0>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
-    run<3, 1>("3 arithmetic only (VALU floor)", d_tab, d_out, n_cu, iters);
+    run<3, 0>("3 arithmetic only, DAG-I shape (output products) on the new radix-8", d_tab, d_out, n_cu, iters);
+    run<3, 1>("3 arithmetic only, DAG-I shape (output products) on the new radix-8", d_tab, d_out, n_cu, iters);
     run<13, 0>("13 arithmetic only, FMA-folded radix-8 (DAG-II gate)", d_tab, d_out, n_cu, iters);
     run<13, 1>("13 arithmetic only, FMA-folded radix-8 (DAG-II gate)", d_tab, d_out, n_cu, iters);
     run<4, 0>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
     run<4, 1>("4 LDS traffic only (LDS floor)", d_tab, d_out, n_cu, iters);
-    run<5, 0>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
-    run<5, 1>("5 fft512_pair1s: stores spread through the butterflies", d_tab, d_out, n_cu, iters);
+    run<8, 1>("8 fft512_pair1t<+1,2>: factors requested early, shared", d_tab, d_out, n_cu, iters);
     run<11, 1>("11 fft512_pair1ts: shared twiddles + spread stores", d_tab, d_out, n_cu, iters);
     run<12, 1>("12 fft512_pair1ts2: + reads under the twiddle products", d_tab, d_out, n_cu, iters);
     run<11, 1, 0, 0, 1>("11 shared twiddles + spread stores", d_tab, d_out, n_cu, iters);
