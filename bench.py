@@ -1042,9 +1042,11 @@ def _pool_runs(out, thread_counts, seconds, eng, P, dev, torch, drv, submit, wai
             drv.spf_pool_drive(pool._h, submit, wait, T, 0.5, lwe1.ctypes.data, P.lwe1_words, P.cbs_ggsw_complex * 2,
                                C.byref(el), C.byref(ck))   # warm-up: staging buffers pinned, shapes settled
             ops0, launches0 = pool.stats()
+            c0 = pool.counters()
             n = drv.spf_pool_drive(pool._h, submit, wait, T, seconds, lwe1.ctypes.data, P.lwe1_words, P.cbs_ggsw_complex * 2,
                                    C.byref(el), C.byref(ck))
             ops1, launches1 = pool.stats()
+            c1 = pool.counters()
         finally:
             pool.close()
         if n < 0:
@@ -1052,6 +1054,8 @@ def _pool_runs(out, thread_counts, seconds, eng, P, dev, torch, drv, submit, wai
         rate = n / el.value
         out["runs"].append({"threads": T, "circuit_bootstraps_per_s": round(rate, 1), "operations": int(n),
                             "achieved_batch": round((ops1 - ops0) / max(1, launches1 - launches0), 1),
+                            "launches_by_shape": {k: c1["bootstrap_launches_by_shape"][k] - c0["bootstrap_launches_by_shape"][k]
+                                                  for k in c1["bootstrap_launches_by_shape"]},
                             "device_resident_rate_at_batch_T": round(dev_rate, 1),
                             "frac_of_device_resident": round(rate / dev_rate, 4)})
 

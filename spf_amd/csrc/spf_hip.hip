@@ -2303,7 +2303,12 @@ spf_status spf_value_download_batch(size_t n, const spf_value* const* values, vo
     spf_value_impl::Arena::DeviceScope ds(values[0]->arena->device);
     if (!ds.ok) return SPF_ERR_HIP;
     if (consecutive) return hipMemcpy(host, values[0]->ptr(), n * bytes, hipMemcpyDeviceToHost) == hipSuccess ? SPF_OK : SPF_ERR_HIP;
-    if (n >= 4 && values[0]->home) {
+    bool pool_alive;
+    {
+        std::lock_guard<std::mutex> lk(values[0]->arena->mu);
+        pool_alive = !values[0]->arena->closed; // (values may outlive their pool: its context and stream are then gone)
+    }
+    if (n >= 4 && pool_alive) {
         // scattered (the outputs of a circuit come from different batches): packed on the device into one scratch block
         // (gather_rows_kernel reading a pointer table at the block's end), then ONE copy — a copy to pageable memory costs ~25 us
         // per call whatever its size
