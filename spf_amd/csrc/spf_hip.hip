@@ -2376,7 +2376,10 @@ spf_status spf_value_trivial(spf_pool* p, int member, spf_value_kind kind, uint6
         spf_value_impl::Arena::DeviceScope ds(c->device);
         std::lock_guard<std::recursive_mutex> g(c->mu);
         st = ds.ok ? ensure_ggsw_constants(c) : fail(c, SPF_ERR_HIP, "hipSetDevice failed");
-        if (st == SPF_OK && hipMemcpy(v->ptr(), (const char*)c->d_ggsw_const + (size_t)bit * bytes, bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        // (a device-to-device hipMemcpy may return before the copy has run: the value is handed out only after the stream is idle —
+        // the kernels that will read it run on the pool's own non-blocking streams, which do not wait for the null stream)
+        if (st == SPF_OK && (hipMemcpy(v->ptr(), (const char*)c->d_ggsw_const + (size_t)bit * bytes, bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+                             hipStreamSynchronize(nullptr) != hipSuccess))
             st = fail(c, SPF_ERR_HIP, "spf_value_trivial: device copy failed");
     }
     if (st != SPF_OK) {
@@ -2439,9 +2442,10 @@ spf_status spf_value_copy_to_member(spf_pool* p, const spf_value* v, int member,
         return fail(leaf->ctx, SPF_ERR_HIP, "spf_value_copy_to_member: out of device memory");
     }
     spf_value_impl::Arena::DeviceScope ds(leaf->ctx->device);
-    const hipError_t e = !ds.ok ? hipErrorInvalidDevice
-                         : (v->arena->device == leaf->ctx->device ? hipMemcpy(w->ptr(), v->ptr(), v->bytes, hipMemcpyDeviceToDevice)
-                                                                  : hipMemcpyPeer(w->ptr(), leaf->ctx->device, v->ptr(), v->arena->device, v->bytes));
+    hipError_t e = !ds.ok ? hipErrorInvalidDevice
+                   : (v->arena->device == leaf->ctx->device ? hipMemcpy(w->ptr(), v->ptr(), v->bytes, hipMemcpyDeviceToDevice)
+                                                            : hipMemcpyPeer(w->ptr(), leaf->ctx->device, v->ptr(), v->arena->device, v->bytes));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // (a device-to-device copy may return before it has run; see spf_value_trivial)
     if (e != hipSuccess) {
         w->release();
         return fail(leaf->ctx, SPF_ERR_HIP, std::string("spf_value_copy_to_member: ") + hipGetErrorString(e));
