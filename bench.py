@@ -392,6 +392,14 @@ def main() -> int:
                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                              "bytes_per_unit": P.cbs_ggsw_complex * 16 + 3 * P.glwe_words * 8, "units_per_launch": B}}
 
+    # HBM bytes per launch and the SQ busy fractions of the dominant kernel: measured by this run with rocprofv3 --pmc CHILD processes
+    # of this same script — here, BEFORE the legs that create the pools' streams: once this process holds two dozen hardware queues
+    # the child's dispatches are time-sliced against them (r06: WRITE_SIZE 854 MB per launch instead of 154, the wave state saved at
+    # every switch, and 40.4 ms instead of 38.1 in the child)
+    live_early = None
+    if rank == 0 and world == 1 and not args.no_live_counters:
+        n_cu_early = torch.cuda.get_device_properties(local_dev).multi_processor_count
+        live_early = leg("live_counters", lambda: _live_counters(kernel_name, B, kernel_ms, n_cu_early))
     gate = leg("gate", _gate) if args.with_keyswitch else None
     uni = leg("pbs_univariate", _pbs_univariate) if extras else None
     cbs = leg("circuit_bootstrap", _cbs) if args.with_cbs else None
@@ -452,8 +460,7 @@ def main() -> int:
     # when rocprofv3 is not on the box or --no-live-counters is given.
     traffic, stored, live = None, None, None
     if rank == 0 and world == 1 and not args.no_live_counters:
-        n_cu = torch.cuda.get_device_properties(local_dev).multi_processor_count
-        live = leg("live_counters", lambda: _live_counters(kernel_name, B, kernel_ms, n_cu))
+        live = live_early
         if live:
             traffic = live.get("hbm_bytes_per_launch")
     tpath = os.path.join(ROOT, "profiles", "latest_counters.json")
