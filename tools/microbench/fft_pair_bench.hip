@@ -19,7 +19,11 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
+#ifdef SPF_DEVICE_HEADER // (e.g. -DSPF_DEVICE_HEADER='"../../profiles/r06_experimental_sources/dag2/spf_device_dag2.hpp"': the DAG-II transform)
+#include SPF_DEVICE_HEADER
+#else
 #include "../../spf_amd/csrc/spf_device.hpp"
+#endif
 
 using namespace spf;
 
