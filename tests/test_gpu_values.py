@@ -333,3 +333,51 @@ def test_values_on_a_group_pool_stay_on_their_member(rig):
         gc.collect()
         pool.close()
         grp.close()
+
+
+def test_batch_upload_and_download_and_a_failing_batch(rig):
+    """`spf_value_upload_batch` / `spf_value_download_batch`: the bits of an integer in one block and one copy (consecutive values)
+    or one gathered copy (scattered values), same words as one by one; and a batch that FAILS (no keyswitch key) reports the
+    status to its waiter and leaves a result value that can never be used."""
+    ks, eng, _ = rig
+    P = ks.params
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=200)
+    try:
+        x = random_glwe(77, 9, P.glwe_len)
+        vals = pool.upload_batch(ValueKind.GLWE1, x)
+        assert len(vals) == 9 and all(v.info()["valid"] for v in vals)
+        p0 = vals[0].device_ptr()
+        assert [v.device_ptr() - p0 for v in vals] == [i * P.glwe_len * 8 for i in range(9)]          # one block, consecutive
+        assert np.array_equal(pool.download_batch(vals), x)                                            # one copy
+        order = [8, 2, 5, 0, 7]
+        assert np.array_equal(pool.download_batch([vals[i] for i in order]), x[order])                # gathered on the device
+        assert np.array_equal(pool.download_batch([vals[3], vals[1]]), x[[3, 1]])                     # (two: one copy each)
+        nots = [pool.run_v(FheOp.Not, [v]) for v in vals[:4]]                                          # results of four batches
+        exp = np.stack([O.glwe_not(x[i], P.N, P.k) for i in range(4)])
+        assert np.array_equal(pool.download_batch(nots), exp)
+        with pytest.raises(spf_amd.SpfError):
+            pool.download_batch([vals[0], pool.upload(ValueKind.LWE1, random_lwe_batch(1, 1, P.N * P.k)[0])])   # mixed kinds
+    finally:
+        import gc
+        gc.collect()
+        pool.close()
+    bare = spf_amd.Engine(eng.params)          # a context without keys
+    pool = spf_amd.Pool(bare, max_batch=8, max_wait_us=100)
+    try:
+        v = pool.upload(ValueKind.LWE1, random_lwe_batch(2, 1, P.N * P.k)[0])
+        res, ticket = pool.submit_v(FheOp.KeyswitchL1toL0, [v])
+        with pytest.raises(spf_amd.SpfError) as e:
+            pool.wait(ticket)
+        assert e.value.status == 3                                 # SPF_ERR_NO_KEY, the batch's status
+        assert res.info()["valid"] is False
+        with pytest.raises(spf_amd.SpfError):
+            res.download()
+        with pytest.raises(spf_amd.SpfError):
+            pool.submit_v(FheOp.CircuitBootstrap, [res])           # a failed result is refused as an operand
+        res.release()
+        assert pool.run_v(FheOp.Not, [pool.upload(ValueKind.GLWE1, random_glwe(3, 1, P.glwe_len)[0])]).info()["valid"]   # the pool goes on
+    finally:
+        import gc
+        gc.collect()
+        pool.close()
+        bare.close()
