@@ -231,4 +231,154 @@ class FheCircuit {
     spf_graph* g_ = nullptr;
 };
 
+// ---- the per-operation boundary with the ciphertexts in HBM (spf_value_*, spf_pool_submit_*_v) -----------------------------
+//
+// The reference's ciphertext types (parasol_runtime/src/crypto/encryption.rs:143-165: L0LweCiphertext, L1LweCiphertext,
+// L1GlweCiphertext, L1GlevCiphertext, L1GgswCiphertext) as typed, move-only owners of ONE device-resident value: what a Rust shim
+// keeps as `Option<SpfValue>` inside those types.  A wrong operand type is a compile error here, as it is
+// there; the C ABI below refuses it at run time.
+template <spf_value_kind K> class DeviceCiphertext {
+  public:
+    static constexpr spf_value_kind kind = K;
+    DeviceCiphertext() = default; // empty: an output that has not been written (the reference allocates with `::allocate`)
+    DeviceCiphertext(DeviceCiphertext&& o) noexcept : v_(o.v_) { o.v_ = nullptr; }
+    DeviceCiphertext& operator=(DeviceCiphertext&& o) noexcept
+    {
+        if (this != &o) {
+            reset();
+            v_ = o.v_;
+            o.v_ = nullptr;
+        }
+        return *this;
+    }
+    DeviceCiphertext(const DeviceCiphertext&) = delete;
+    DeviceCiphertext& operator=(const DeviceCiphertext&) = delete;
+    ~DeviceCiphertext() { reset(); }
+    // `Clone`: another owner of the same immutable value (a reference count, no copy)
+    DeviceCiphertext share() const
+    {
+        DeviceCiphertext c;
+        if (v_ && spf_value_retain(v_) == SPF_OK) c.v_ = v_;
+        return c;
+    }
+    explicit operator bool() const { return v_ != nullptr; }
+    spf_value* raw() const { return v_; }
+    // HBM -> host, the reference layout (u64 words; the GGSW: complex f64)
+    void download(void* host) const
+    {
+        const spf_status s = v_ ? spf_value_download(v_, host) : SPF_ERR_INVALID_ARGUMENT;
+        if (s != SPF_OK) throw Error(s, "DeviceCiphertext::download: no valid value");
+    }
+    void reset()
+    {
+        if (v_) spf_value_release(v_);
+        v_ = nullptr;
+    }
+
+  private:
+    friend class PooledEvaluation;
+    spf_value* v_ = nullptr;
+};
+using L0LweCiphertext = DeviceCiphertext<SPF_VAL_LWE0>;
+using L1LweCiphertext = DeviceCiphertext<SPF_VAL_LWE1>;
+using L1GlweCiphertext = DeviceCiphertext<SPF_VAL_GLWE1>;
+using L1GlevCiphertext = DeviceCiphertext<SPF_VAL_GLEV1>;
+using L1GgswCiphertext = DeviceCiphertext<SPF_VAL_GGSW1>;
+
+// `Evaluation` as `CircuitProcessor`'s workers call it (circuit_processor/mod.rs:255-540): one operation on one ciphertext per
+// call, from any number of threads, output first — over a pool of the Evaluation's group, so that the concurrent calls of many
+// workers become one launch, with operands and results in HBM.  Each method returns when its output is valid, like the reference's.
+class PooledEvaluation {
+  public:
+    explicit PooledEvaluation(const Evaluation& ev, size_t max_batch = 1024, uint32_t max_wait_us = 100) : grp_(ev.group())
+    {
+        if (spf_pool_create_group(grp_, max_batch, max_wait_us, &pool_) != SPF_OK) throw Error(SPF_ERR_HIP, spf_group_last_error(grp_));
+    }
+    PooledEvaluation(const PooledEvaluation&) = delete;
+    PooledEvaluation& operator=(const PooledEvaluation&) = delete;
+    ~PooledEvaluation() { spf_pool_destroy(pool_); }
+    spf_pool* raw() const { return pool_; }
+
+    // `encrypt` / `trivial_*` land here: host words -> a device ciphertext on the calling thread's member
+    template <class C> C upload(const void* host) const
+    {
+        C c;
+        check(spf_value_upload(pool_, -1, C::kind, host, &c.v_));
+        return c;
+    }
+    template <class C> C trivial(uint64_t bit) const
+    {
+        C c;
+        check(spf_value_trivial(pool_, -1, C::kind, bit, &c.v_));
+        return c;
+    }
+
+    // KeylessEvaluation (crypto/evaluation.rs:47-133)
+    void not_(L1GlweCiphertext& output, const L1GlweCiphertext& input) const { run(SPF_OP_NOT, output, {input.raw()}); }
+    void xor_(L1GlweCiphertext& output, const L1GlweCiphertext& a, const L1GlweCiphertext& b) const
+    {
+        run(SPF_OP_GLWE_ADD, output, {a.raw(), b.raw()});
+    }
+    void mul_xn(L1GlweCiphertext& output, const L1GlweCiphertext& input, size_t n) const { run(SPF_OP_MUL_XN, output, {input.raw()}, n); }
+    void cmux(L1GlweCiphertext& output, const L1GgswCiphertext& sel, const L1GlweCiphertext& a, const L1GlweCiphertext& b) const
+    {
+        run(SPF_OP_CMUX, output, {sel.raw(), a.raw(), b.raw()});
+    }
+    void glev_cmux(L1GlevCiphertext& output, const L1GgswCiphertext& sel, const L1GlevCiphertext& a, const L1GlevCiphertext& b) const
+    {
+        run(SPF_OP_GLEV_CMUX, output, {sel.raw(), a.raw(), b.raw()});
+    }
+    void multiply_glwe_ggsw(L1GlweCiphertext& output, const L1GlweCiphertext& glwe, const L1GgswCiphertext& ggsw) const
+    {
+        run(SPF_OP_MULTIPLY_GGSW_GLWE, output, {ggsw.raw(), glwe.raw()});
+    }
+    void sample_extract_l1(L1LweCiphertext& output, const L1GlweCiphertext& input, size_t idx) const
+    {
+        run(SPF_OP_SAMPLE_EXTRACT, output, {input.raw()}, idx);
+    }
+    // Evaluation (crypto/evaluation.rs:211-251)
+    void keyswitch_lwe_l1_lwe_l0(L0LweCiphertext& output, const L1LweCiphertext& input) const
+    {
+        run(SPF_OP_KEYSWITCH_L1_TO_L0, output, {input.raw()});
+    }
+    void circuit_bootstrap(L1GgswCiphertext& output, const L0LweCiphertext& input) const
+    {
+        run(SPF_OP_CIRCUIT_BOOTSTRAP, output, {input.raw()});
+    }
+    void scheme_switch(L1GgswCiphertext& output, const L1GlevCiphertext& input) const { run(SPF_OP_SCHEME_SWITCH, output, {input.raw()}); }
+    // FheOp::KeyswitchL1toL0 -> FheOp::CircuitBootstrap as one operation (the L0 ciphertext never exists outside the launch)
+    void keyswitch_circuit_bootstrap(L1GgswCiphertext& output, const L1LweCiphertext& input) const
+    {
+        spf_value* out = nullptr;
+        uint64_t t = 0;
+        check(spf_pool_submit_keyswitch_circuit_bootstrap_v(pool_, input.raw(), &out, &t));
+        finish(output, out, t);
+    }
+
+  private:
+    template <class C> void run(spf_graph_op op, C& output, std::initializer_list<const spf_value*> in, uint64_t param = 0) const
+    {
+        spf_value* out = nullptr;
+        uint64_t t = 0;
+        check(spf_pool_submit_op_v(pool_, op, in.begin(), in.size(), param, &out, &t));
+        finish(output, out, t);
+    }
+    template <class C> void finish(C& output, spf_value* out, uint64_t ticket) const
+    {
+        const spf_status s = spf_pool_wait(pool_, ticket);
+        if (s != SPF_OK) {
+            spf_value_release(out); // never valid: released in every case
+            check(s);
+        }
+        output.reset();
+        output.v_ = out;
+    }
+    void check(spf_status s) const // (the pool leaves its messages with the first member's context)
+    {
+        if (s != SPF_OK) throw Error(s, spf_last_error(spf_group_ctx(grp_, 0)));
+    }
+    spf_group* grp_ = nullptr;
+    spf_pool* pool_ = nullptr;
+};
+
 } // namespace spf

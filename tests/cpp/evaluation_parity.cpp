@@ -13,6 +13,7 @@ extern "C" {
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -163,6 +164,56 @@ int main()
                 all_same = all_same && same(jout[(size_t)j], gref);
             }
             expect(on0 == 2 && on1 == 2 && all_same, "FheCircuit jobs over the group: dealt 2 + 2, oracle's words");
+        }
+
+        // the same chain operation by operation, the ciphertexts in HBM: twelve worker threads call PooledEvaluation the way
+        // CircuitProcessor's rayon workers call Evaluation (circuit_processor/mod.rs:255-540), one ciphertext per call
+        {
+            spf::PooledEvaluation pe(ev, 64, 200);
+            const int T = 12;
+            std::vector<std::vector<uint64_t>> tout((size_t)T, std::vector<uint64_t>((k + 1) * N));
+            std::vector<int> ok((size_t)T, 0);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t] {
+                    try {
+                        auto x = pe.upload<spf::L1GlweCiphertext>(bit.data());
+                        auto va = pe.upload<spf::L1GlweCiphertext>(a.data());
+                        auto vb = pe.upload<spf::L1GlweCiphertext>(b.data());
+                        spf::L1LweCiphertext e1;
+                        spf::L0LweCiphertext e0;
+                        spf::L1GgswCiphertext sel_v, sel_fused;
+                        spf::L1GlweCiphertext nb, o, o2;
+                        pe.sample_extract_l1(e1, x, 0);
+                        pe.keyswitch_lwe_l1_lwe_l0(e0, e1);
+                        pe.circuit_bootstrap(sel_v, e0);
+                        pe.not_(nb, vb);
+                        pe.cmux(o, sel_v, va, nb);
+                        o.download(tout[(size_t)t].data());
+                        // the fused key switch + circuit bootstrap gives the same selector
+                        pe.keyswitch_circuit_bootstrap(sel_fused, e1);
+                        pe.cmux(o2, sel_fused, va, nb);
+                        std::vector<uint64_t> again((k + 1) * N);
+                        o2.download(again.data());
+                        ok[(size_t)t] = again == tout[(size_t)t];
+                    } catch (const spf::Error&) {
+                        ok[(size_t)t] = 0;
+                    }
+                });
+            for (auto& t : th) t.join();
+            bool all = true;
+            for (int t = 0; t < T; t++) all = all && ok[(size_t)t] && same(tout[(size_t)t], gref);
+            expect(all, "PooledEvaluation by handle, 12 threads: the chain's oracle words");
+            size_t live = 1, live_bytes = 1, cached = 0;
+            spf_pool_value_stats(pe.raw(), &live, &live_bytes, &cached);
+            expect(live == 0 && live_bytes == 0 && cached > 0, "  ... every value released: nothing live, the blocks cached");
+            // an output that was never written is refused (the reference cannot express it; the C ABI reports it)
+            bool refused = false;
+            try {
+                spf::L1GlweCiphertext none, o;
+                pe.not_(o, none);
+            } catch (const spf::Error& e) { refused = e.status == SPF_ERR_INVALID_ARGUMENT; }
+            expect(refused, "  ... an empty operand is SPF_ERR_INVALID_ARGUMENT");
         }
 
         // malformed graph: wrong operand type must throw when the node is added (task.rs:26-31)

@@ -106,6 +106,16 @@ def test_c_header_is_plain_c_and_cpp_mirror_compiles(tmp_path):
     cpp = tmp_path / "t.cpp"
     cpp.write_text('#include "spf_evaluation.hpp"\nint main(){ spf::ComputeKey k{nullptr,0,nullptr,0,nullptr,0,nullptr,0}; (void)k; return 0; }\n')
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], check=True)
+    # the typed device ciphertexts: the by-handle mirror instantiates, and a wrong operand type is a compile error
+    # (as `&L1GlweCiphertext` for a `&L1GgswCiphertext` is in the reference)
+    body = ('#include "spf_evaluation.hpp"\nvoid f(spf::PooledEvaluation& pe, spf::L1GgswCiphertext& s, spf::L1GlweCiphertext& a,'
+            ' spf::L1GlweCiphertext& o, spf::L1LweCiphertext& e1, spf::L0LweCiphertext& e0){ pe.sample_extract_l1(e1, a, 0);'
+            ' pe.keyswitch_lwe_l1_lwe_l0(e0, e1); pe.circuit_bootstrap(s, e0); %s }\nint main(){return 0;}\n')
+    good, bad = tmp_path / "good.cpp", tmp_path / "bad.cpp"
+    good.write_text(body % "pe.cmux(o, s, a, a);")
+    bad.write_text(body % "pe.cmux(o, a, a, a);")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(good)], check=True)
+    assert subprocess.run(["g++", "-std=c++17", "-I", inc, "-fsyntax-only", str(bad)], capture_output=True).returncode != 0
     # and a real link + run against the built library (no GPU call: version + params only)
     exe = tmp_path / "t"
     subprocess.run(["gcc", "-std=c99", "-I", inc, str(c), "-o", str(exe), "-L", os.path.dirname(spf_amd.lib_path()),

@@ -16,7 +16,7 @@ def test_cpp_evaluation_and_fhe_circuit_match_the_oracle(tmp_path):
     libdir = os.path.dirname(spf_amd.lib_path())
     oracle_so = O.library_path()
     exe = tmp_path / "evaluation_parity"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
                     "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "cpp", "evaluation_parity.cpp"),
                     "-o", str(exe), "-L", libdir, "-lspf_hip", oracle_so,
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.dirname(oracle_so)], check=True)
