@@ -66,8 +66,9 @@ typedef struct spf_params {
 /* DEFAULT_128 (parasol_runtime/src/params.rs:107-134): the parameter set the tuned kernels are built for (lwe_dimension and the
  * keyswitch radix are free).  Any other set with polynomial_degree a power of two in 16 .. 2048 and radices with
  * radix_log * count < 64 whose (glwe_size + 1) polynomials fit one CU's LDS is served by a generic, untuned kernel family with the
- * same results as the reference's generic functions (every entry point except the gate graphs); anything else — e.g.
- * polynomial_degree 2048 with glwe_size >= 2 — is SPF_ERR_UNSUPPORTED. */
+ * same results as the reference's generic functions (every entry point: batch and device-pointer forms, the pool by host pointer
+ * and by handle, the gate graphs, the device group); anything else — e.g. polynomial_degree 2048 with glwe_size >= 2 — is
+ * SPF_ERR_UNSUPPORTED. */
 void spf_default_params(spf_params *out);
 
 typedef struct spf_ctx spf_ctx;

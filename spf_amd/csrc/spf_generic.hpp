@@ -320,6 +320,7 @@ struct GenericCmuxArgs {
     const uint64_t* d1;
     uint64_t* out;
     uint32_t units, per_ggsw, d0_zero, radix_log, count;
+    const void* const* ptrs; // non-null: 4 pointers per unit {selector, d0 (null = the zero ciphertext), d1, out} instead (gate graphs, values)
 };
 
 // cmux (fft_ops.rs:149-181): out = d0 + IFFT(decomp(d1 - d0) [*] ggsw); with d0_zero: multiply_glwe_ggsw
@@ -336,7 +337,15 @@ __global__ __launch_bounds__(kGenericThreads) void generic_cmux_kernel(GenericCm
     const uint64_t* d1 = a.d1 + (size_t)u * len;
     uint64_t* out = a.out + (size_t)u * len;
     const c64* ggsw = a.ggsw + (size_t)(u / a.per_ggsw) * (size_t)(k + 1) * a.count * (k + 1) * h;
-    const bool zero = a.d0_zero != 0;
+    bool zero = a.d0_zero != 0;
+    if (a.ptrs) {
+        const void* const* q = a.ptrs + (size_t)u * 4;
+        ggsw = static_cast<const c64*>(q[0]);
+        d1 = static_cast<const uint64_t*>(q[2]);
+        zero = q[1] == nullptr;
+        d0 = zero ? d1 : static_cast<const uint64_t*>(q[1]);
+        out = static_cast<uint64_t*>(const_cast<void*>(q[3]));
+    }
     generic_glwe_ggsw_mad(g, accf, buf, state, ggsw, a.radix_log, a.count,
                           [&](uint32_t p, uint32_t i) { return zero ? d1[p * N + i] : d1[p * N + i] - d0[p * N + i]; });
     for (uint32_t q = 0; q <= k; q++)

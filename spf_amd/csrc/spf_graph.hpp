@@ -553,7 +553,6 @@ static void group_forget_graph(struct spf_group* grp, spf_graph* graph);
 spf_status spf_graph_create(spf_ctx* c, spf_graph** out)
 {
     if (!c || !out) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    if (c->generic) return fail(c, SPF_ERR_UNSUPPORTED, "gate graphs are built for DEFAULT_128 only (the generic kernels serve the batch entry points)");
     spf_graph* g = new (std::nothrow) spf_graph();
     if (!g) return fail(c, SPF_ERR_HIP, "out of host memory");
     g->ctx = c;

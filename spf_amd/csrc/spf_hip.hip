@@ -1211,13 +1211,23 @@ spf_status spf_cmux_dev(spf_ctx* c, void* stream, size_t B, const double* d_sel,
 spf_status spf_cmux_scattered_dev(spf_ctx* c, void* stream, size_t units, const void* const* d_ptrs)
 {
     if (!c || (units && !d_ptrs)) return fail(c, SPF_ERR_INVALID_ARGUMENT, "null argument");
-    if (c->generic) return fail(c, SPF_ERR_UNSUPPORTED, "the scattered CMUX form (gate graphs) is built for DEFAULT_128 only");
-    if (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4)
+    if (!c->generic && (c->prm.cbs_radix_log != 4 || c->prm.cbs_radix_count != 4))
         return fail(c, SPF_ERR_UNSUPPORTED, "cmux kernel is built for cbs_radix 4 x 4 bits");
     if (units == 0) return SPF_OK;
     if (units > 0x7fffffffu) return fail(c, SPF_ERR_INVALID_ARGUMENT, "batch too large");
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->generic) {
+        GenericCmuxArgs ga{};
+        ga.g = generic_shape(c);
+        ga.units = (uint32_t)units; ga.per_ggsw = 1; ga.ptrs = d_ptrs;
+        ga.radix_log = c->prm.cbs_radix_log; ga.count = c->prm.cbs_radix_count;
+        c->last_cmux_kernel = "generic_cmux_kernel";
+        hipLaunchKernelGGL(generic_cmux_kernel, dim3((unsigned)units), dim3(kGenericThreads), generic_lds_bytes(ga.g.N, ga.g.k, false),
+                           (hipStream_t)stream, ga);
+        HIPCHK(c, hipGetLastError());
+        return SPF_OK;
+    }
     CmuxArgs a{};
     a.tables = c->d_tables; a.B = (uint32_t)units; a.per_ggsw = 1; a.ptrs = d_ptrs;
     launch_cmux_args(c, (hipStream_t)stream, a);

@@ -210,7 +210,8 @@ def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
 def test_random_parameter_sets_through_the_generic_family():
     """Random parameter sets outside the tuned kernels (N = 16 .. 1024, k = 1 .. 3, random radices and LWE dimension) and the
     N = 2048 sets with another PBS radix: a random entry point of the generic family per case — generalized / univariate /
-    circuit-bootstrap PBS, CMUX, keyswitch, trace, scheme switch, whole circuit bootstrap — every checked word against the oracle."""
+    circuit-bootstrap PBS, CMUX, keyswitch, trace, scheme switch, whole circuit bootstrap, a small gate graph — every
+    checked word against the oracle."""
     rng = np.random.default_rng(SEED + 3)
     for case in range(max(4, CASES // 2)):
         if rng.random() < 0.2:
@@ -246,7 +247,7 @@ def test_random_parameter_sets_through_the_generic_family():
         eng.load_automorphism_key(ak)
         eng.load_scheme_switch_key(ssk)
         B = int(rng.integers(1, 7))
-        kind = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 8))
         lwe = rng.integers(0, 1 << 64, size=(B, n + 1), dtype=np.uint64)
         if kind == 0:
             lut = random_glwe(int(rng.integers(1 << 30)), B, P.glwe_len)
@@ -284,9 +285,29 @@ def test_random_parameter_sets_through_the_generic_family():
             for i in range(B):
                 assert np.array_equal(got[i], O.mod_switch_trace_and_rotate(glwe[i], ak, P)), (tag, kind, i)
                 assert np.array_equal(gg[i].view(np.float64), O.scheme_switch_fft(glev[i], ssk, P).view(np.float64)), (tag, kind, i)
-        else:
+        elif kind == 6:
             got = eng.circuit_bootstrap(lwe[:2])
             for i in range(min(B, 2)):
                 exp = O.circuit_bootstrap(lwe[i], ks.bsk_fft, ak, ssk, P)
                 assert np.array_equal(got[i].view(np.float64).reshape(-1), exp.view(np.float64).reshape(-1)), (tag, kind, i)
+        else:
+            # a gate graph at this parameter set: KeyswitchL1toL0 -> CircuitBootstrap -> a chain of CMux gates over scattered operands
+            from spf_amd import FheOp, ValueKind
+            nb = min(B, 2)
+            lwe1 = rng.integers(0, 1 << 64, size=(nb, k * N + 1), dtype=np.uint64)
+            a = rng.integers(0, 1 << 64, size=(nb + 1, P.glwe_len), dtype=np.uint64)
+            g = spf_amd.FheCircuit(eng)
+            sel = [g.add_op(FheOp.CircuitBootstrap, [g.add_op(FheOp.KeyswitchL1toL0, [g.add_input(ValueKind.LWE1, x)])]) for x in lwe1]
+            ai = [g.add_input(ValueKind.GLWE1, x) for x in a]
+            acc = ai[nb]
+            for i in range(nb):
+                acc = g.add_op(FheOp.CMux, [sel[i], g.add_op(FheOp.Not, [acc]), ai[i]])
+            out = g.add_output(acc, ValueKind.GLWE1)
+            g.run()
+            exp = a[nb]
+            for i in range(nb):
+                l0 = O.keyswitch_lwe(lwe1[i], ks.ksk, k * N, n, kl, kc)
+                exp = O.cmux(O.glwe_not(exp, N, k), a[i], O.circuit_bootstrap(l0, ks.bsk_fft, ak, ssk, P), N, k, cl, cc)
+            assert np.array_equal(out, exp), (tag, kind)
+            g.close()
         eng.close()

@@ -203,12 +203,100 @@ def test_generic_circuit_bootstrap_tail_against_the_oracle(P):
         assert np.array_equal(eng.l1ggsw_constant(bit).view(np.float64), O.circuit_bootstrap(triv, ks.bsk_fft, ak, ssk, P).view(np.float64))
 
 
+@pytest.mark.parametrize("P", [TEST1.replace(lwe_n=5, tr_radix_log=7, tr_count=6, ss_radix_log=3, ss_count=15),
+                               SMALL16.replace(tr_radix_log=6, tr_count=5, ss_radix_log=5, ss_count=6)], ids=["N128k2", "N16k1"])
+def test_gate_graph_and_values_by_handle_over_a_generic_parameter_set(P):
+    """`FheCircuit` + `CircuitProcessor` (fhe_circuit.rs:34-205, circuit_processor/mod.rs:573-623) and the per-operation boundary by
+    handle are parameter-agnostic too: the CMUX family over scattered operands runs in the generic kernel.  A graph with every
+    operation kind at TEST_GLWE_DEF_1 (k = 2) / N = 16, and the same operations one by one through the pool by handle, against
+    the oracle (CMux, conversion chain) and the batch entry points (which the tests above hold to the oracle)."""
+    from spf_amd import FheOp, ValueKind
+    ks = O.gen_keyset(0x5EED000C, P)
+    r = O.Rng(0x7A15)
+    ak, ssk = O.gen_auto_key_fft(r, ks.glwe_sk, P), O.gen_ssk_fft(r, ks.glwe_sk, P)
+    eng = spf_amd.Engine(_eng_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(ak)
+    eng.load_scheme_switch_key(ssk)
+    glwe = random_glwe(0x7E00 + P.N, 6, P.glwe_len)
+    lwe1 = random_lwe_batch(0x7E01 + P.N, 3, P.k * P.N)
+    glev = random_glwe(0x7E02 + P.N, 2 * P.cbs_count, P.glwe_len).reshape(2, -1)
+
+    g = spf_amd.FheCircuit(eng)
+    gi = [g.add_input(ValueKind.GLWE1, x) for x in glwe]
+    li = [g.add_input(ValueKind.LWE1, x) for x in lwe1]
+    vi = [g.add_input(ValueKind.GLEV1, x) for x in glev]
+    one, gone = g.add_trivial(ValueKind.GLWE1, 1), g.add_trivial(ValueKind.GGSW1, 1)
+    k0 = [g.add_op(FheOp.KeyswitchL1toL0, [x]) for x in li]
+    se = g.add_op(FheOp.SampleExtract, [gi[4]], 5)
+    nt = g.add_op(FheOp.Not, [gi[1]])
+    ad = g.add_op(FheOp.GlweAdd, [gi[2], gi[5]])
+    rot = g.add_op(FheOp.MulXN, [gi[0]], 2 * P.N + 7)
+    ss = g.add_op(FheOp.SchemeSwitch, [vi[1]])
+    cb = [g.add_op(FheOp.CircuitBootstrap, [x]) for x in k0]
+    k1 = g.add_op(FheOp.KeyswitchL1toL0, [se])
+    mux = g.add_op(FheOp.CMux, [cb[0], nt, ad])
+    mul = g.add_op(FheOp.MultiplyGgswGlwe, [cb[1], rot])
+    gmux = g.add_op(FheOp.GlevCMux, [cb[2], vi[0], vi[1]])
+    mux2 = g.add_op(FheOp.CMux, [ss, one, gi[3]])
+    mux3 = g.add_op(FheOp.CMux, [gone, gi[3], gi[4]])
+    cb1 = g.add_op(FheOp.CircuitBootstrap, [k1])
+    last = g.add_op(FheOp.CMux, [cb1, mux, mul])
+    outs = {n: g.add_output(n, k) for n, k in [
+        (k0[2], ValueKind.LWE0), (se, ValueKind.LWE1), (ss, ValueKind.GGSW1), (cb[1], ValueKind.GGSW1), (mux, ValueKind.GLWE1),
+        (mul, ValueKind.GLWE1), (gmux, ValueKind.GLEV1), (mux2, ValueKind.GLWE1), (mux3, ValueKind.GLWE1), (last, ValueKind.GLWE1)]}
+    g.run()
+    assert eng.last_cmux_kernel() == "generic_cmux_kernel"
+
+    e_k0 = eng.keyswitch_lwe_l1_lwe_l0(lwe1)
+    e_cb = eng.circuit_bootstrap(e_k0)
+    e_se = eng.sample_extract_l1(glwe[4:5], 5)
+    e_nt, e_ad = eng.glwe_not(glwe[1:2])[0], eng.glwe_xor(glwe[2:3], glwe[5:6])[0]
+    e_rot = eng.glwe_mul_xn(glwe[0:1], 2 * P.N + 7)[0]
+    e_ss = eng.scheme_switch(glev[1:2])
+    e_mux = eng.cmux(e_cb[0:1], e_nt, e_ad)[0]
+    e_mul = eng.multiply_glwe_ggsw(e_rot, e_cb[1:2])[0]
+    trivial_one = np.zeros(P.glwe_len, dtype=np.uint64)
+    trivial_one[P.N * P.k] = 1 << 63
+    e_cb1 = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(e_se))
+    assert np.array_equal(outs[k0[2]], O.keyswitch_lwe(lwe1[2], ks.ksk, P.k * P.N, P.lwe_n, P.ks_radix_log, P.ks_count))
+    assert np.array_equal(outs[se], O.sample_extract(glwe[4], 5, P.N, P.k))
+    assert np.array_equal(outs[ss].view(np.float64), O.scheme_switch_fft(glev[1].reshape(P.cbs_count, -1), ssk, P).view(np.float64))
+    assert np.array_equal(outs[cb[1]].view(np.float64), O.circuit_bootstrap(e_k0[1], ks.bsk_fft, ak, ssk, P).view(np.float64))
+    assert np.array_equal(outs[mux], O.cmux(e_nt, e_ad, e_cb[0], P.N, P.k, P.cbs_radix_log, P.cbs_count))
+    assert np.array_equal(outs[mux], e_mux) and np.array_equal(outs[mul], e_mul)
+    assert np.array_equal(outs[gmux], eng.glev_cmux(e_cb[2:3], glev[0:1], glev[1:2]).reshape(-1))
+    assert np.array_equal(outs[mux2], eng.cmux(e_ss, trivial_one, glwe[3])[0])
+    assert np.array_equal(outs[mux3], eng.cmux(eng.l1ggsw_constant(1)[None], glwe[3], glwe[4])[0])
+    assert np.array_equal(outs[last], O.cmux(e_mux, e_mul, e_cb1[0], P.N, P.k, P.cbs_radix_log, P.cbs_count))
+    g.close()
+
+    # the same operations one at a time by handle (operands and results stay in HBM between the calls)
+    pool = spf_amd.Pool(eng, max_batch=16, max_wait_us=200)
+    try:
+        v = [pool.upload(ValueKind.GLWE1, x) for x in glwe]
+        vl = pool.upload(ValueKind.LWE1, lwe1[0])
+        ve = [pool.upload(ValueKind.GLEV1, x) for x in glev]
+        sel = pool.run_v(FheOp.CircuitBootstrap, [pool.run_v(FheOp.KeyswitchL1toL0, [vl])])
+        assert np.array_equal(sel.download().view(np.float64), e_cb[0].view(np.float64))
+        assert np.array_equal(pool.keyswitch_circuit_bootstrap_v(vl).download().view(np.float64), e_cb[0].view(np.float64))
+        m = pool.run_v(FheOp.CMux, [sel, pool.run_v(FheOp.Not, [v[1]]), pool.run_v(FheOp.GlweAdd, [v[2], v[5]])])
+        assert np.array_equal(m.download(), e_mux)
+        assert np.array_equal(pool.run_v(FheOp.MultiplyGgswGlwe, [sel, v[0]]).download(), eng.multiply_glwe_ggsw(glwe[0], e_cb[0:1])[0])
+        assert np.array_equal(pool.run_v(FheOp.GlevCMux, [sel, ve[0], ve[1]]).download(), eng.glev_cmux(e_cb[0:1], glev[0:1], glev[1:2]).reshape(-1))
+        assert np.array_equal(pool.run_v(FheOp.SchemeSwitch, [ve[1]]).download().view(np.float64), e_ss.reshape(-1).view(np.float64))
+        assert np.array_equal(pool.run_v(FheOp.CMux, [pool.trivial(ValueKind.GGSW1, 1), v[3], v[4]]).download(), outs[mux3])
+        assert np.array_equal(pool.run_v(FheOp.SampleExtract, [v[4]], 5).download(), e_se[0])
+        assert np.array_equal(pool.run_v(FheOp.MulXN, [v[0]], 2 * P.N + 7).download(), e_rot)
+    finally:
+        import gc
+        gc.collect()
+        pool.close()
+
+
 def test_generic_contexts_say_what_they_do_not_do():
     P = to_engine_params(TEST1)
-    eng = spf_amd.Engine(P)
-    with pytest.raises(spf_amd.SpfError) as e:
-        spf_amd.FheCircuit(eng)
-    assert e.value.status == 4 and "DEFAULT_128" in str(e.value)
     with pytest.raises(spf_amd.SpfError):
         spf_amd.Engine(P.replace(polynomial_degree=96))        # not a power of two
     with pytest.raises(spf_amd.SpfError):
