@@ -1083,7 +1083,8 @@ def _pinned_to_quota():
     return scope()
 
 
-def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), seconds=2.0):
+def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), seconds=2.0, cmux_cases=((64, 1), (256, 1), (16, 64)),
+                          cbs_wait_us=200):
     """The drop-in scenario BY HANDLE (r06, include/spf_hip.h "device-resident values"): the same T native callers, one operation
     per call, operands and results device-resident values — nothing crosses PCIe per call.
       cmux            T callers loop one CMux gate each (the reference's `FheOp::CMux` task, circuit_processor/mod.rs:391-421):
@@ -1107,7 +1108,7 @@ def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), sec
     b = rng.integers(0, 1 << 64, size=P.glwe_words, dtype=np.uint64)
     lwe1 = rng.integers(0, 1 << 64, size=P.lwe1_words, dtype=np.uint64)
     with _pinned_to_quota():
-        for T, window in ((64, 1), (256, 1), (16, 64)):
+        for T, window in cmux_cases:
             row = {"threads": T, "tickets_open_per_thread": window}
             pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
             try:
@@ -1155,7 +1156,7 @@ def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), sec
             torch.cuda.synchronize()
             dev_rate = T * reps / (time.perf_counter() - t0)
             del d_in, d_mid, d_out
-            pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=200)
+            pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=cbs_wait_us)
             try:
                 ins = [pool.upload(1, lwe1 + np.uint64(t)) for t in range(T)]
                 hin = drvmod.handles(ins)
