@@ -355,10 +355,20 @@ spf_status spf_pool_counters_get(spf_pool *pool, spf_pool_counters *out);
  *     drops it (spf_value_retain adds one).  The pool keeps operands alive while an operation that reads them is queued or
  *     running, so a caller may release an operand right after the submit that used it.  Values may outlive their pool (their
  *     memory is freed on release); they must not be USED with another pool.
- *   Validity: a result value exists as soon as the submit returns, but becomes valid only when spf_pool_wait has returned
- *     SPF_OK for its ticket — exactly when the reference's task output becomes visible to its dependents
- *     (circuit_processor/mod.rs:214-246).  Using it earlier (or after a failed batch) is SPF_ERR_INVALID_ARGUMENT, never a
- *     read of unfinished data.  It must be released in every case.
+ *   Validity: a result value exists as soon as the submit returns, but becomes valid only when its operation has run:
+ *     spf_pool_wait has returned SPF_OK for its ticket — exactly when the reference's task output becomes visible to its
+ *     dependents (circuit_processor/mod.rs:214-246) — or spf_value_wait has returned SPF_OK for the value.  Reading it earlier
+ *     (spf_value_download, spf_value_device_ptr, spf_value_copy_to_member), or after a failed batch, is
+ *     SPF_ERR_INVALID_ARGUMENT, never a read of unfinished data.  It must be released in every case.
+ *   Deferred operands: a result that is still pending MAY be passed as an operand of a later `_v` submit to the same pool.  The
+ *     pool orders the two on the device (the dependent batch's stream waits for the producing batch's event) and batches what
+ *     has been pushed by level: operations on pending operands join the open batch of their (depth, kind, parameter), depth =
+ *     1 + the deepest batch an operand comes from, and the table is launched in depth order when a result in it is waited for,
+ *     when a batch of it is full, or when nothing has joined it for max_wait_us.  A caller can thus push a whole circuit —
+ *     every `FheOp` one `_v` submit, from one thread, without a single wait — and wait for the outputs only: the level batching
+ *     of spf_graph_run, built while the operations arrive.  An operation whose operand's producer failed fails with that status.
+ *     `ticket` may be NULL in the `_v` submits: nobody will spf_pool_wait for that operation (no ticket to collect, no
+ *     back-pressure from it); spf_value_wait on the result, or on anything computed from it, takes its place.
  *   Placement: a value lives on ONE member of a group pool (member 0 of a plain pool).  `member` < 0 in spf_value_upload /
  *     spf_value_trivial = the calling thread's home member (as the host-pointer submits deal their callers); an operation
  *     runs on the member its operands live on, its result stays there; operands on different members are
@@ -383,6 +393,9 @@ spf_status spf_value_download_batch(size_t n, const spf_value *const *values, vo
 spf_status spf_value_trivial(spf_pool *pool, int member, spf_value_kind kind, uint64_t bit, spf_value **out);
 /* HBM -> host (blocking); `host` has room for the kind's words */
 spf_status spf_value_download(const spf_value *value, void *host);
+/* blocks until the operation that produces `value` has run (returns at once for a valid value): SPF_OK, or the failure;
+ * any thread, any number of times, whether or not the operation has a ticket.  Launches what is still deferred. */
+spf_status spf_value_wait(const spf_value *value);
 spf_status spf_value_retain(spf_value *value);
 void spf_value_release(spf_value *value);
 /* any of the out pointers may be NULL */
@@ -396,8 +409,8 @@ spf_status spf_pool_value_stats(spf_pool *pool, size_t *live_values, size_t *liv
 spf_status spf_pool_trim(spf_pool *pool);
 
 /* The pool's submits by handle: same operations, same batching, same spf_pool_wait as the host-pointer forms above; operands
- * are valid values of this pool, *out receives the result value (see Validity).  Batches by handle never mix with host-pointer
- * callers.  No staging, no copies: the CMUX family reads its operands where they are, the other kinds pack theirs on the device
+ * are values of this pool — valid, or still pending (see Deferred operands) —, *out receives the result value (see Validity),
+ * `ticket` may be NULL.  Batches by handle never mix with host-pointer callers.  No staging, no copies: the CMUX family reads its operands where they are, the other kinds pack theirs on the device
  * (gather_rows_kernel) unless they already lie consecutively. */
 spf_status spf_pool_submit_keyswitch_v(spf_pool *pool, const spf_value *lwe1, spf_value **lwe0_out, uint64_t *ticket);
 spf_status spf_pool_submit_circuit_bootstrap_v(spf_pool *pool, const spf_value *lwe0, spf_value **ggsw_out, uint64_t *ticket);

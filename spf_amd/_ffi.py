@@ -165,6 +165,7 @@ SYMBOLS = [
     ("spf_value_download_batch", _I, [_SZ, C.POINTER(_P), _P]),
     ("spf_value_trivial", _I, [_P, _I, _I, _U64, C.POINTER(_P)]),
     ("spf_value_download", _I, [_P, _P]),
+    ("spf_value_wait", _I, [_P]),
     ("spf_value_retain", _I, [_P]),
     ("spf_value_release", None, [_P]),
     ("spf_value_info", _I, [_P, C.POINTER(_I), C.POINTER(_SZ), C.POINTER(_I), C.POINTER(_I)]),
@@ -892,6 +893,14 @@ class Pool:
         self._ck(self._lib.spf_pool_submit_op_v(self._h, int(op), arr, len(inputs), int(param), C.byref(h), C.byref(t)), "spf_pool_submit_op_v")
         return Value(self, h), t.value
 
+    def push_v(self, op: int, inputs, param: int = 0) -> "Value":
+        """`spf_pool_submit_op_v` without a ticket: the operands may be results that are still pending (the pool orders and
+        batches what is pushed by level); Value.wait() on the result — or on anything computed from it — makes it run"""
+        arr = (C.c_void_p * len(inputs))(*[v._h for v in inputs])
+        h = C.c_void_p()
+        self._ck(self._lib.spf_pool_submit_op_v(self._h, int(op), arr, len(inputs), int(param), C.byref(h), None), "spf_pool_submit_op_v")
+        return Value(self, h)
+
     def run_v(self, op: int, inputs, param: int = 0) -> "Value":
         v, t = self.submit_v(op, inputs, param)
         try:
@@ -940,6 +949,13 @@ class Value:
         if st != 0:
             raise SpfError(st, "spf_value_download: the value is not valid (wait for its ticket first)")
         return out
+
+    def wait(self) -> "Value":
+        """`spf_value_wait`: until the operation that produces the value has run"""
+        st = self._lib.spf_value_wait(self._h)
+        if st != 0:
+            raise SpfError(st, "spf_value_wait: the producing operation failed")
+        return self
 
     def device_ptr(self) -> int:
         p = C.c_void_p()

@@ -2208,7 +2208,7 @@ spf_pool* value_pool(spf_pool* top, int member, int* which)
 spf_status pool_submit_v(spf_pool* top, int op, const spf_value* const* vals, size_t n_vals, uint64_t param, spf_value** out,
                          uint64_t* ticket)
 {
-    if (!top || !out || !ticket || !vals) return SPF_ERR_INVALID_ARGUMENT;
+    if (!top || !out || !vals) return SPF_ERR_INVALID_ARGUMENT; // (ticket may be null: nobody will wait for this operation itself)
     PoolOpInfo info{};
     if (!pool_op_info(op, &info) || n_vals != (size_t)info.arity) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: wrong number of operands");
     spf_value* v[3] = {nullptr, nullptr, nullptr};
@@ -2216,8 +2216,8 @@ spf_status pool_submit_v(spf_pool* top, int op, const spf_value* const* vals, si
         v[k] = const_cast<spf_value*>(vals[k]);
         if (!v[k]) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: null operand");
         if (v[k]->kind != info.in_kind[k]) return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operand has the wrong ciphertext type");
-        if (!v[k]->ready())
-            return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operand is not valid (its producing operation has not been waited for, or failed)");
+        if (v[k]->state.load(std::memory_order_acquire) == spf_value_impl::FAILED)
+            return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: the operation that was to produce this operand failed");
         if (v[k]->home != v[0]->home)
             return fail(top->ctx, SPF_ERR_INVALID_ARGUMENT, "pool operation by handle: operands live on different members of the group (spf_value_copy_to_member moves one)");
     }
@@ -2230,9 +2230,9 @@ spf_status pool_submit_v(spf_pool* top, int op, const spf_value* const* vals, si
     const spf_status st = leaf->submit_v(op, v, res, ticket, param);
     if (st != SPF_OK) {
         res->release();
-        return st;
+        return st == SPF_ERR_INVALID_ARGUMENT ? fail(top->ctx, st, "pool operation by handle: refused (pool closing, or an operand's producing operation failed)") : st;
     }
-    if (leaf != top) *ticket |= (uint64_t)member << spf_pool::kMemberShift;
+    if (leaf != top && ticket) *ticket |= (uint64_t)member << spf_pool::kMemberShift;
     *out = res;
     return SPF_OK;
 }
@@ -2407,6 +2407,16 @@ spf_status spf_value_download(const spf_value* v, void* host)
     spf_value_impl::Arena::DeviceScope ds(v->arena->device);
     if (!ds.ok || hipMemcpy(host, v->ptr(), v->bytes, hipMemcpyDeviceToHost) != hipSuccess) return SPF_ERR_HIP;
     return SPF_OK;
+}
+
+spf_status spf_value_wait(const spf_value* v)
+{
+    if (!v) return SPF_ERR_INVALID_ARGUMENT;
+    // (a value may outlive its pool, a PENDING one cannot: spf_pool_destroy drains every batch first)
+    const int st = v->state.load(std::memory_order_acquire);
+    if (st == spf_value_impl::READY) return SPF_OK;
+    if (st == spf_value_impl::FAILED) return SPF_ERR_HIP;
+    return v->home ? v->home->wait_value(v) : SPF_ERR_INVALID_ARGUMENT;
 }
 
 spf_status spf_value_retain(spf_value* v)

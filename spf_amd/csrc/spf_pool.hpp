@@ -46,6 +46,8 @@
 #include "../../include/spf_hip.h"
 
 #include <algorithm>
+#include <map>
+#include <tuple>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -168,6 +170,13 @@ struct Batch {
     uint64_t param = 0;           // SampleExtract index / MulXN amount: one value per batch (a different one opens a new batch)
     bool closed = false, done = false;
     bool kernels_done = false;    // its kernels have left the GPU (the device-to-host copy may still run): the next batch may go
+    // Deferred batches (by handle, operands that are still PENDING results of this pool): not in `filling` but in the pool's
+    // `deferred` table under (depth, kind, parameter); `depth` = 1 + the deepest batch an operand comes from, so launching in
+    // depth order is a topological order; `deps` = the batches the operands come from (the set's stream waits for their events);
+    // the staging set is taken when the batch is launched, not when it is opened (a circuit has more levels than there are sets)
+    bool deferred = false;
+    int64_t depth = 0;
+    std::vector<std::shared_ptr<Batch>> deps;
     // The outputs leave the GPU in up to kMaxChunks copies (each a multiple of kWordSlots slots, all but the last equal), each with
     // its own event.  The waiters sleep on the word of their slot group (futex, 0 -> 1 when the group's bytes are in pinned
     // memory or the batch failed): the callers of the first chunk copy out and come back while the later chunks are still
@@ -313,6 +322,10 @@ struct spf_pool {
     std::atomic<uint64_t> work_epoch{0};  // bumped whenever the launcher has something new to look at
     std::atomic<bool> launcher_asleep{false};
     std::vector<std::shared_ptr<Batch>> polling; // the launcher's own: cheap batches by handle it enqueued and completes itself
+    // by handle, operations on PENDING operands: open batches by (depth, kind, parameter) — see Batch::deferred, flush_deferred
+    std::map<std::tuple<int64_t, int, uint64_t>, std::shared_ptr<Batch>> deferred;
+    std::chrono::steady_clock::time_point t_last_deferred{};
+    uint64_t n_deferred_ops = 0;
     uint64_t n_shape[3] = {0, 0, 0};      // bootstrap launches by blind-rotation shape: eight waves per ciphertext / two / four per workgroup
     hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
@@ -473,8 +486,8 @@ struct spf_pool {
         const void* src[3] = {a, b_in, c};
         return submit_impl(op, false, src, out, nullptr, nullptr, ticket, param);
     }
-    // by handle: `v` are ready values of this pool (checked by the caller, pool_submit_v); *result is a new value that becomes
-    // valid when spf_pool_wait returns SPF_OK for the ticket
+    // by handle: `v` are values of this pool, valid or still pending (checked by the caller, pool_submit_v); *result is a new value
+    // that becomes valid when its batch has run (spf_pool_wait for the ticket, or spf_value_wait); `ticket` may be null
     spf_status submit_v(int op, spf_value* const* v, spf_value* result, uint64_t* ticket, uint64_t param = 0)
     {
         return submit_impl(op, true, nullptr, nullptr, v, result, ticket, param);
@@ -517,10 +530,58 @@ struct spf_pool {
         const int lane = lane_of(op, by_handle, grp);
         const int kind = (by_handle ? N_OPS : 0) + op;
         std::shared_ptr<Batch> b;
-        for (;;) {
+        // By handle an operand may be the PENDING result of an earlier submit to this pool (its batch open, closed or running): the
+        // operation is then DEFERRED — it joins the open batch of its (depth, kind, parameter), depth = 1 + the deepest batch an
+        // operand comes from.  Nothing is launched for it until flush_deferred: a whole circuit pushed by one thread without a
+        // single wait becomes one batch per kind and level, launched in depth order, each ordered behind the batches its operands
+        // come from by their events — the level batching of spf_graph_run, built while the operations arrive.
+        std::shared_ptr<Batch> dep[3];
+        int n_dep = 0;
+        if (by_handle) {
+            int64_t depth = 0;
+            for (int k = 0; k < 3; k++) {
+                if (!vin[k]) continue;
+                const int vs = vin[k]->state.load(std::memory_order_acquire);
+                if (vs == spf_value_impl::READY) continue;
+                if (vs == spf_value_impl::FAILED) return SPF_ERR_INVALID_ARGUMENT;
+                const std::shared_ptr<Batch>& p = vin[k]->producer; // (set and cleared under `mu`)
+                if (!p || p->done) continue; // its batch is being handed back right now: the kernels have run
+                depth = std::max(depth, p->depth + 1);
+                bool seen = false;
+                for (int j = 0; j < n_dep; j++) seen = seen || dep[j] == p;
+                if (!seen) dep[n_dep++] = p;
+            }
+            if (n_dep) {
+                const auto key = std::make_tuple(depth, op, param);
+                try {
+                    auto it = deferred.find(key);
+                    if (it != deferred.end()) b = it->second;
+                    else {
+                        const size_t cap = std::min(batch_cap(op), std::max<size_t>(cap_hint[kind], 64));
+                        b = std::make_shared<Batch>();
+                        b->slots.resize(cap);
+                        const size_t ng = cap / Batch::kTreeGroup + 1;
+                        b->gword.reset(new std::atomic<uint32_t>[ng]);
+                        b->gwoken.reset(new std::atomic<uint32_t>[ng]);
+                        for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); }
+                        b->op = op; b->set = -1; b->cap = cap; b->lane = lane; b->param = param; b->by_handle = true;
+                        b->deferred = true; b->depth = depth;
+                        const bool first = deferred.empty();
+                        deferred.emplace(key, b);
+                        if (first) poke(); // (the launcher arms the quiet time that flushes the table)
+                    }
+                    for (int j = 0; j < n_dep; j++)
+                        if (std::find(b->deps.begin(), b->deps.end(), dep[j]) == b->deps.end()) b->deps.push_back(dep[j]);
+                } catch (const std::exception&) {
+                    return SPF_ERR_HIP;
+                }
+            }
+        }
+        while (!b) {
             b = filling[lane];
             if (b && b->param != param) { // (SampleExtract index / MulXN amount: the kernels take one value per launch)
                 close_batch(lane);
+                b.reset();
                 continue;
             }
             if (b) break; // (a batch leaves `filling` the moment it is closed: what is there has room)
@@ -570,8 +631,8 @@ struct spf_pool {
             break;
         }
         const size_t slot = b->n;
-        const uint64_t my_ticket = next_ticket;
-        b->slots[slot] = Slot{out, my_ticket, 0, who, 0, {nullptr, nullptr, nullptr}, nullptr};
+        const uint64_t my_ticket = ticket ? next_ticket : 0; // (0: nobody will wait for this operation — spf_value_wait on its result instead)
+        b->slots[slot] = Slot{out, my_ticket, 0, who, (uint8_t)(ticket ? 0 : 2), {nullptr, nullptr, nullptr}, nullptr};
         // a caller "comes back" when it submits with nothing else outstanding (the synchronous pattern); a thread that
         // submits many tickets before it waits for any is not waited for — its batches close on the timer or when full.
         // (Only where batches are closed by who is back: not for the cheap kinds by handle.)
@@ -585,39 +646,50 @@ struct spf_pool {
                 return SPF_ERR_HIP;
             }
         }
-        if (heavy(op)) heavy_open++;
-        n_open++;
+        if (heavy(op)) heavy_open++; // (taken back by spf_pool_wait, or — no ticket — when the batch is handed back)
+        if (ticket) n_open++;
         if (by_handle) { // the operands stay alive until the batch has run; the batch holds its own reference to the result
             Slot& sl = b->slots[slot];
             for (int k = 0; k < 3; k++)
                 if (vin[k]) { vin[k]->retain(); sl.vin[k] = vin[k]; }
             vout->retain();
             sl.vout = vout;
+            vout->producer = b;
+            vout->slot = (uint32_t)slot;
         }
         b->t_last = std::chrono::steady_clock::now();
         if (b->n == 0) b->t0 = b->t_last;
         b->n++;
-        *ticket = next_ticket++;
-        if (b->n == b->cap) {
+        if (ticket) *ticket = next_ticket++;
+        if (b->deferred) {
+            n_deferred_ops++;
+            t_last_deferred = b->t_last;
+            if (b->n == b->cap) { // full: it goes now, and with it everything it may depend on
+                cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap);
+                flush_deferred();
+            }
+        } else if (b->n == b->cap) {
             cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
             close_batch(lane);
-        } else if (by_handle && heavy(op) && b->n * split >= std::max(heavy_population(b->t_last), n_open.load())) {
+        } else if (by_handle && heavy(op) && ticket && b->n * split >= std::max(heavy_population(b->t_last), n_open.load())) {
             // By handle a caller is back microseconds after its result (nothing to copy out), so the callers need no dealing into
             // groups that meet again: a bootstrap batch simply goes as soon as it holds a quarter of the callers in the pool
             // (all callers count, whatever they are waiting for: the conversions of a circuit's inputs arrive out of its keyswitch
             // batches; or nobody has joined it for max_wait), on the workgroup shape of the whole population — up to four or five
             // batches tile the CUs side by side, each on its set's stream, and whoever comes back meanwhile is the next one.
             // A 32-bit adder's 64 conversions are four launches within the time the callers take to arrive, not four paced
-            // quarter batches; 1 024 synchronous callers keep four batches of 256 in flight.
+            // quarter batches; 1 024 synchronous callers keep four batches of 256 in flight.  (Operations without a ticket come from
+            // a pusher that does not block: its batches close on the quiet time.)
             close_batch(lane);
         } else if (tracks_callers && everybody_is_back(*b)) {
             poke(); // the launcher need not wait for more
         }
         if (by_handle) { // nothing to copy: the slot is ready as it stands
             b->n_ready++;
-            if (slot == 0 || (b->closed && b->n_ready == b->n)) poke();
+            if (!b->deferred && (slot == 0 || (b->closed && b->n_ready == b->n))) poke();
         }
         lk.unlock();
+        if (!ticket) return SPF_OK;
         // the ticket becomes findable (by any thread) and, for this thread, findable without looking
         bool registered = true;
         {
@@ -742,6 +814,27 @@ struct spf_pool {
         poke();
     }
 
+    // `mu` held: every deferred batch is closed, shallowest first (so that `closing`, which the launcher takes in order, holds every
+    // batch behind the ones its operands come from); a batch of the ordinary lanes that an operand comes from and that is still
+    // filling is closed ahead of its first user.  Called when a deferred batch is full, when somebody waits for a result that
+    // sits in one (spf_pool_wait, spf_value_wait), when nothing has been deferred for the quiet time (launcher), at destroy.
+    void flush_deferred()
+    {
+        if (deferred.empty()) return;
+        const auto now = std::chrono::steady_clock::now();
+        for (auto& kv : deferred) {
+            std::shared_ptr<Batch>& b = kv.second;
+            for (auto& d : b->deps)
+                if (!d->deferred && !d->closed && filling[d->lane] == d) close_batch(d->lane);
+            b->closed = true;
+            b->t_close = now;
+            outstanding[b->lane]++;
+            closing.push_back(b);
+        }
+        deferred.clear();
+        poke();
+    }
+
     // `mu` held.  Deliver the uncollected outputs of done batches that have waited longer than the grace period.
     void reclaim(std::unique_lock<Mutex>& lk)
     {
@@ -801,6 +894,10 @@ struct spf_pool {
         }
         // sleep on the batch's own word: no pool-wide condition variable, no mutex on the way out
         const bool is_heavy = heavy(b->op);
+        if (b->deferred) { // somebody wants a result of the deferred table: everything pushed so far goes
+            std::lock_guard<Mutex> lk(mu);
+            if (!b->closed) flush_deferred();
+        }
         if (b->by_handle) {
             const size_t g = slot / Batch::kTreeGroup;
             std::atomic<uint32_t>& word = b->gword[g];
@@ -855,6 +952,28 @@ struct spf_pool {
             cv_space.notify_all();
         }
         return st;
+    }
+
+    // spf_value_wait: until the value's batch has been handed back (any number of threads, any number of times; no ticket involved)
+    spf_status wait_value(const spf_value* v)
+    {
+        using namespace spf_pool_impl;
+        if (v->state.load(std::memory_order_acquire) == spf_value_impl::PENDING) {
+            blocked++;
+            struct Leave { spf_pool* p; ~Leave() { if (--p->blocked == 0 && p->stop) { std::lock_guard<Mutex> g(p->mu); p->cv_idle.notify_all(); } } } leave{this};
+            std::shared_ptr<Batch> b;
+            {
+                std::lock_guard<Mutex> lk(mu);
+                b = v->producer;
+                if (b && b->deferred && !b->closed) flush_deferred();
+            }
+            if (b) {
+                std::atomic<uint32_t>& word = b->gword[v->slot / Batch::kTreeGroup];
+                while (word.load(std::memory_order_acquire) == 0) futex_wait(&word, 0);
+            }
+        }
+        const int st = v->state.load(std::memory_order_acquire);
+        return st == spf_value_impl::READY ? SPF_OK : (st == spf_value_impl::FAILED ? SPF_ERR_HIP : SPF_ERR_INVALID_ARGUMENT);
     }
 
     // ---- launcher: closes batches and enqueues them
@@ -1013,16 +1132,31 @@ struct spf_pool {
     void finish_handle_batch(const std::shared_ptr<Batch>& b)
     {
         using namespace spf_pool_impl;
+        // a batch whose operands came from a batch that failed has computed on nothing: it fails with that status (the stream order
+        // puts the producers' completion before this batch's; `deps` is this thread's from here on: the launcher is done with it)
+        for (auto& d : b->deps)
+            if (b->st == SPF_OK && d->st != SPF_OK) b->st = d->st.load();
         const int state = b->st == SPF_OK ? spf_value_impl::READY : spf_value_impl::FAILED;
+        size_t no_ticket_heavy = 0;
+        for (size_t i = 0; i < b->n; i++) { // (the state first: a submit that still sees PENDING under the mutex finds `producer` set)
+            b->slots[i].vout->state.store(state, std::memory_order_release);
+            no_ticket_heavy += (b->slots[i].ticket == 0 && heavy(b->op)) ? 1 : 0;
+        }
+        {
+            std::lock_guard<Mutex> lk(mu);
+            for (size_t i = 0; i < b->n; i++) b->slots[i].vout->producer.reset();
+        }
         for (size_t i = 0; i < b->n; i++) { // (outside the lock: the last reference to a value gives its block back to the arena)
             Slot& sl = b->slots[i];
-            sl.vout->state.store(state, std::memory_order_release);
             sl.vout->release();
             sl.vout = nullptr;
             for (spf_value*& v : sl.vin)
                 if (v) { v->release(); v = nullptr; }
         }
         b->out_blk.reset();
+        b->deps.clear();
+        for (size_t h = heavy_open.load(); no_ticket_heavy && h;) // (operations without a ticket leave the population here)
+            if (heavy_open.compare_exchange_weak(h, h - std::min(h, no_ticket_heavy))) break;
         {
             std::lock_guard<Mutex> lk(mu);
             last_gpu_span[b->op] = b->t_sync - b->t_enq;
@@ -1088,9 +1222,20 @@ struct spf_pool {
             // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in (the first one that can go:
             // a batch whose members are still copying does not hold up the ones behind it)
             std::shared_ptr<Batch> go;
+            bool no_set_for_deferred = false;
             for (auto it = closing.begin(); it != closing.end(); ++it) {
                 Batch& b = **it;
                 if (b.n_ready < b.n) continue; // (submit wakes this thread when the last input is in)
+                if (b.deferred && b.set < 0) {
+                    // a deferred batch takes its staging set now (stream, pointer table, intermediates); when every set is held it
+                    // waits — and so does every deferred batch behind it: they go in the order they were closed (depth order)
+                    if (no_set_for_deferred) continue;
+                    int set = -1;
+                    for (int i = 0; i < n_sets; i++) if (!sets[i].busy) { set = i; break; }
+                    if (set < 0) { no_set_for_deferred = true; continue; } // (a batch that is handed back pokes this thread)
+                    sets[set].busy = true;
+                    b.set = set;
+                }
                 // Pacing of the bootstrap kinds: resident batches that start together also finish together — their copies out
                 // queue behind each other and their callers come back in one crowd, i.e. they behave as ONE big batch and the GPU
                 // idles through the common turn-around.  A batch therefore starts no sooner than a 1 / groups share of a batch's
@@ -1116,10 +1261,22 @@ struct spf_pool {
                     const size_t n_cu = (size_t)ctx->n_cu;
                     n_shape[(b->n <= n_cu && b->per_wg <= 1) ? 0 : ((b->n <= 2 * n_cu && b->per_wg <= 2) ? 1 : 2)]++;
                 }
+                // the batches its operands come from: enqueued before it (they were closed before it), possibly on other sets'
+                // streams — its own stream waits for their events; one that has failed fails it
+                spf_status st = SPF_OK;
+                if (!b->deps.empty()) {
+                    if (hipSetDevice(ctx->device) != hipSuccess) st = SPF_ERR_HIP;
+                    for (auto& d : b->deps) {
+                        if (st != SPF_OK) break;
+                        if (d->st != SPF_OK) st = d->st.load();
+                        else if (d->done) continue;
+                        else if (!d->ev_k || hipStreamWaitEvent(sets[b->set].sk, d->ev_k, 0) != hipSuccess) st = SPF_ERR_HIP;
+                    }
+                }
                 lk.unlock();
-                spf_status st;
                 try {
-                    st = enqueue(*b);
+                    if (st == SPF_OK && b->deferred && !prepare_set(sets[b->set], b->op, b->cap, true)) st = SPF_ERR_HIP;
+                    if (st == SPF_OK) st = enqueue(*b);
                 } catch (const std::exception&) {
                     st = SPF_ERR_HIP;
                 }
@@ -1169,7 +1326,16 @@ struct spf_pool {
                 continue;
             }
             if (lane >= 0) wake = std::min(wake, best);
-            if (stop && closing.empty() && polling.empty() && lane < 0) return;
+            // the deferred table goes when nothing has joined it for the quiet time (a pusher that does not wait for anything)
+            if (!deferred.empty()) {
+                const auto due = stop ? now : t_last_deferred + std::chrono::duration_cast<clock::duration>(max_wait);
+                if (now >= due) {
+                    flush_deferred();
+                    continue;
+                }
+                wake = std::min(wake, due);
+            }
+            if (stop && closing.empty() && polling.empty() && lane < 0 && deferred.empty()) return;
             // 3. nothing to do right now.  While cheap operations by handle are in flight or were a moment ago, poll (the event
             // of a 15 us kernel, the next level's submits): going to sleep costs a wake-up per circuit level.  Otherwise sleep
             // until the next deadline or the next poke.

@@ -23,6 +23,10 @@
 #include <memory>
 #include <mutex>
 
+namespace spf_pool_impl {
+struct Batch; // spf_pool.hpp: the batch that will produce a pending value
+}
+
 namespace spf_value_impl {
 
 struct Arena : std::enable_shared_from_this<Arena> {
@@ -172,6 +176,10 @@ struct spf_value {
     std::shared_ptr<spf_value_impl::Block> blk; // set at upload, or when the producing batch is enqueued
     size_t off = 0;
     std::atomic<int> state{spf_value_impl::PENDING};
+    // a PENDING result: the batch that produces it and its slot there (set and cleared under the pool's mutex; a later operation
+    // of the same pool may take the value as an operand right away and is ordered behind that batch — spf_pool.hpp, "deferred")
+    std::shared_ptr<spf_pool_impl::Batch> producer;
+    uint32_t slot = 0;
     void* ptr() const { return static_cast<char*>(blk->p) + off; }
     bool ready() const { return state.load(std::memory_order_acquire) == spf_value_impl::READY; }
     void retain() { refs.fetch_add(1, std::memory_order_relaxed); }

@@ -127,10 +127,12 @@ def test_misuse_is_an_error_not_a_read_of_unfinished_data(rig):
             other.submit_v(FheOp.Not, [a])
         pending, ticket = pool.submit_v(FheOp.KeyswitchL1toL0, [lwe1])
         assert pending.info()["valid"] is False
-        with pytest.raises(spf_amd.SpfError):   # not waited for yet: refused, not read
-            pool.submit_v(FheOp.CircuitBootstrap, [pending])
-        with pytest.raises(spf_amd.SpfError):
+        with pytest.raises(spf_amd.SpfError):   # not run yet: reading it is refused, not a read of unfinished data
             pending.download()
+        with pytest.raises(spf_amd.SpfError):
+            pending.device_ptr()
+        with pytest.raises(spf_amd.SpfError):   # ... and another pool will not order itself behind this one
+            other.submit_v(FheOp.CircuitBootstrap, [pending])
         lwe1.release()                          # an operand may go as soon as the submit has returned
         pool.wait(ticket)
         assert pending.info()["valid"] is True
@@ -148,6 +150,121 @@ def test_misuse_is_an_error_not_a_read_of_unfinished_data(rig):
         gc.collect()
         pool.close()
         other.close()
+
+
+def test_pending_results_as_operands_a_chain_pushed_without_a_wait(rig):
+    """Deferred operands (include/spf_hip.h): a result that is still pending is an operand of the next submit; the pool orders the
+    batches on the device and launches what was pushed when somebody waits for a result.  A whole chain — SampleExtract ->
+    KeyswitchL1toL0 -> CircuitBootstrap -> CMux(sel, Not(a), GlweAdd(a, b)) -> CMux again — is pushed from ONE thread for twelve
+    independent inputs without a single wait and without tickets, then only the last values are waited for: every word equals
+    the operation-by-operation entry points, the pushed operations of a kind and level ran as ONE launch each, and a chain on a
+    failing producer fails as a whole."""
+    ks, eng, _ = rig
+    P = ks.params
+    n = 12
+    a, b = random_glwe(301, n, P.glwe_len), random_glwe(302, n, P.glwe_len)
+    x = random_glwe(303, n, P.glwe_len)
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=100000)   # (a long quiet time: only the waits below launch anything)
+    try:
+        va, vb, vx = pool.upload_batch(ValueKind.GLWE1, a), pool.upload_batch(ValueKind.GLWE1, b), pool.upload_batch(ValueKind.GLWE1, x)
+        c0 = pool.counters()
+        last, mid = [], []
+        for i in range(n):
+            se = pool.push_v(FheOp.SampleExtract, [vx[i]], 3)          # operands valid: an ordinary batch, still open
+            l0 = pool.push_v(FheOp.KeyswitchL1toL0, [se])              # pending operand: deferred, depth 1
+            sel = pool.push_v(FheOp.CircuitBootstrap, [l0])            # depth 2
+            nt = pool.push_v(FheOp.Not, [va[i]])
+            ad = pool.push_v(FheOp.GlweAdd, [va[i], vb[i]])
+            m1 = pool.push_v(FheOp.CMux, [sel, nt, ad])                # depth 3
+            m2 = pool.push_v(FheOp.CMux, [sel, m1, pool.push_v(FheOp.MulXN, [m1], 5)])   # depth 5 (MulXN at 4)
+            assert not m2.info()["valid"]
+            mid.append(m1)
+            last.append(m2)
+        got2 = [v.wait().download() for v in last]                     # the first wait launches everything pushed so far
+        got1 = [v.download() for v in mid]                             # valid: they ran before their users
+        c1 = pool.counters()
+        assert c1["handle_ops"] - c0["handle_ops"] == 8 * n
+        assert c1["handle_launches"] - c0["handle_launches"] == 8, c1   # one launch per kind and level
+        # a ticket for a deferred operation works like any other ticket
+        v, t = pool.submit_v(FheOp.Not, [pool.push_v(FheOp.Not, [va[0]])])
+        pool.wait(t)
+        assert np.array_equal(v.download(), a[0])
+    finally:
+        import gc
+        gc.collect()
+        pool.close()
+    e_sel = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(eng.sample_extract_l1(x, 3)))
+    e_m1 = eng.cmux(e_sel, eng.glwe_not(a), eng.glwe_xor(a, b))
+    e_m2 = eng.cmux(e_sel, e_m1, eng.glwe_mul_xn(e_m1, 5))
+    for i in range(n):
+        assert np.array_equal(got1[i], e_m1[i]), i
+        assert np.array_equal(got2[i], e_m2[i]), i
+        assert np.array_equal(got1[i], O.cmux(O.glwe_not(a[i], P.N, P.k), O.glwe_xor(a[i], b[i], P.N, P.k), e_sel[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
+
+    # a producer that fails (no keys in this context): everything pushed behind it fails with it, nothing is read, the pool goes on
+    bare = spf_amd.Engine(to_engine_params(P))
+    pool = spf_amd.Pool(bare, max_batch=16, max_wait_us=100000)
+    try:
+        g = pool.upload(ValueKind.GLWE1, a[0])
+        l0 = pool.push_v(FheOp.KeyswitchL1toL0, [pool.push_v(FheOp.SampleExtract, [g], 0)])   # no keyswitch key: this batch fails
+        sel = pool.push_v(FheOp.CircuitBootstrap, [l0])
+        out = pool.push_v(FheOp.CMux, [sel, g, g])
+        with pytest.raises(spf_amd.SpfError):
+            out.wait()
+        assert not out.info()["valid"] and not sel.info()["valid"] and not l0.info()["valid"]
+        with pytest.raises(spf_amd.SpfError):
+            pool.push_v(FheOp.Not, [out])                                # an operand whose producer failed is refused
+        assert np.array_equal(pool.push_v(FheOp.Not, [g]).wait().download(), O.glwe_not(a[0], P.N, P.k))
+    finally:
+        import gc
+        gc.collect()
+        pool.close()
+        bare.close()
+
+
+def test_reference_adder_pushed_from_one_thread_without_waits():
+    """`mux_circuits::add::ripple_carry_adder(32, 32, false)`: all 1 871 operations pushed by ONE native thread in the order the
+    reference's processor would make them ready (level by level), no ticket, no wait; then the 33 outputs are waited for
+    (tools/pool_driver.cpp: spf_circuit_push).  Word-equal to spf_graph_run of the same circuit, and the pool made about one
+    launch per kind and level; afterwards no value is left alive."""
+    import tools.driver as drv
+    from spf_amd.gate_pool import circuit_jobs_as_one_graph
+    from spf_amd.mux_circuits import ripple_carry_adder
+    ks = keyset(0x5EED0002, SMALL_N)
+    P = ks.params
+    r = O.Rng(0x7A12)
+    eng = spf_amd.Engine(to_engine_params(P))
+    eng.load_bootstrap_key(ks.bsk_fft)
+    eng.load_keyswitch_key(ks.ksk)
+    eng.load_automorphism_key(O.gen_auto_key_fft(r, ks.glwe_sk, P))
+    eng.load_scheme_switch_key(O.gen_ssk_fft(r, ks.glwe_sk, P))
+    A, B = 0x9E3779B9, 0x7F4A7C15
+    cts = _adder_inputs(ks, r, A, B)[None]
+    rec, _ = circuit_jobs_as_one_graph(eng, ripple_carry_adder(32, 32, False), cts, record=True)
+    g, g_outs = rec.lower(eng)
+    g.run()
+    st = g.stats()
+    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=50)
+    try:
+        c0 = pool.counters()
+        outs, inner, whole = drv.push_circuit_by_handles(pool, rec)
+        c1 = pool.counters()
+        assert len(outs) == 33 and all(np.array_equal(x, y) for x, y in zip(outs, g_outs))
+        total = 0
+        for i, o in enumerate(outs):
+            total |= int(O.decode(O.decrypt_glwe_raw(o, ks.glwe_sk, P.N, P.k)[0], 1)) << i
+        assert total == A + B
+        n_ops = c1["handle_ops"] - c0["handle_ops"]
+        n_l = c1["handle_launches"] - c0["handle_launches"]
+        assert n_ops == len([o for o in rec.op if o >= 0])
+        assert n_l <= 3 * st["launches"], (n_l, st)     # level batches, not one launch per operation
+        import gc
+        gc.collect()
+        vs = pool.value_stats()
+        assert vs["live_values"] == 0 and vs["live_bytes"] == 0, vs
+    finally:
+        pool.close()
+        g.close()
 
 
 def _adder_inputs(ks, r, a, b):

@@ -37,6 +37,8 @@ def load():
     d.spf_pool_drive_cmux.argtypes = [P, P, P, C.c_int, C.c_int, C.c_double, P, C.c_size_t, P, P, C.c_size_t, D]
     d.spf_pool_drive_cmux_v.restype = C.c_long
     d.spf_pool_drive_cmux_v.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_double, P, P, P, D]
+    d.spf_circuit_push.restype = C.c_int
+    d.spf_circuit_push.argtypes = [P, P, P, P, C.c_uint32, P, P, P, P, P, P, P, C.c_uint32, P, C.c_uint32, D]
     d.spf_circuit_drive.restype = C.c_int
     d.spf_circuit_drive.argtypes = [P, P, P, P, C.c_int, C.c_uint32, P, P, P, P, P, P, D]
     _DRV = d
@@ -114,6 +116,59 @@ def run_circuit_by_handles(pool, rec, threads=64, member=-1, vals=None):
         outs = list(pool.download_batch(order))
     else:
         outs = [v.download() for v in order]
+    t_down = time.perf_counter() - t0
+    for v in kept.values():
+        v.release()
+    for v in vals:
+        if v is not None:
+            v.release()
+    return outs, el.value, t_up + el.value + t_down
+
+
+def push_circuit_by_handles(pool, rec, member=-1):
+    """-> (outputs as arrays in rec.outputs order, seconds inside the pusher, seconds of upload + pusher + download).  ONE native
+    thread submits every operation of the circuit without a ticket and without a wait, level by level (operands that are still
+    pending: include/spf_hip.h "Deferred operands"), then waits for the output values only."""
+    import time
+    import numpy as np
+    from spf_amd import Value
+    d = load()
+    lib = pool._lib
+    a = rec.arrays()
+    n = len(rec.op)
+    level = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        if rec.op[i] >= 0:
+            level[i] = 1 + max((level[j] for j in rec.inputs[i]), default=0)
+    order = np.array([i for i in np.argsort(level, kind="stable") if rec.op[i] >= 0], dtype=np.uint32)
+    outputs = np.array(rec.outputs, dtype=np.uint32)
+    t0 = time.perf_counter()
+    vals = upload_circuit_inputs(pool, rec, member)
+    t_up = time.perf_counter() - t0
+    table = (C.c_void_p * n)(*[(v._h if v is not None else None) for v in vals])
+    el = C.c_double()
+    st = d.spf_circuit_push(pool._h, fn(lib, "spf_pool_submit_op_v"), fn(lib, "spf_value_wait"), fn(lib, "spf_value_release"), n,
+                            a["op"].ctypes.data, a["in"].ctypes.data, a["n_in"].ctypes.data, a["param"].ctypes.data, table,
+                            a["keep"].ctypes.data, order.ctypes.data, len(order), outputs.ctypes.data, len(outputs), C.byref(el))
+    for i, v in enumerate(vals):   # inputs the pusher released must not be released again by their wrappers
+        if v is not None and not table[i]:
+            v._h = None
+    kept = {}
+    for node in rec.outputs:
+        if node not in kept:
+            kept[node] = None if not table[node] else (vals[node] if vals[node] is not None else Value(pool, C.c_void_p(table[node])))
+    if st != 0:
+        for v in kept.values():
+            if v is not None:
+                v.release()
+        raise RuntimeError(f"spf_circuit_push: status {st}")
+    order_v = [kept[node] for node in rec.outputs]
+    kinds = {rec.kind[node] for node in rec.outputs}
+    t0 = time.perf_counter()
+    if len(kinds) == 1 and len(order_v) > 1:
+        outs = list(pool.download_batch(order_v))
+    else:
+        outs = [v.download() for v in order_v]
     t_down = time.perf_counter() - t0
     for v in kept.values():
         v.release()

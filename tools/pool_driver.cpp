@@ -318,4 +318,45 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
     return error.load();
 }
 
+// The same circuit PUSHED: one thread submits every operation without a ticket and without waiting for anything, in the order
+// `order` gives (level by level: the order in which the reference's processor would see the tasks become ready if every task
+// returned at once) — the operands of a task are results that are still pending, the pool orders and batches them by level
+// (spf_hip.h, "Deferred operands") — then waits for the `n_out` output values only.  Values nobody keeps are released right after
+// the last submit that takes them (the pool holds its own references while they are needed).
+typedef spf_status (*value_wait_fn)(const spf_value*);
+int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_wait, release_fn release, uint32_t n_nodes,
+                     const int32_t* op, const uint32_t* in, const uint32_t* n_in, const uint64_t* param, spf_value** values,
+                     const uint8_t* keep, const uint32_t* order, uint32_t n_order, const uint32_t* outputs, uint32_t n_out,
+                     double* elapsed_s)
+{
+    std::vector<uint32_t> users(n_nodes, 0);
+    for (uint32_t i = 0; i < n_nodes; i++)
+        if (op[i] >= 0)
+            for (uint32_t k = 0; k < n_in[i]; k++) users[in[3 * i + k]]++;
+    const auto t0 = std::chrono::steady_clock::now();
+    int error = 0;
+    for (uint32_t j = 0; j < n_order && !error; j++) {
+        const uint32_t node = order[j];
+        const spf_value* operands[3] = {nullptr, nullptr, nullptr};
+        for (uint32_t k = 0; k < n_in[node]; k++) operands[k] = values[in[3 * node + k]];
+        spf_value* out = nullptr;
+        const spf_status st = submit(pool, (spf_graph_op)op[node], operands, n_in[node], param[node], &out, nullptr);
+        if (st != SPF_OK) { error = st; break; }
+        values[node] = out;
+        for (uint32_t k = 0; k < n_in[node]; k++) {
+            const uint32_t src = in[3 * node + k];
+            if (--users[src] == 0 && !keep[src] && values[src]) { release(values[src]); values[src] = nullptr; }
+        }
+    }
+    for (uint32_t j = 0; j < n_out && !error; j++) {
+        const spf_status st = value_wait(values[outputs[j]]);
+        if (st != SPF_OK) error = st;
+    }
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t i = 0; i < n_nodes; i++) // (what never found its last user: unused results, or everything after a failure)
+        if (op[i] >= 0 && !keep[i] && values[i]) { release(values[i]); values[i] = nullptr; }
+    return error;
+}
+
+
 }
