@@ -1138,6 +1138,31 @@ def _bench_pool_by_handle(eng, P, dev, torch, thread_counts=(64, 256, 1024), sec
             finally:
                 pool.close()
             out["cmux"].append(row)
+        # ... and PUSHED: bursts of gates without tickets, two bursts in flight per thread, the values of a burst waited for before
+        # its slots are reused (tools/pool_driver.cpp spf_pool_push_cmux_v)
+        for T, burst in (((1, 2048), (4, 1024)) if cmux_cases else ()):
+            pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=20)
+            try:
+                vs = pool.upload_batch(3, np.tile(sel.view(np.complex128), (T, 1)))
+                va = pool.upload_batch(2, np.tile(a, (T, 1)))
+                vb = pool.upload_batch(2, np.tile(b, (T, 1)))
+                hs, ha, hb = drvmod.handles(vs), drvmod.handles(va), drvmod.handles(vb)
+                el = C.c_double()
+                argp = (pool._h, drvmod.fn(lib, "spf_pool_submit_cmux_v"), drvmod.fn(lib, "spf_value_wait"), release, T, burst)
+                drv.spf_pool_push_cmux_v(*argp, 0.3, hs, ha, hb, C.byref(el))
+                c1 = pool.counters()
+                n = drv.spf_pool_push_cmux_v(*argp, seconds, hs, ha, hb, C.byref(el))
+                c2 = pool.counters()
+                if n < 0:
+                    raise RuntimeError("pool driver: a pushed CMux failed")
+                for v in vs + va + vb:
+                    v.release()
+            finally:
+                pool.close()
+            host_rate = out["cmux"][0]["host_pointer_gates_per_s"]
+            out["cmux"].append({"threads": T, "pushed_burst": burst, "by_handle_gates_per_s": round(n / el.value, 1),
+                                "by_handle_achieved_batch": round((c2["handle_ops"] - c1["handle_ops"]) / max(1, c2["handle_launches"] - c1["handle_launches"]), 1),
+                                "by_handle_over_host_pointer": round(n / el.value / host_rate, 2)})
         for T in thread_counts:
             d_in = torch.randint(-(2 ** 63), 2 ** 63 - 1, (T, P.lwe1_words), device=dev, dtype=torch.int64)
             d_mid = torch.empty((T, P.lwe0_words), device=dev, dtype=torch.int64)
@@ -1213,12 +1238,31 @@ def _bench_add32_by_handles(eng, P, threads=64, reps=5):
             c1 = pool.counters()
         finally:
             pool.close()
+        # the same DAG PUSHED by ONE thread: every operation one spf_pool_submit_op_v without a ticket, operands that are still
+        # pending, no wait until the outputs (spf_value_wait) — include/spf_hip.h "Deferred operands", tools/pool_driver.cpp
+        # spf_circuit_push.  (A long quiet time: the wait for the outputs launches what was pushed.)
+        pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=1000)
+        try:
+            for _ in range(3):      # (the sets' pointer tables and the batch sizes grow to the circuit's levels)
+                outs, _, _ = drvmod.push_circuit_by_handles(pool, rec)
+            same_p = all(np.array_equal(x, y) for x, y in zip(outs, g_outs))
+            p0 = pool.counters()
+            best_p = (1e9, 1e9)
+            for _ in range(reps):
+                _, inner, whole = drvmod.push_circuit_by_handles(pool, rec)
+                best_p = min(best_p, (whole, inner))
+            p1 = pool.counters()
+        finally:
+            pool.close()
     g.close()
     return {"threads": threads, "operations": (c1["handle_ops"] - c0["handle_ops"]) // reps,
             "launches": round((c1["handle_launches"] - c0["handle_launches"]) / reps, 1),
             "ms_per_add_by_handles": round(best[0] * 1e3, 3), "ms_inside_the_driver": round(best[1] * 1e3, 3),
             "ms_per_add_as_one_graph": round(best_g * 1e3, 3), "by_handles_over_graph": round(best[0] / best_g, 2),
-            "word_equal_to_the_graph": bool(same)}
+            "word_equal_to_the_graph": bool(same),
+            "pushed": {"threads": 1, "launches": round((p1["handle_launches"] - p0["handle_launches"]) / reps, 1),
+                       "ms_per_add": round(best_p[0] * 1e3, 3), "ms_inside_the_pusher": round(best_p[1] * 1e3, 3),
+                       "over_graph": round(best_p[0] / best_g, 2), "word_equal_to_the_graph": bool(same_p)}}
 
 
 def _bench_mul8_pool(eng, P, rank, world, per_gpu=8):

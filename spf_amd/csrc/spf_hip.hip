@@ -1919,12 +1919,12 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     if (const char* e = getenv("SPF_POOL_SPLIT")) p->split = (size_t)std::min(std::max(1, atoi(e)), 16);
     if (const char* e = getenv("SPF_POOL_SPIN_US")) p->spin_us = std::max(0, atoi(e));
     if (const char* e = getenv("SPF_POOL_HOT_US")) p->hot_us = std::max(0, atoi(e)); // (0: the launcher never polls; completers complete every batch)
-    bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking) == hipSuccess;
+    bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_def, hipStreamNonBlocking) == hipSuccess;
     for (auto& set : p->sets)
         streams_ok = streams_ok && hipStreamCreateWithFlags(&set.sk, hipStreamNonBlocking) == hipSuccess;
     if (!streams_ok) {
         p->free_sets();
-        if (p->s_in) (void)hipStreamDestroy(p->s_in);
+        if (p->s_def) (void)hipStreamDestroy(p->s_def);
         delete p;
         return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the pool's streams");
     }
@@ -1993,7 +1993,7 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         for (auto& t : p->completers)
             if (t.joinable()) t.join();
         p->free_sets();
-        (void)hipStreamDestroy(p->s_in);
+        (void)hipStreamDestroy(p->s_def);
         delete p;
         return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the pool threads: ") + e.what());
     }
@@ -2046,7 +2046,7 @@ void spf_pool_destroy(spf_pool* p)
             b->destroy_events();
     }
     p->free_sets();
-    (void)hipStreamDestroy(p->s_in);
+    (void)hipStreamDestroy(p->s_def);
     if (p->arena) p->arena->close(); // cached blocks go back to the driver; values still alive free theirs when they are released
     delete p;
 }

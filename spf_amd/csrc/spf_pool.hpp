@@ -213,16 +213,24 @@ struct Batch {
     // batch's 5.8 ms cycle); the tree is three levels deep.  The completing thread also walks all groups in order and wakes what
     // nobody has woken yet, so a waiter that never comes (an abandoned ticket) leaves no group asleep.
     static constexpr size_t kTreeGroup = 8;
-    std::unique_ptr<std::atomic<uint32_t>[]> gword, gwoken; // by handle: [cap / 8 + 1]
+    std::unique_ptr<std::atomic<uint32_t>[]> gword, gwoken, gsleep; // by handle: [cap / 8 + 1]
     size_t n_groups() const { return (n + kTreeGroup - 1) / kTreeGroup; }
+    // a waiter announces itself in gsleep before it looks at the word for the last time; the waker sets the word before it looks at
+    // gsleep (both sequentially consistent): a group nobody sleeps on costs no system call — operations pushed without a ticket have
+    // no waiters at all, and a batch of 400 of them was 50 futex calls of ~2 us on the launcher's critical path
+    void sleep_on_group(size_t g)
+    {
+        gsleep[g].fetch_add(1, std::memory_order_seq_cst);
+        while (gword[g].load(std::memory_order_seq_cst) == 0) futex_wait(&gword[g], 0);
+    }
     void wake_group(size_t g)
     {
-        if (gwoken[g].exchange(1, std::memory_order_acq_rel) == 0) futex_wake_all(&gword[g]);
+        if (gwoken[g].exchange(1, std::memory_order_acq_rel) == 0 && gsleep[g].load(std::memory_order_seq_cst) != 0) futex_wake_all(&gword[g]);
     }
     void wake_tree() // by the thread that completed the batch (n is final)
     {
         const size_t ng = n_groups();
-        for (size_t g = 0; g < ng; g++) gword[g].store(1, std::memory_order_release);
+        for (size_t g = 0; g < ng; g++) gword[g].store(1, std::memory_order_seq_cst);
         for (size_t g = 0; g < ng; g++) wake_group(g);
     }
     void wake_chunk(int i) // the words of copy i
@@ -324,10 +332,15 @@ struct spf_pool {
     std::vector<std::shared_ptr<Batch>> polling; // the launcher's own: cheap batches by handle it enqueued and completes itself
     // by handle, operations on PENDING operands: open batches by (depth, kind, parameter) — see Batch::deferred, flush_deferred
     std::map<std::tuple<int64_t, int, uint64_t>, std::shared_ptr<Batch>> deferred;
+    std::vector<std::shared_ptr<Batch>> deferred_full; // ... and the ones that filled up (the next one of their key is bigger): they go with the rest
     std::chrono::steady_clock::time_point t_last_deferred{};
     uint64_t n_deferred_ops = 0;
     uint64_t n_shape[3] = {0, 0, 0};      // bootstrap launches by blind-rotation shape: eight waves per ciphertext / two / four per workgroup
-    hipStream_t s_in = nullptr;           // (r04: host-to-device copies; since r05 every set has its own in-order stream)
+    hipStream_t s_def = nullptr;          // the DEFERRED batches' stream: all of them, in the order they were closed — a batch behind the
+                                          // batch its operands come from needs no event (measured: a level of a pushed 32-bit adder on its
+                                          // set's own stream, tied to the previous level's stream by an event, took ~150 us on the GPU;
+                                          // 15-20 us in order on one stream).  Batches of the ordinary lanes keep their sets' streams.
+    hipStream_t stream_of(const Batch& b) const { return b.deferred ? s_def : sets[b.set].sk; }
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
     std::vector<uintptr_t> last_members[kLanes]; // threads of the most recently finished batch of a lane, sorted
     size_t cap_hint[kKinds] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
@@ -563,10 +576,11 @@ struct spf_pool {
                         const size_t ng = cap / Batch::kTreeGroup + 1;
                         b->gword.reset(new std::atomic<uint32_t>[ng]);
                         b->gwoken.reset(new std::atomic<uint32_t>[ng]);
-                        for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); }
+                        b->gsleep.reset(new std::atomic<uint32_t>[ng]);
+                        for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); b->gsleep[g].store(0); }
                         b->op = op; b->set = -1; b->cap = cap; b->lane = lane; b->param = param; b->by_handle = true;
                         b->deferred = true; b->depth = depth;
-                        const bool first = deferred.empty();
+                        const bool first = deferred.empty() && deferred_full.empty();
                         deferred.emplace(key, b);
                         if (first) poke(); // (the launcher arms the quiet time that flushes the table)
                     }
@@ -619,7 +633,8 @@ struct spf_pool {
                     const size_t ng = cap / Batch::kTreeGroup + 1;
                     b->gword.reset(new std::atomic<uint32_t>[ng]);
                     b->gwoken.reset(new std::atomic<uint32_t>[ng]);
-                    for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); }
+                        b->gsleep.reset(new std::atomic<uint32_t>[ng]);
+                    for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); b->gsleep[g].store(0); }
                 }
             } catch (const std::exception&) {
                 sets[set].busy = false;
@@ -664,9 +679,16 @@ struct spf_pool {
         if (b->deferred) {
             n_deferred_ops++;
             t_last_deferred = b->t_last;
-            if (b->n == b->cap) { // full: it goes now, and with it everything it may depend on
+            if (b->n == b->cap) {
+                // full: the next batch of this key is twice as big; this one waits with the rest (launching it now would take every
+                // shallower batch with it, half filled: a level of 1 024 gates pushed into a fresh pool is a few launches, once)
                 cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap);
-                flush_deferred();
+                try {
+                    deferred_full.push_back(b);
+                    deferred.erase(std::make_tuple(b->depth, op, param));
+                } catch (const std::exception&) {
+                    flush_deferred();
+                }
             }
         } else if (b->n == b->cap) {
             cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap); // it filled up: the callers can feed a bigger one
@@ -820,18 +842,26 @@ struct spf_pool {
     // sits in one (spf_pool_wait, spf_value_wait), when nothing has been deferred for the quiet time (launcher), at destroy.
     void flush_deferred()
     {
-        if (deferred.empty()) return;
+        if (deferred.empty() && deferred_full.empty()) return;
         const auto now = std::chrono::steady_clock::now();
-        for (auto& kv : deferred) {
-            std::shared_ptr<Batch>& b = kv.second;
+        auto close_one = [&](const std::shared_ptr<Batch>& b) {
             for (auto& d : b->deps)
                 if (!d->deferred && !d->closed && filling[d->lane] == d) close_batch(d->lane);
             b->closed = true;
             b->t_close = now;
             outstanding[b->lane]++;
             closing.push_back(b);
+        };
+        // (the map is in depth order; the full ones are merged in by depth: they were filled in any order)
+        std::stable_sort(deferred_full.begin(), deferred_full.end(), [](const std::shared_ptr<Batch>& x, const std::shared_ptr<Batch>& y) { return x->depth < y->depth; });
+        size_t f = 0;
+        for (auto& kv : deferred) {
+            while (f < deferred_full.size() && deferred_full[f]->depth <= kv.second->depth) close_one(deferred_full[f++]);
+            close_one(kv.second);
         }
+        while (f < deferred_full.size()) close_one(deferred_full[f++]);
         deferred.clear();
+        deferred_full.clear();
         poke();
     }
 
@@ -913,7 +943,7 @@ struct spf_pool {
                     }
                 }
             }
-            while (word.load(std::memory_order_acquire) == 0) futex_wait(&word, 0);
+            if (word.load(std::memory_order_acquire) == 0) b->sleep_on_group(g);
             const size_t child = Batch::kTreeGroup * g + 1 + slot % Batch::kTreeGroup; // this waiter's share of the waking
             if (child < b->n_groups()) b->wake_group(child);
         } else {
@@ -968,8 +998,8 @@ struct spf_pool {
                 if (b && b->deferred && !b->closed) flush_deferred();
             }
             if (b) {
-                std::atomic<uint32_t>& word = b->gword[v->slot / Batch::kTreeGroup];
-                while (word.load(std::memory_order_acquire) == 0) futex_wait(&word, 0);
+                const size_t g = v->slot / Batch::kTreeGroup;
+                if (b->gword[g].load(std::memory_order_acquire) == 0) b->sleep_on_group(g);
             }
         }
         const int st = v->state.load(std::memory_order_acquire);
@@ -981,7 +1011,7 @@ struct spf_pool {
     spf_status run_kernels(const Batch& b, const spf_pool_impl::Staging& s, size_t B, void* const d[3], void* d_out)
     {
         using namespace spf_pool_impl;
-        hipStream_t sk = s.sk;
+        hipStream_t sk = stream_of(b);
         Scratch* scr = const_cast<Scratch*>(&s.scr);
         spf_status st;
         switch (b.op) {
@@ -1029,7 +1059,7 @@ struct spf_pool {
         // polling the event from a CPU; the cheap batches are polled by the launcher itself.  SPF_POOL_EVENT_FLAGS overrides.)
         static const unsigned heavy_flags = [] { const char* e = getenv("SPF_POOL_EVENT_FLAGS"); return e ? (unsigned)atoi(e) : (unsigned)hipEventBlockingSync; }();
         if (hipEventCreateWithFlags(&b.ev_k, heavy(b.op) ? heavy_flags : hipEventDefault) != hipSuccess) return SPF_ERR_HIP;
-        hipStream_t sk = s.sk;
+        hipStream_t sk = stream_of(b);
         spf_status st = SPF_OK;
         if (scattered_cmux(b.op)) {
             // units {selector, low (taken when the selector is 0; null = the zero ciphertext), high, out}; units of one selector next
@@ -1207,7 +1237,7 @@ struct spf_pool {
                     if (e != hipSuccess) {
                         (void)hipGetLastError();
                         b.st = SPF_ERR_HIP;
-                        (void)hipStreamSynchronize(sets[b.set].sk);
+                        (void)hipStreamSynchronize(stream_of(b));
                     }
                     b.t_sync = clock::now();
                     std::shared_ptr<Batch> done = polling[i];
@@ -1261,16 +1291,17 @@ struct spf_pool {
                     const size_t n_cu = (size_t)ctx->n_cu;
                     n_shape[(b->n <= n_cu && b->per_wg <= 1) ? 0 : ((b->n <= 2 * n_cu && b->per_wg <= 2) ? 1 : 2)]++;
                 }
-                // the batches its operands come from: enqueued before it (they were closed before it), possibly on other sets'
-                // streams — its own stream waits for their events; one that has failed fails it
+                // the batches its operands come from: enqueued before it (they were closed before it) — deferred ones on the same
+                // stream, batches of the ordinary lanes on their sets' streams: the deferred stream waits for THEIR events; one
+                // that has failed fails it
                 spf_status st = SPF_OK;
                 if (!b->deps.empty()) {
                     if (hipSetDevice(ctx->device) != hipSuccess) st = SPF_ERR_HIP;
                     for (auto& d : b->deps) {
                         if (st != SPF_OK) break;
                         if (d->st != SPF_OK) st = d->st.load();
-                        else if (d->done) continue;
-                        else if (!d->ev_k || hipStreamWaitEvent(sets[b->set].sk, d->ev_k, 0) != hipSuccess) st = SPF_ERR_HIP;
+                        else if (d->done || d->deferred) continue; // (deferred: ahead of this batch on the same in-order stream)
+                        else if (!d->ev_k || hipStreamWaitEvent(s_def, d->ev_k, 0) != hipSuccess) st = SPF_ERR_HIP;
                     }
                 }
                 lk.unlock();
@@ -1327,7 +1358,7 @@ struct spf_pool {
             }
             if (lane >= 0) wake = std::min(wake, best);
             // the deferred table goes when nothing has joined it for the quiet time (a pusher that does not wait for anything)
-            if (!deferred.empty()) {
+            if (!deferred.empty() || !deferred_full.empty()) {
                 const auto due = stop ? now : t_last_deferred + std::chrono::duration_cast<clock::duration>(max_wait);
                 if (now >= due) {
                     flush_deferred();
@@ -1335,7 +1366,7 @@ struct spf_pool {
                 }
                 wake = std::min(wake, due);
             }
-            if (stop && closing.empty() && polling.empty() && lane < 0 && deferred.empty()) return;
+            if (stop && closing.empty() && polling.empty() && lane < 0 && deferred.empty() && deferred_full.empty()) return;
             // 3. nothing to do right now.  While cheap operations by handle are in flight or were a moment ago, poll (the event
             // of a 15 us kernel, the next level's submits): going to sleep costs a wake-up per circuit level.  Otherwise sleep
             // until the next deadline or the next poke.
@@ -1372,7 +1403,7 @@ struct spf_pool {
             if (b->st == SPF_OK && b->by_handle) {
                 if (hipEventSynchronize(b->ev_k) != hipSuccess) {
                     b->st = SPF_ERR_HIP;
-                    (void)hipStreamSynchronize(sets[b->set].sk);
+                    (void)hipStreamSynchronize(stream_of(*b));
                 }
                 b->t_sync = std::chrono::steady_clock::now();
             } else if (b->st == SPF_OK) {
@@ -1393,11 +1424,11 @@ struct spf_pool {
                     b->wake_chunk(i);
                 }
                 if (b->st == SPF_OK && hipEventSynchronize(b->ev_chunk[b->n_chunks - 1]) != hipSuccess) b->st = SPF_ERR_HIP;
-                if (b->st != SPF_OK) (void)hipStreamSynchronize(sets[b->set].sk); // nothing may still be writing the staging set
+                if (b->st != SPF_OK) (void)hipStreamSynchronize(stream_of(*b)); // nothing may still be writing the staging set
                 b->t_sync = std::chrono::steady_clock::now();
             } else {
                 // something was enqueued before the failure: let it drain before the staging set is reused
-                (void)hipStreamSynchronize(sets[b->set].sk);
+                (void)hipStreamSynchronize(stream_of(*b));
             }
             if (b->by_handle) {
                 lk.lock();

@@ -57,6 +57,13 @@ def main():
     pin = bench._pinned_to_quota()
     pin.__enter__()
     pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=wait_us)
+    if os.environ.get("SPF_PUSH_ONLY"):      # (for traces: the pushed form alone)
+        for _ in range(reps):
+            outs, inner, _ = drv.push_circuit_by_handles(pool, rec)
+            print(f"pushed: {inner * 1e3:.3f} ms inside the pusher; equal {all(np.array_equal(a, b) for a, b in zip(outs, g_outs))}")
+        pool.close()
+        g.close()
+        return
     outs, _, _ = drv.run_circuit_by_handles(pool, rec, threads=T)
     same = all(np.array_equal(a, b) for a, b in zip(outs, g_outs))
     c0 = pool.counters()
@@ -69,6 +76,18 @@ def main():
     n_l = (c1["handle_launches"] - c0["handle_launches"]) / reps
     print(f"by handles (K = {K}, {T} threads, max_wait {wait_us} us): {best[0] * 1e3:.3f} ms with upload / download, {best[1] * 1e3:.3f} ms "
           f"inside the driver; {n_ops} operations in {n_l:.0f} launches per run; word-equal to the graph: {same}")
+    # the same circuit PUSHED by one thread (pending results as operands, no ticket, no wait until the outputs)
+    outs, _, _ = drv.push_circuit_by_handles(pool, rec)
+    same = all(np.array_equal(a, b) for a, b in zip(outs, g_outs))
+    c0 = pool.counters()
+    best = (1e9, 1e9)
+    for _ in range(reps):
+        _, inner, whole = drv.push_circuit_by_handles(pool, rec)
+        best = min(best, (whole, inner))
+    c1 = pool.counters()
+    n_l = (c1["handle_launches"] - c0["handle_launches"]) / reps
+    print(f"pushed by one thread (K = {K}, max_wait {wait_us} us): {best[0] * 1e3:.3f} ms with upload / download, {best[1] * 1e3:.3f} ms "
+          f"inside the pusher; {n_l:.0f} launches per run; word-equal to the graph: {same}")
     pool.close()
     g.close()
 

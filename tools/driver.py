@@ -37,6 +37,8 @@ def load():
     d.spf_pool_drive_cmux.argtypes = [P, P, P, C.c_int, C.c_int, C.c_double, P, C.c_size_t, P, P, C.c_size_t, D]
     d.spf_pool_drive_cmux_v.restype = C.c_long
     d.spf_pool_drive_cmux_v.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_double, P, P, P, D]
+    d.spf_pool_push_cmux_v.restype = C.c_long
+    d.spf_pool_push_cmux_v.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_double, P, P, P, D]
     d.spf_circuit_push.restype = C.c_int
     d.spf_circuit_push.argtypes = [P, P, P, P, C.c_uint32, P, P, P, P, P, P, P, C.c_uint32, P, C.c_uint32, D]
     d.spf_circuit_drive.restype = C.c_int

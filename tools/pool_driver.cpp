@@ -7,6 +7,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -209,6 +211,45 @@ long spf_pool_drive_cmux_v(spf_pool* pool, submit_cmux_v_fn submit, wait_fn wait
     return failed.load() ? -1 : done.load();
 }
 
+// CMux gates PUSHED: each thread submits bursts of `burst` gates without tickets (nobody waits for a single gate), two bursts in
+// flight — while one runs the next is pushed — and waits for the VALUES of a burst before it reuses its slots.
+typedef spf_status (*value_wait_fn)(const spf_value*);
+long spf_pool_push_cmux_v(spf_pool* pool, submit_cmux_v_fn submit, value_wait_fn value_wait, release_fn release, int threads, int burst,
+                          double seconds, spf_value* const* sel, spf_value* const* a, spf_value* const* b, double* elapsed_s)
+{
+    std::atomic<long> done{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> th;
+    if (burst < 1) burst = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto until = t0 + std::chrono::duration<double>(seconds);
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            std::vector<spf_value*> outs[2];
+            auto collect = [&](std::vector<spf_value*>& v) {
+                for (spf_value* x : v) {
+                    if (value_wait(x) != SPF_OK) failed.store(1);
+                    release(x);
+                }
+                done.fetch_add((long)v.size());
+                v.clear();
+            };
+            for (int half = 0; std::chrono::steady_clock::now() < until && !failed.load(); half ^= 1) {
+                collect(outs[half]);
+                for (int i = 0; i < burst; i++) {
+                    spf_value* o = nullptr;
+                    if (submit(pool, sel[t], a[t], b[t], &o, nullptr) != SPF_OK) { failed.store(1); break; }
+                    outs[half].push_back(o);
+                }
+            }
+            collect(outs[0]);
+            collect(outs[1]);
+        });
+    for (auto& x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load() ? -1 : done.load();
+}
+
 // A gate graph executed the way the reference executes it (circuit_processor/mod.rs:130-253): one task per node, a task runs as
 // soon as its operands exist, every task calls the evaluator with ONE operation and blocks until it is done — here
 // spf_pool_submit_op_v + spf_pool_wait from a pool of `threads` workers; a node's value is released when its last consumer has
@@ -323,7 +364,6 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
 // returned at once) — the operands of a task are results that are still pending, the pool orders and batches them by level
 // (spf_hip.h, "Deferred operands") — then waits for the `n_out` output values only.  Values nobody keeps are released right after
 // the last submit that takes them (the pool holds its own references while they are needed).
-typedef spf_status (*value_wait_fn)(const spf_value*);
 int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_wait, release_fn release, uint32_t n_nodes,
                      const int32_t* op, const uint32_t* in, const uint32_t* n_in, const uint64_t* param, spf_value** values,
                      const uint8_t* keep, const uint32_t* order, uint32_t n_order, const uint32_t* outputs, uint32_t n_out,
@@ -348,10 +388,15 @@ int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_
             if (--users[src] == 0 && !keep[src] && values[src]) { release(values[src]); values[src] = nullptr; }
         }
     }
+    const auto t_pushed = std::chrono::steady_clock::now();
     for (uint32_t j = 0; j < n_out && !error; j++) {
         const spf_status st = value_wait(values[outputs[j]]);
         if (st != SPF_OK) error = st;
     }
+    if (getenv("SPF_PUSH_TRACE"))
+        fprintf(stderr, "[push] %u operations pushed in %.0f us, outputs after another %.0f us\n", n_order,
+                std::chrono::duration<double, std::micro>(t_pushed - t0).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pushed).count());
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t i = 0; i < n_nodes; i++) // (what never found its last user: unused results, or everything after a failure)
         if (op[i] >= 0 && !keep[i] && values[i]) { release(values[i]); values[i] = nullptr; }
