@@ -263,10 +263,18 @@ template <spf_value_kind K> class DeviceCiphertext {
     }
     explicit operator bool() const { return v_ != nullptr; }
     spf_value* raw() const { return v_; }
-    // HBM -> host, the reference layout (u64 words; the GGSW: complex f64)
+    // until the operation that produces the value has run (at once for a valid value; PooledEvaluation in pushed mode hands out
+    // ciphertexts that are still pending)
+    void wait() const
+    {
+        const spf_status s = v_ ? spf_value_wait(v_) : SPF_ERR_INVALID_ARGUMENT;
+        if (s != SPF_OK) throw Error(s, "DeviceCiphertext::wait: the producing operation failed (or there is no value)");
+    }
+    // HBM -> host, the reference layout (u64 words; the GGSW: complex f64); waits for a pending value first
     void download(void* host) const
     {
-        const spf_status s = v_ ? spf_value_download(v_, host) : SPF_ERR_INVALID_ARGUMENT;
+        wait();
+        const spf_status s = spf_value_download(v_, host);
         if (s != SPF_OK) throw Error(s, "DeviceCiphertext::download: no valid value");
     }
     void reset()
@@ -287,10 +295,15 @@ using L1GgswCiphertext = DeviceCiphertext<SPF_VAL_GGSW1>;
 
 // `Evaluation` as `CircuitProcessor`'s workers call it (circuit_processor/mod.rs:255-540): one operation on one ciphertext per
 // call, from any number of threads, output first — over a pool of the Evaluation's group, so that the concurrent calls of many
-// workers become one launch, with operands and results in HBM.  Each method returns when its output is valid, like the reference's.
+// workers become one launch, with operands and results in HBM.  Each method returns when its output is valid, like the reference's
+// — or, in PUSHED mode, at once: the output is a pending ciphertext that later calls take as an operand right away (the pool
+// orders and batches what has been pushed by kind and level: spf_hip.h, "Deferred operands"); only `wait()` / `download()` of a
+// ciphertext block.  One thread can push a whole circuit that way.
 class PooledEvaluation {
   public:
-    explicit PooledEvaluation(const Evaluation& ev, size_t max_batch = 1024, uint32_t max_wait_us = 100) : grp_(ev.group())
+    enum class Mode { Blocking, Pushed };
+    explicit PooledEvaluation(const Evaluation& ev, size_t max_batch = 1024, uint32_t max_wait_us = 100, Mode mode = Mode::Blocking)
+        : grp_(ev.group()), pushed_(mode == Mode::Pushed)
     {
         if (spf_pool_create_group(grp_, max_batch, max_wait_us, &pool_) != SPF_OK) throw Error(SPF_ERR_HIP, spf_group_last_error(grp_));
     }
@@ -351,7 +364,7 @@ class PooledEvaluation {
     {
         spf_value* out = nullptr;
         uint64_t t = 0;
-        check(spf_pool_submit_keyswitch_circuit_bootstrap_v(pool_, input.raw(), &out, &t));
+        check(spf_pool_submit_keyswitch_circuit_bootstrap_v(pool_, input.raw(), &out, pushed_ ? nullptr : &t));
         finish(output, out, t);
     }
 
@@ -360,15 +373,17 @@ class PooledEvaluation {
     {
         spf_value* out = nullptr;
         uint64_t t = 0;
-        check(spf_pool_submit_op_v(pool_, op, in.begin(), in.size(), param, &out, &t));
+        check(spf_pool_submit_op_v(pool_, op, in.begin(), in.size(), param, &out, pushed_ ? nullptr : &t));
         finish(output, out, t);
     }
     template <class C> void finish(C& output, spf_value* out, uint64_t ticket) const
     {
-        const spf_status s = spf_pool_wait(pool_, ticket);
-        if (s != SPF_OK) {
-            spf_value_release(out); // never valid: released in every case
-            check(s);
+        if (!pushed_) {
+            const spf_status s = spf_pool_wait(pool_, ticket);
+            if (s != SPF_OK) {
+                spf_value_release(out); // never valid: released in every case
+                check(s);
+            }
         }
         output.reset();
         output.v_ = out;
@@ -379,6 +394,7 @@ class PooledEvaluation {
     }
     spf_group* grp_ = nullptr;
     spf_pool* pool_ = nullptr;
+    bool pushed_ = false;
 };
 
 } // namespace spf

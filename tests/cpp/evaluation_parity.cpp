@@ -216,6 +216,41 @@ int main()
             expect(refused, "  ... an empty operand is SPF_ERR_INVALID_ARGUMENT");
         }
 
+        // ... and PUSHED from this one thread: no call blocks, the outputs are pending ciphertexts that the next call takes as
+        // operands; only the download waits.  Six independent chains, one launch per kind and level.
+        {
+            spf::PooledEvaluation pe(ev, 64, 100000, spf::PooledEvaluation::Mode::Pushed);
+            const int C = 6;
+            std::vector<spf::L1GlweCiphertext> outs((size_t)C);
+            spf_pool_counters c0{}, c1{};
+            spf_pool_counters_get(pe.raw(), &c0);
+            {
+                auto x = pe.upload<spf::L1GlweCiphertext>(bit.data());
+                auto va = pe.upload<spf::L1GlweCiphertext>(a.data());
+                auto vb = pe.upload<spf::L1GlweCiphertext>(b.data());
+                for (int c = 0; c < C; c++) {
+                    spf::L1LweCiphertext e1;
+                    spf::L0LweCiphertext e0;
+                    spf::L1GgswCiphertext sel_v;
+                    spf::L1GlweCiphertext nb;
+                    pe.sample_extract_l1(e1, x, 0);
+                    pe.keyswitch_lwe_l1_lwe_l0(e0, e1);
+                    pe.circuit_bootstrap(sel_v, e0);
+                    pe.not_(nb, vb);
+                    pe.cmux(outs[(size_t)c], sel_v, va, nb);
+                } // (the intermediates are released here, still pending: the pool keeps what it needs)
+            }
+            bool all = true;
+            for (int c = 0; c < C; c++) {
+                std::vector<uint64_t> got((k + 1) * N);
+                outs[(size_t)c].download(got.data());
+                all = all && same(got, gref);
+            }
+            spf_pool_counters_get(pe.raw(), &c1);
+            expect(all, "PooledEvaluation pushed from one thread: the chain's oracle words");
+            expect(c1.handle_ops - c0.handle_ops == 5u * C && c1.handle_launches - c0.handle_launches == 5, "  ... one launch per kind and level (5 for 30 operations)");
+        }
+
         // malformed graph: wrong operand type must throw when the node is added (task.rs:26-31)
         bool threw = false;
         try { g.op(SPF_OP_CIRCUIT_BOOTSTRAP, {ia}); } catch (const spf::Error&) { threw = true; }

@@ -258,6 +258,16 @@ def test_reference_adder_pushed_from_one_thread_without_waits():
         n_l = c1["handle_launches"] - c0["handle_launches"]
         assert n_ops == len([o for o in rec.op if o >= 0])
         assert n_l <= 3 * st["launches"], (n_l, st)     # level batches, not one launch per operation
+        # four pushers and a blocking 32-worker walk of the same circuit at the same time on the same pool: every one of them
+        # gets the graph's words (the pushers' deferred batches mix operations of all four; the blocking callers' batches are
+        # the ordinary lanes')
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=5) as ex:
+            jobs = [ex.submit(drv.push_circuit_by_handles, pool, rec) for _ in range(4)]
+            jobs.append(ex.submit(drv.run_circuit_by_handles, pool, rec, 32))
+            for j in jobs:
+                o = j.result()[0]
+                assert len(o) == 33 and all(np.array_equal(x, y) for x, y in zip(o, g_outs))
         import gc
         gc.collect()
         vs = pool.value_stats()
@@ -444,6 +454,16 @@ def test_values_on_a_group_pool_stay_on_their_member(rig):
         assert moved.info()["member"] == 1
         got = pool.run_v(FheOp.CMux, [moved, va1, vb1]).download()
         assert np.array_equal(got, eng.cmux(exp_sel[:1], a[1:], b[1:])[0])
+        # pushed chains (pending operands) live on the member their operands live on, both members at the same time
+        pushed = []
+        for m, (va_m, vb_m) in enumerate(((va0, vb0), (va1, vb1))):
+            vl = pool.upload(ValueKind.LWE1, lwe1[m], member=m)
+            sel = pool.push_v(FheOp.CircuitBootstrap, [pool.push_v(FheOp.KeyswitchL1toL0, [vl])])
+            pushed.append(pool.push_v(FheOp.CMux, [sel, pool.push_v(FheOp.Not, [va_m]), vb_m]))
+        for m, v in enumerate(pushed):
+            assert v.wait().info()["member"] == m
+            assert np.array_equal(v.download(), eng.cmux(exp_sel[m:m + 1], eng.glwe_not(a[m:m + 1]), b[m:m + 1])[0])
+        del pushed, sel, vl
     finally:
         import gc
         del outs
