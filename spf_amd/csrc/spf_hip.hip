@@ -1918,13 +1918,15 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
     if (const char* e = getenv("SPF_POOL_SETS")) p->n_sets = std::min(std::max(1, atoi(e)), (int)spf_pool_impl::kSets);
     if (const char* e = getenv("SPF_POOL_SPLIT")) p->split = (size_t)std::min(std::max(1, atoi(e)), 16);
     if (const char* e = getenv("SPF_POOL_SPIN_US")) p->spin_us = std::max(0, atoi(e));
+    if (const char* e = getenv("SPF_POOL_DEF_HEAVY")) p->max_def_heavy = std::max(0, atoi(e));
+    if (const char* e = getenv("SPF_POOL_TABLE_SETS")) p->n_table_sets = std::min(std::max(1, atoi(e)), (int)spf_pool::kTableSets);
     if (const char* e = getenv("SPF_POOL_HOT_US")) p->hot_us = std::max(0, atoi(e)); // (0: the launcher never polls; completers complete every batch)
-    bool streams_ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&p->s_def, hipStreamNonBlocking) == hipSuccess;
+    bool streams_ok = hipSetDevice(c->device) == hipSuccess && p->create_def_streams();
     for (auto& set : p->sets)
         streams_ok = streams_ok && hipStreamCreateWithFlags(&set.sk, hipStreamNonBlocking) == hipSuccess;
     if (!streams_ok) {
         p->free_sets();
-        if (p->s_def) (void)hipStreamDestroy(p->s_def);
+        p->destroy_def_streams();
         delete p;
         return fail(c, SPF_ERR_HIP, "spf_pool_create: cannot create the pool's streams");
     }
@@ -1993,7 +1995,7 @@ spf_status spf_pool_create(spf_ctx* c, size_t max_batch, uint32_t max_wait_us, s
         for (auto& t : p->completers)
             if (t.joinable()) t.join();
         p->free_sets();
-        (void)hipStreamDestroy(p->s_def);
+        p->destroy_def_streams();
         delete p;
         return fail(c, SPF_ERR_HIP, std::string("spf_pool_create: cannot start the pool threads: ") + e.what());
     }
@@ -2046,7 +2048,7 @@ void spf_pool_destroy(spf_pool* p)
             b->destroy_events();
     }
     p->free_sets();
-    (void)hipStreamDestroy(p->s_def);
+    p->destroy_def_streams();
     if (p->arena) p->arena->close(); // cached blocks go back to the driver; values still alive free theirs when they are released
     delete p;
 }

@@ -41,7 +41,13 @@
 // lanes of their own (they never mix with host-pointer callers); the cheap kinds take ONE caller group and no pacing — a
 // 15 us CMUX level gains nothing from four resident batches.  Completion is per staging set (one completer thread each), so
 // a CMUX batch that finishes in 15 us is handed back at once although a 4 ms bootstrap batch was enqueued before it.
-// Errors follow the reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters.
+// r06 (late): PENDING results as operands.  The blocking convention costs a thread sleep and wake-up per operation and keeps one
+// operation in flight per thread; so a `_v` submit also takes operands whose producing operation has not run yet, needs no
+// ticket, and spf_value_wait waits for a value.  Operations on pending operands are DEFERRED: batches by (depth, kind,
+// parameter) in a table of their own (`deferred`), closed together shallowest first (a wait, or the quiet time), launched in
+// that order on ONE in-order stream — a pushed circuit runs as the level plan a gate graph would have, built while it arrives.
+// Errors follow the reference's first-error-wins rule per batch: the batch's status is returned to each of its waiters (and to
+// every batch whose operands came out of it).
 #pragma once
 #include "../../include/spf_hip.h"
 
@@ -176,6 +182,7 @@ struct Batch {
     // the staging set is taken when the batch is launched, not when it is opened (a circuit has more levels than there are sets)
     bool deferred = false;
     int64_t depth = 0;
+    int rank = 0; // bootstrap batches on the longest path to the batch's operations (part of its key: see submit_impl)
     std::vector<std::shared_ptr<Batch>> deps;
     // The outputs leave the GPU in up to kMaxChunks copies (each a multiple of kWordSlots slots, all but the last equal), each with
     // its own event.  The waiters sleep on the word of their slot group (futex, 0 -> 1 when the group's bytes are in pinned
@@ -317,6 +324,14 @@ struct spf_pool {
     std::atomic<bool> stop{false};
     std::thread launcher, completers[spf_pool_impl::kSets];
     spf_pool_impl::Staging sets[spf_pool_impl::kSets];
+    // Table sets: what a CHEAP deferred batch needs between its launch and its kernels — the pinned pointer table and the rows
+    // its scattered operands are packed into; no stream (s_def), no intermediates, no completer thread (the launcher polls its
+    // event).  Many more of them than staging sets: the launcher runs ahead of the GPU by as many levels as there are tables, and
+    // the sixteen staging sets stay free for the bootstrap batches (several conversions of a circuit in flight side by side).
+    static constexpr int kTableSets = 96;
+    spf_pool_impl::Staging tsets[kTableSets];
+    static bool table_batch(const Batch& b) { return b.deferred && !spf_pool_impl::heavy(b.op); }
+    spf_pool_impl::Staging& staging_of(const Batch& b) { return table_batch(b) ? tsets[b.set] : sets[b.set]; }
     std::shared_ptr<Batch> flying[spf_pool_impl::kSets]; // the enqueued batch of each set (one at most)
     std::condition_variable_any cv_fly[spf_pool_impl::kSets];
     uint64_t n_reclaimed = 0;             // outputs delivered on their owners' behalf (reclaim)
@@ -331,16 +346,34 @@ struct spf_pool {
     std::atomic<bool> launcher_asleep{false};
     std::vector<std::shared_ptr<Batch>> polling; // the launcher's own: cheap batches by handle it enqueued and completes itself
     // by handle, operations on PENDING operands: open batches by (depth, kind, parameter) — see Batch::deferred, flush_deferred
-    std::map<std::tuple<int64_t, int, uint64_t>, std::shared_ptr<Batch>> deferred;
+    std::map<std::tuple<int64_t, int, uint64_t, int>, std::shared_ptr<Batch>> deferred; // (depth, kind, parameter, rank)
     std::vector<std::shared_ptr<Batch>> deferred_full; // ... and the ones that filled up (the next one of their key is bigger): they go with the rest
     std::chrono::steady_clock::time_point t_last_deferred{};
     uint64_t n_deferred_ops = 0;
     uint64_t n_shape[3] = {0, 0, 0};      // bootstrap launches by blind-rotation shape: eight waves per ciphertext / two / four per workgroup
-    hipStream_t s_def = nullptr;          // the DEFERRED batches' stream: all of them, in the order they were closed — a batch behind the
-                                          // batch its operands come from needs no event (measured: a level of a pushed 32-bit adder on its
-                                          // set's own stream, tied to the previous level's stream by an event, took ~150 us on the GPU;
-                                          // 15-20 us in order on one stream).  Batches of the ordinary lanes keep their sets' streams.
-    hipStream_t stream_of(const Batch& b) const { return b.deferred ? s_def : sets[b.set].sk; }
+    // The cheap DEFERRED batches' stream: all of them, in the order they were launched — a batch behind the batch its operands come
+    // from needs no event (measured: a level of a pushed 32-bit adder on its set's own stream, tied to the previous level's stream
+    // by an event, took ~150 us on the GPU; 15-20 us in order on one stream).  A deferred BOOTSTRAP batch is milliseconds long
+    // whatever its width and runs on its staging set's own stream, side by side with the others (the conversions inside a 32 x 32
+    // multiplication become ready at 32 different depths); nothing is ever enqueued BEHIND one: what takes its results is launched
+    // when it has finished (launch_loop) — hipStreamWaitEvent on the event of a running bootstrap batch blocked the calling thread
+    // until the batch was through (3.9-4.2 ms per call on this runtime: the launcher ran a pushed multiplication's 32 conversion
+    // batches one after the other, 172 ms; the gate graph, which moves them to common levels: 22).
+    // Batches of the ordinary lanes keep their sets' streams.
+    hipStream_t s_def = nullptr;
+    bool create_def_streams() { return hipStreamCreateWithFlags(&s_def, hipStreamNonBlocking) == hipSuccess; }
+    // (a stream of the highest priority instead — hardware queues are kept per priority — changed nothing: 96 against 95 ms)
+    void destroy_def_streams()
+    {
+        if (s_def) (void)hipStreamDestroy(s_def);
+        s_def = nullptr;
+    }
+    int n_table_sets = kTableSets; // (SPF_POOL_TABLE_SETS: experiments)
+    int max_def_heavy = 3;         // deferred bootstrap batches in flight side by side (SPF_POOL_DEF_HEAVY; 0 = no limit).  A pushed 32 x 32
+                                   // multiplication (31 conversion batches of four, at 31 depths): 1: 152-160 ms, 2: 99-102, 3: 79-84, 4: 92-101,
+                                   // no limit: 98-104 — beside five or more of them the levels on s_def stop being served (a CMux level enqueued
+                                   // beside seven running conversions completed 8 ms later, when the last of them had finished)
+    hipStream_t stream_of(const Batch& b) const { return table_batch(b) ? s_def : sets[b.set].sk; }
     std::chrono::milliseconds grace{200}; // after this long an uncollected output is delivered by the launcher
     std::vector<uintptr_t> last_members[kLanes]; // threads of the most recently finished batch of a lane, sorted
     size_t cap_hint[kKinds] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}; // slots of the next batch of a kind: doubles whenever a batch fills up
@@ -444,7 +477,7 @@ struct spf_pool {
     void free_sets()
     {
         (void)hipSetDevice(ctx->device);
-        for (auto& s : sets) {
+        auto free_one = [](spf_pool_impl::Staging& s) {
             for (int k = 0; k < 3; k++) {
                 if (s.h_in[k]) (void)hipHostFree(s.h_in[k]);
                 if (s.d_in[k]) (void)hipFree(s.d_in[k]);
@@ -456,7 +489,9 @@ struct spf_pool {
             scratch_free(s.scr);
             if (s.sk) (void)hipStreamDestroy(s.sk);
             s = spf_pool_impl::Staging{};
-        }
+        };
+        for (auto& s : sets) free_one(s);
+        for (auto& s : tsets) free_one(s);
     }
 
     // output of one slot to its caller's buffer (any thread; the pinned buffer is stable while the batch is collecting)
@@ -552,6 +587,10 @@ struct spf_pool {
         int n_dep = 0;
         if (by_handle) {
             int64_t depth = 0;
+            int rank = 0; // (operations behind different numbers of bootstrap batches do not share a batch: what waits for a conversion
+                          // — a bootstrap batch is milliseconds — must not hold back the operations of its level that do not; the
+                          // conversions inside a 32 x 32 multiplication are 31 levels apart and each was started when the previous
+                          // one had finished, 165 ms, because every level held an adder gate that waited for the previous one)
             for (int k = 0; k < 3; k++) {
                 if (!vin[k]) continue;
                 const int vs = vin[k]->state.load(std::memory_order_acquire);
@@ -560,12 +599,13 @@ struct spf_pool {
                 const std::shared_ptr<Batch>& p = vin[k]->producer; // (set and cleared under `mu`)
                 if (!p || p->done) continue; // its batch is being handed back right now: the kernels have run
                 depth = std::max(depth, p->depth + 1);
+                rank = std::max(rank, p->rank + (heavy(p->op) ? 1 : 0));
                 bool seen = false;
                 for (int j = 0; j < n_dep; j++) seen = seen || dep[j] == p;
                 if (!seen) dep[n_dep++] = p;
             }
             if (n_dep) {
-                const auto key = std::make_tuple(depth, op, param);
+                const auto key = std::make_tuple(depth, op, param, rank);
                 try {
                     auto it = deferred.find(key);
                     if (it != deferred.end()) b = it->second;
@@ -579,7 +619,7 @@ struct spf_pool {
                         b->gsleep.reset(new std::atomic<uint32_t>[ng]);
                         for (size_t g = 0; g < ng; g++) { b->gword[g].store(0); b->gwoken[g].store(0); b->gsleep[g].store(0); }
                         b->op = op; b->set = -1; b->cap = cap; b->lane = lane; b->param = param; b->by_handle = true;
-                        b->deferred = true; b->depth = depth;
+                        b->deferred = true; b->depth = depth; b->rank = rank;
                         const bool first = deferred.empty() && deferred_full.empty();
                         deferred.emplace(key, b);
                         if (first) poke(); // (the launcher arms the quiet time that flushes the table)
@@ -685,7 +725,7 @@ struct spf_pool {
                 cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap);
                 try {
                     deferred_full.push_back(b);
-                    deferred.erase(std::make_tuple(b->depth, op, param));
+                    deferred.erase(std::make_tuple(b->depth, op, param, b->rank));
                 } catch (const std::exception&) {
                     flush_deferred();
                 }
@@ -1049,7 +1089,7 @@ struct spf_pool {
         using namespace spf_pool_impl;
         size_t in[3], out;
         in_out_sizes(b.op, in, out);
-        const Staging& s = sets[b.set];
+        const Staging& s = staging_of(b);
         const size_t B = b.n;
         if (hipSetDevice(ctx->device) != hipSuccess) return SPF_ERR_HIP;
         b.out_blk = spf_value_impl::Block::make(arena, B * out);
@@ -1204,7 +1244,7 @@ struct spf_pool {
                         us(b->t0 - epoch), us(b->t_close - b->t0), us(b->t_ready - b->t_close), us(b->t_enq - b->t_ready), us(b->t_sync - b->t_enq), us(b->t_done - b->t_sync));
             }
 #endif
-            sets[b->set].busy = false; // nothing to collect: the staging set is free again
+            staging_of(*b).busy = false; // nothing to collect: the staging set is free again
             b->destroy_events();
             if (set_waiters) cv_set.notify_all();
             n_handle_launches++;
@@ -1224,16 +1264,36 @@ struct spf_pool {
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // the quiet times below are tens of microseconds: the default slack is 50
         std::unique_lock<Mutex> lk(mu);
         auto hot_until = clock::now();
+#ifdef SPF_POOL_TRACE
+        struct Tally { double t_setdev = 0; long n_deps = 0, n_waits = 0; double t_deps = 0, t_prep = 0, t_enq2 = 0, t_relock = 0; double poll = 0, enq = 0, spin = 0, sleep = 0; long n_poll = 0, n_enq = 0, n_spin = 0, n_sleep = 0, n_noset = 0; ~Tally() { fprintf(stderr, "[pool] launcher: polling %.1f ms in %ld passes, enqueue %.1f ms for %ld batches, spinning %.1f ms (%ld), asleep %.1f ms (%ld), passes without a set for a deferred batch %ld; inside the enqueue block: deps %.1f ms (hipSetDevice %.1f ms; %ld dependencies looked at, %ld event waits), prepare %.1f, enqueue %.1f, relock %.1f\n", poll, n_poll, enq, n_enq, spin, n_spin, sleep, n_sleep, n_noset, t_deps, t_setdev, n_deps, n_waits, t_prep, t_enq2, t_relock); } } tally;
+        auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
+#endif
         for (;;) {
             auto now = clock::now();
             // 0. the cheap batches by handle this thread enqueued: it also completes them (a 15 us CMUX level handed to a
             // completer thread costs that thread's wake-up — more than the kernel — before anybody looks at the event)
             if (!polling.empty()) {
+#ifdef SPF_POOL_TRACE
+                const auto t_poll = clock::now();
+                struct P { Tally& t; clock::time_point t0; ~P() { t.poll += std::chrono::duration<double, std::milli>(clock::now() - t0).count(); t.n_poll++; } } p_{tally, t_poll};
+#endif
                 lk.unlock();
+                // (streams are in order: behind a batch that has not finished nothing of its stream has — one query per stream and
+                // pass, not one per batch: with dozens of deferred batches parked behind a bootstrap the queries were 200 us a pass)
+                hipStream_t waiting[1 + spf_pool_impl::kSets];
+                int n_waiting = 0;
                 for (size_t i = 0; i < polling.size();) {
                     Batch& b = *polling[i];
+                    const hipStream_t bs = stream_of(b);
+                    bool behind = false;
+                    for (int w = 0; w < n_waiting; w++) behind = behind || waiting[w] == bs;
+                    if (behind) { i++; continue; }
                     const hipError_t e = hipEventQuery(b.ev_k);
-                    if (e == hipErrorNotReady) { i++; continue; }
+                    if (e == hipErrorNotReady) {
+                        if (n_waiting < (int)(sizeof(waiting) / sizeof(waiting[0]))) waiting[n_waiting++] = bs;
+                        i++;
+                        continue;
+                    }
                     if (e != hipSuccess) {
                         (void)hipGetLastError();
                         b.st = SPF_ERR_HIP;
@@ -1252,19 +1312,39 @@ struct spf_pool {
             // 1. a closed batch: enqueue it as soon as its last members have copied their inputs in (the first one that can go:
             // a batch whose members are still copying does not hold up the ones behind it)
             std::shared_ptr<Batch> go;
-            bool no_set_for_deferred = false;
+            bool no_set_for_deferred = false, no_table_set = false;
             for (auto it = closing.begin(); it != closing.end(); ++it) {
                 Batch& b = **it;
                 if (b.n_ready < b.n) continue; // (submit wakes this thread when the last input is in)
                 if (b.deferred && b.set < 0) {
-                    // a deferred batch takes its staging set now (stream, pointer table, intermediates); when every set is held it
-                    // waits — and so does every deferred batch behind it: they go in the order they were closed (depth order)
-                    if (no_set_for_deferred) continue;
+                    // A deferred batch goes when every batch its operands come from has been ENQUEUED (its own stream is then in
+                    // order behind them, or waits for their events) and the bootstrap batches among them have FINISHED (see s_def:
+                    // nothing is enqueued behind a running bootstrap batch).  `closing` holds the deferred batches shallowest first,
+                    // so what is skipped here is looked at again before anything that depends on it.
+                    bool ready = true;
+                    for (auto& d : b.deps) {
+                        if (d->st != SPF_OK || d->done) continue; // (failed: this batch is launched to fail with it)
+                        if (!d->ev_k || heavy(d->op)) { ready = false; break; }
+                    }
+                    if (!ready) continue;
+                    // ... and takes its set now (bootstrap: stream, pointer table, intermediates; cheap: a table set); when every
+                    // set of its kind is held it waits for a batch to be handed back (which pokes this thread)
+                    const bool table = table_batch(b);
+                    if (table ? no_table_set : no_set_for_deferred) continue;
+                    if (!table && max_def_heavy > 0) { // (see max_def_heavy)
+                        int flying_heavy = 0;
+                        for (auto& f : in_flight) flying_heavy += (f->deferred && heavy(f->op)) ? 1 : 0;
+                        if (flying_heavy >= max_def_heavy) continue;
+                    }
                     int set = -1;
-                    for (int i = 0; i < n_sets; i++) if (!sets[i].busy) { set = i; break; }
-                    if (set < 0) { no_set_for_deferred = true; continue; } // (a batch that is handed back pokes this thread)
-                    sets[set].busy = true;
+                    if (table) {
+                        for (int i = 0; i < n_table_sets; i++) if (!tsets[i].busy) { set = i; break; }
+                    } else {
+                        for (int i = 0; i < n_sets; i++) if (!sets[i].busy) { set = i; break; }
+                    }
+                    if (set < 0) { (table ? no_table_set : no_set_for_deferred) = true; continue; }
                     b.set = set;
+                    staging_of(b).busy = true;
                 }
                 // Pacing of the bootstrap kinds: resident batches that start together also finish together — their copies out
                 // queue behind each other and their callers come back in one crowd, i.e. they behave as ONE big batch and the GPU
@@ -1282,7 +1362,13 @@ struct spf_pool {
                 closing.erase(it);
                 break;
             }
+#ifdef SPF_POOL_TRACE
+            if (no_set_for_deferred) tally.n_noset++;
+#endif
             if (go) {
+#ifdef SPF_POOL_TRACE
+                struct E { Tally& t; clock::time_point t0; ~E() { t.enq += std::chrono::duration<double, std::milli>(clock::now() - t0).count(); t.n_enq++; } } e_{tally, clock::now()};
+#endif
                 std::shared_ptr<Batch> b = go;
                 b->t_ready = clock::now();
                 if (heavy(b->op)) last_enq = b->t_ready;
@@ -1291,39 +1377,89 @@ struct spf_pool {
                     const size_t n_cu = (size_t)ctx->n_cu;
                     n_shape[(b->n <= n_cu && b->per_wg <= 1) ? 0 : ((b->n <= 2 * n_cu && b->per_wg <= 2) ? 1 : 2)]++;
                 }
-                // the batches its operands come from: enqueued before it (they were closed before it) — deferred ones on the same
-                // stream, batches of the ordinary lanes on their sets' streams: the deferred stream waits for THEIR events; one
-                // that has failed fails it
+                // the batches its operands come from: enqueued before it (they were closed before it) — on the same in-order
+                // stream (deferred cheap batches), or on a set's stream (the ordinary lanes, deferred bootstraps): this batch's
+                // stream waits for THEIR events; one that has failed fails it
                 spf_status st = SPF_OK;
                 if (!b->deps.empty()) {
+#ifdef SPF_POOL_TRACE
+                    const auto t_sd = clock::now();
+#endif
                     if (hipSetDevice(ctx->device) != hipSuccess) st = SPF_ERR_HIP;
+#ifdef SPF_POOL_TRACE
+                    tally.t_setdev += ms_since(t_sd);
+                    tally.n_deps += (long)b->deps.size();
+#endif
+                    const hipStream_t mine = stream_of(*b);
                     for (auto& d : b->deps) {
                         if (st != SPF_OK) break;
                         if (d->st != SPF_OK) st = d->st.load();
-                        else if (d->done || d->deferred) continue; // (deferred: ahead of this batch on the same in-order stream)
-                        else if (!d->ev_k || hipStreamWaitEvent(s_def, d->ev_k, 0) != hipSuccess) st = SPF_ERR_HIP;
+                        else if (d->done || stream_of(*d) == mine) continue; // (ahead of this batch on the same in-order stream)
+                        else {
+#ifdef SPF_POOL_TRACE
+                            tally.n_waits++;
+                            const auto t_w = clock::now();
+#endif
+                            if (!d->ev_k || hipStreamWaitEvent(mine, d->ev_k, 0) != hipSuccess) st = SPF_ERR_HIP;
+#ifdef SPF_POOL_TRACE
+                            if (ms_since(t_w) > 0.1) fprintf(stderr, "[pool] launcher: hipStreamWaitEvent took %.0f us (batch op %d waits for op %d deferred %d)\n", ms_since(t_w) * 1e3, b->op, d->op, (int)d->deferred);
+#endif
+                        }
                     }
                 }
+#ifdef SPF_POOL_TRACE
+                const auto t_a = clock::now();
+#endif
                 lk.unlock();
+#ifdef SPF_POOL_TRACE
+                auto t_b = clock::now(), t_c = t_b;
+#endif
                 try {
-                    if (st == SPF_OK && b->deferred && !prepare_set(sets[b->set], b->op, b->cap, true)) st = SPF_ERR_HIP;
+                    if (st == SPF_OK && b->deferred && !prepare_set(staging_of(*b), b->op, b->cap, true)) st = SPF_ERR_HIP;
+#ifdef SPF_POOL_TRACE
+                    t_c = clock::now();
+#endif
                     if (st == SPF_OK) st = enqueue(*b);
                 } catch (const std::exception&) {
                     st = SPF_ERR_HIP;
                 }
+#ifdef SPF_POOL_TRACE
+                const auto t_d = clock::now();
+#endif
                 lk.lock();
+#ifdef SPF_POOL_TRACE
+                tally.t_deps += std::chrono::duration<double, std::milli>(t_a - b->t_ready).count();
+                tally.t_prep += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+                tally.t_enq2 += std::chrono::duration<double, std::milli>(t_d - t_c).count();
+                tally.t_relock += std::chrono::duration<double, std::milli>(clock::now() - t_d).count();
+                if (ms_since(t_a) > 0.5)
+                    fprintf(stderr, "[pool] launcher: op %d n %zu deferred %d: deps %.0f us, prepare %.0f us, enqueue %.0f us, relock %.0f us\n", b->op, b->n, (int)b->deferred,
+                            std::chrono::duration<double, std::micro>(t_a - b->t_ready).count(), std::chrono::duration<double, std::micro>(t_c - t_b).count(),
+                            std::chrono::duration<double, std::micro>(t_d - t_c).count(), std::chrono::duration<double, std::micro>(clock::now() - t_d).count());
+#endif
                 b->st = st;
                 b->t_enq = clock::now();
                 in_flight.push_back(b);
                 bool mine = false;
-                if (b->by_handle && !heavy(b->op) && st == SPF_OK && hot_us > 0) {
+                if (b->by_handle && !heavy(b->op) && st == SPF_OK && (hot_us > 0 || table_batch(*b))) {
                     try {
                         polling.push_back(b);
                         mine = true;
                     } catch (const std::exception&) {
                     }
                 }
-                if (!mine) {
+                if (!mine && table_batch(*b)) {
+                    // (no completer thread serves the table sets: a batch that failed before its event was recorded — or that the
+                    // polling list has no room for — is handed back here, once whatever was enqueued for it has drained)
+                    lk.unlock();
+                    if (st != SPF_OK || hipEventSynchronize(b->ev_k) != hipSuccess) {
+                        if (b->st == SPF_OK) b->st = SPF_ERR_HIP;
+                        (void)hipStreamSynchronize(stream_of(*b));
+                    }
+                    b->t_sync = clock::now();
+                    finish_handle_batch(b);
+                    lk.lock();
+                } else if (!mine) {
                     flying[b->set] = b;
                     cv_fly[b->set].notify_one();
                 }
@@ -1372,6 +1508,9 @@ struct spf_pool {
             // until the next deadline or the next poke.
             if (!polling.empty() || now < hot_until) {
                 const uint64_t seen = work_epoch.load(std::memory_order_acquire);
+#ifdef SPF_POOL_TRACE
+                struct S { Tally& t; clock::time_point t0; ~S() { t.spin += std::chrono::duration<double, std::milli>(clock::now() - t0).count(); t.n_spin++; } } s_{tally, clock::now()};
+#endif
                 lk.unlock();
                 const auto until = std::min(wake, polling.empty() ? hot_until : now + std::chrono::microseconds(2));
                 for (int i = 0; work_epoch.load(std::memory_order_acquire) == seen; i++) {
@@ -1381,6 +1520,9 @@ struct spf_pool {
                 lk.lock();
                 continue;
             }
+#ifdef SPF_POOL_TRACE
+            struct Z { Tally& t; clock::time_point t0; ~Z() { t.sleep += std::chrono::duration<double, std::milli>(clock::now() - t0).count(); t.n_sleep++; } } z_{tally, clock::now()};
+#endif
             launcher_asleep.store(true, std::memory_order_release);
             if (wake == clock::time_point::max()) cv_work.wait(lk);
             else cv_work.wait_until(lk, wake);
