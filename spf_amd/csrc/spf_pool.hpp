@@ -605,7 +605,14 @@ struct spf_pool {
                 if (!seen) dep[n_dep++] = p;
             }
             if (n_dep) {
-                const auto key = std::make_tuple(depth, op, param, rank);
+                // The bootstrap kinds are keyed WITHOUT their depth: every deferred conversion behind the same number of bootstrap
+                // batches joins ONE batch, whatever level its operand comes from (the batch's depth is its deepest member's).  A launch
+                // of these kinds costs ~4 ms whatever its width, and the 128 conversions inside a 32 x 32 multiplication become ready
+                // at 31 depths: 31 launches of four (80 ms pushed) or one of 128.  No cycle can come of it: whatever a bootstrap batch
+                // of rank r needs has rank <= r, whatever needs it has rank > r.  (The early members wait for the late ones — the gate
+                // graph's planner, which knows every consumer, moves them by their slack; here nothing is known about consumers.)
+                const int64_t key_depth = heavy(op) ? -1 : depth;
+                const auto key = std::make_tuple(key_depth, op, param, rank);
                 try {
                     auto it = deferred.find(key);
                     if (it != deferred.end()) b = it->second;
@@ -624,6 +631,7 @@ struct spf_pool {
                         deferred.emplace(key, b);
                         if (first) poke(); // (the launcher arms the quiet time that flushes the table)
                     }
+                    b->depth = std::max(b->depth, depth);
                     for (int j = 0; j < n_dep; j++)
                         if (std::find(b->deps.begin(), b->deps.end(), dep[j]) == b->deps.end()) b->deps.push_back(dep[j]);
                 } catch (const std::exception&) {
@@ -719,13 +727,16 @@ struct spf_pool {
         if (b->deferred) {
             n_deferred_ops++;
             t_last_deferred = b->t_last;
+            // (launching what has gathered every N operations, so that the GPU works while a long push goes on, was measured and
+            // loses: it cuts the merged conversion batches into pieces — a pushed 32 x 32 multiplication 75-81 ms at 4 096 / 16 384
+            // operations per flush, 64 at 65 536, 60-65 with none)
             if (b->n == b->cap) {
                 // full: the next batch of this key is twice as big; this one waits with the rest (launching it now would take every
                 // shallower batch with it, half filled: a level of 1 024 gates pushed into a fresh pool is a few launches, once)
                 cap_hint[kind] = std::min(batch_cap(op), 2 * b->cap);
                 try {
                     deferred_full.push_back(b);
-                    deferred.erase(std::make_tuple(b->depth, op, param, b->rank));
+                    deferred.erase(std::make_tuple(heavy(op) ? (int64_t)-1 : b->depth, op, param, b->rank));
                 } catch (const std::exception&) {
                     flush_deferred();
                 }
