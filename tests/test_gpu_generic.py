@@ -289,6 +289,12 @@ def test_gate_graph_and_values_by_handle_over_a_generic_parameter_set(P):
         assert np.array_equal(pool.run_v(FheOp.CMux, [pool.trivial(ValueKind.GGSW1, 1), v[3], v[4]]).download(), outs[mux3])
         assert np.array_equal(pool.run_v(FheOp.SampleExtract, [v[4]], 5).download(), e_se[0])
         assert np.array_equal(pool.run_v(FheOp.MulXN, [v[0]], 2 * P.N + 7).download(), e_rot)
+        # ... and pushed: pending results as operands, nothing waited for but the last value
+        psel = pool.push_v(FheOp.CircuitBootstrap, [pool.push_v(FheOp.KeyswitchL1toL0, [vl])])
+        pm = pool.push_v(FheOp.CMux, [psel, pool.push_v(FheOp.Not, [v[1]]), pool.push_v(FheOp.GlweAdd, [v[2], v[5]])])
+        plast = pool.push_v(FheOp.CMux, [psel, pm, pool.push_v(FheOp.MultiplyGgswGlwe, [psel, pm])])
+        assert np.array_equal(plast.wait().download(), eng.cmux(e_cb[0:1], e_mux, eng.multiply_glwe_ggsw(e_mux, e_cb[0:1])[0])[0])
+        assert np.array_equal(pm.download(), e_mux)
     finally:
         import gc
         gc.collect()
