@@ -258,6 +258,33 @@ def test_reference_adder_pushed_from_one_thread_without_waits():
         n_l = c1["handle_launches"] - c0["handle_launches"]
         assert n_ops == len([o for o in rec.op if o >= 0])
         assert n_l <= 3 * st["launches"], (n_l, st)     # level batches, not one launch per operation
+        # any topological order will do: the nodes in creation order (depth first through every gate's sub-circuit, not level
+        # by level), and a random topological order — the pool sorts what it is given into (depth, kind) batches
+        creation = [i for i in range(len(rec.op)) if rec.op[i] >= 0]
+        outs, _, _ = drv.push_circuit_by_handles(pool, rec, order=creation)
+        assert all(np.array_equal(x, y) for x, y in zip(outs, g_outs))
+        rng = np.random.default_rng(5)
+        prio = rng.random(len(rec.op))
+        import heapq
+        n_wait = [sum(1 for j in rec.inputs[i] if rec.op[j] >= 0) if rec.op[i] >= 0 else 0 for i in range(len(rec.op))]
+        users = [[] for _ in rec.op]
+        for i in creation:
+            for j in rec.inputs[i]:
+                if rec.op[j] >= 0:
+                    users[j].append(i)
+        heap = [(prio[i], i) for i in creation if n_wait[i] == 0]
+        heapq.heapify(heap)
+        shuffled = []
+        while heap:
+            _, i = heapq.heappop(heap)
+            shuffled.append(i)
+            for u in users[i]:
+                n_wait[u] -= 1
+                if n_wait[u] == 0:
+                    heapq.heappush(heap, (prio[u], u))
+        assert len(shuffled) == len(creation) and shuffled != creation
+        outs, _, _ = drv.push_circuit_by_handles(pool, rec, order=shuffled)
+        assert all(np.array_equal(x, y) for x, y in zip(outs, g_outs))
         # four pushers and a blocking 32-worker walk of the same circuit at the same time on the same pool: every one of them
         # gets the graph's words (the pushers' deferred batches mix operations of all four; the blocking callers' batches are
         # the ordinary lanes')

@@ -127,7 +127,7 @@ def run_circuit_by_handles(pool, rec, threads=64, member=-1, vals=None):
     return outs, el.value, t_up + el.value + t_down
 
 
-def push_circuit_by_handles(pool, rec, member=-1):
+def push_circuit_by_handles(pool, rec, member=-1, order=None):
     """-> (outputs as arrays in rec.outputs order, seconds inside the pusher, seconds of upload + pusher + download).  ONE native
     thread submits every operation of the circuit without a ticket and without a wait, level by level (operands that are still
     pending: include/spf_hip.h "Deferred operands"), then waits for the output values only."""
@@ -142,7 +142,9 @@ def push_circuit_by_handles(pool, rec, member=-1):
     for i in range(n):
         if rec.op[i] >= 0:
             level[i] = 1 + max((level[j] for j in rec.inputs[i]), default=0)
-    order = np.array([i for i in np.argsort(level, kind="stable") if rec.op[i] >= 0], dtype=np.uint32)
+    if order is None:   # level by level; any topological order of the operation nodes will do (the pool batches by depth)
+        order = [i for i in np.argsort(level, kind="stable") if rec.op[i] >= 0]
+    order = np.array(order, dtype=np.uint32)
     outputs = np.array(rec.outputs, dtype=np.uint32)
     t0 = time.perf_counter()
     vals = upload_circuit_inputs(pool, rec, member)
