@@ -148,24 +148,33 @@ def test_random_tail_cmux_and_keyswitch_calls_against_the_oracle(tail_rig):
 def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
     """Random gate graphs through `spf_graph_*`: levels 1 to 300 gates wide (the executor sends a level to the four-waves-per-gate
     kernel or to the streaming kernel by its width), operands drawn from every earlier level, CMux / Not / GlweAdd / MulXN mixed,
-    selectors produced inside the graph (KeyswitchL1toL0 -> CircuitBootstrap).  Every output against the same operations run
-    level by level through the batch entry points (which the tests above hold against the oracle)."""
-    from spf_amd import FheOp, ValueKind
+    selectors produced inside the graph (KeyswitchL1toL0 -> CircuitBootstrap, of inputs and — conversions in the middle of the
+    graph — of graph values).  Every output against the same operations run level by level through the batch entry points (which
+    the tests above hold against the oracle); and the same DAG pushed operation by operation through the pool by handle (pending
+    results as operands: the pool's deferred scheduler) against the same expectation."""
+    import tools.driver as drv
+    from spf_amd import FheOp, RecordedCircuit, ValueKind
     ks, ak, ssk, eng = tail_rig
     P = ks.params
     rng = np.random.default_rng(SEED + 2)
+    pool = spf_amd.Pool(eng, max_batch=4096, max_wait_us=int(rng.choice((20, 200, 2000))))
     for case in range(max(2, CASES // 6)):
-        g = spf_amd.FheCircuit(eng)
+        g = RecordedCircuit()                                # (lowered into a gate graph AND pushed through the pool below)
         n_in, n_sel = int(rng.integers(2, 9)), int(rng.integers(1, 7))
         glwe_in = rng.integers(0, 1 << 64, size=(n_in, P.glwe_len), dtype=np.uint64)
         lwe1_in = rng.integers(0, 1 << 64, size=(n_sel, P.k * P.N + 1), dtype=np.uint64)
         val_nodes = [g.add_input(ValueKind.GLWE1, x) for x in glwe_in]
         sel_nodes = [g.add_op(FheOp.CircuitBootstrap, [g.add_op(FheOp.KeyswitchL1toL0, [g.add_input(ValueKind.LWE1, x)])])
                      for x in lwe1_in]
-        sel_vals = eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(lwe1_in))
+        sel_vals = list(eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(lwe1_in)))
         vals = [x for x in glwe_in]                      # eager value of val_nodes[i]
         depth = int(rng.integers(2, 8))
         for lvl in range(depth):
+            if rng.random() < 0.4:                       # a conversion in the middle of the graph: a selector made of a graph value
+                j, idx = int(rng.integers(0, len(val_nodes))), int(rng.integers(0, P.N))
+                sel_nodes.append(g.add_op(FheOp.CircuitBootstrap, [g.add_op(FheOp.KeyswitchL1toL0, [g.add_op(FheOp.SampleExtract, [val_nodes[j]], idx)])]))
+                sel_vals.append(eng.circuit_bootstrap(eng.keyswitch_lwe_l1_lwe_l0(eng.sample_extract_l1(vals[j][None], idx)))[0])
+                n_sel += 1
             width = int(rng.choice((1, 2, 3, 5, 40, 70, 260, 300)))
             avail = len(val_nodes)
             ops = rng.integers(0, 4, size=width)
@@ -187,7 +196,7 @@ def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
             Bv = np.stack([vals[i] for i in ib])
             mux = np.nonzero(ops == 0)[0]
             if mux.size:
-                r = eng.cmux(np.ascontiguousarray(sel_vals[isel[mux]]), A[mux], Bv[mux])
+                r = eng.cmux(np.stack([sel_vals[i] for i in isel[mux]]), A[mux], Bv[mux])
                 for j, k in enumerate(mux):
                     new_vals[k] = r[j]
             for k in np.nonzero(ops == 1)[0]:
@@ -200,11 +209,25 @@ def test_random_gate_graphs_equal_level_by_level_evaluation(tail_rig):
             vals += new_vals
         check = sorted(set(range(len(val_nodes) - len(new_nodes), len(val_nodes))) |
                        set(int(i) for i in rng.integers(n_in, len(val_nodes), size=20)))
-        outs = {i: g.add_output(val_nodes[i], ValueKind.GLWE1) for i in check}
-        g.run()
+        at = {i: g.add_output(val_nodes[i], ValueKind.GLWE1) for i in check}
+        graph, outs = g.lower(eng)
+        graph.run()
         for i in check:
-            assert np.array_equal(outs[i], vals[i]), f"graph case {case} (seed {SEED + 2}): node {i} of {len(val_nodes)}"
-        g.close()
+            assert np.array_equal(outs[at[i]], vals[i]), f"graph case {case} (seed {SEED + 2}): node {i} of {len(val_nodes)}"
+        graph.close()
+        # the same DAG PUSHED operation by operation through the pool (pending results as operands, nothing waited for but the
+        # outputs): in creation order, which is level by level here, or with every level's operations behind the next level's
+        # conversions — any topological order gives the graph's words
+        order = None
+        if case % 2:
+            order = sorted((i for i in range(len(g.op)) if g.op[i] >= 0), key=lambda i: (0 if g.op[i] in (int(FheOp.SampleExtract), int(FheOp.KeyswitchL1toL0), int(FheOp.CircuitBootstrap)) else 1, i))
+            pos = {n: k for k, n in enumerate(order)}
+            if any(pos.get(j, -1) > pos[i] for i in order for j in g.inputs[i] if g.op[j] >= 0):
+                order = None                             # (conversions of graph values cannot all go first: creation order then)
+        pushed = drv.push_circuit_by_handles(pool, g, order=order)[0]
+        for i in check:
+            assert np.array_equal(pushed[at[i]], vals[i]), f"pushed case {case} (seed {SEED + 2}): node {i} of {len(val_nodes)}"
+    pool.close()
 
 
 def test_random_parameter_sets_through_the_generic_family():
