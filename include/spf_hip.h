@@ -361,10 +361,11 @@ spf_status spf_pool_counters_get(spf_pool *pool, spf_pool_counters *out);
  *     (spf_value_download, spf_value_device_ptr, spf_value_copy_to_member), or after a failed batch, is
  *     SPF_ERR_INVALID_ARGUMENT, never a read of unfinished data.  It must be released in every case.
  *   Deferred operands: a result that is still pending MAY be passed as an operand of a later `_v` submit to the same pool.  The
- *     pool orders the two on the device (the dependent batch's stream waits for the producing batch's event) and batches what
- *     has been pushed by level: operations on pending operands join the open batch of their (depth, kind, parameter), depth =
- *     1 + the deepest batch an operand comes from, and the table is launched in depth order when a result in it is waited for,
- *     when a batch of it is full, or when nothing has joined it for max_wait_us.  A caller can thus push a whole circuit —
+ *     pool orders the two on the device (stream order, events, or — behind a bootstrap batch — launching the dependent batch
+ *     when the producing one has finished) and batches what has been pushed by level: operations on pending operands join the
+ *     open batch of their (depth, kind, parameter), depth = 1 + the deepest batch an operand comes from (the bootstrap kinds:
+ *     one batch per number of bootstraps they are behind, whatever the depth), and the table is launched in dependency order
+ *     when a result in it is waited for or when nothing has joined it for max_wait_us.  A caller can thus push a whole circuit —
  *     every `FheOp` one `_v` submit, from one thread, without a single wait — and wait for the outputs only: the level batching
  *     of spf_graph_run, built while the operations arrive.  An operation whose operand's producer failed fails with that status.
  *     `ticket` may be NULL in the `_v` submits: nobody will spf_pool_wait for that operation (no ticket to collect, no
