@@ -201,6 +201,18 @@ def test_pending_results_as_operands_a_chain_pushed_without_a_wait(rig):
         assert np.array_equal(got2[i], e_m2[i]), i
         assert np.array_equal(got1[i], O.cmux(O.glwe_not(a[i], P.N, P.k), O.glwe_xor(a[i], b[i], P.N, P.k), e_sel[i], P.N, P.k, P.cbs_radix_log, P.cbs_count)), i
 
+    # a pool that is closed with a pushed chain nobody has waited for: spf_pool_destroy launches and drains it, the results are
+    # valid afterwards (a value may outlive its pool)
+    pool = spf_amd.Pool(eng, max_batch=64, max_wait_us=100000)
+    va0, vx0 = pool.upload(ValueKind.GLWE1, a[0]), pool.upload(ValueKind.GLWE1, x[0])
+    sel = pool.push_v(FheOp.CircuitBootstrap, [pool.push_v(FheOp.KeyswitchL1toL0, [pool.push_v(FheOp.SampleExtract, [vx0], 3)])])
+    left = pool.push_v(FheOp.CMux, [sel, va0, pool.push_v(FheOp.Not, [va0])])
+    assert not left.info()["valid"]
+    pool.close()
+    assert left.info()["valid"] and left.wait() is left
+    assert np.array_equal(left.download(), eng.cmux(e_sel[0:1], a[0:1], eng.glwe_not(a[0:1]))[0])
+    del left, sel, va0, vx0
+
     # a producer that fails (no keys in this context): everything pushed behind it fails with it, nothing is read, the pool goes on
     bare = spf_amd.Engine(to_engine_params(P))
     pool = spf_amd.Pool(bare, max_batch=16, max_wait_us=100000)
