@@ -397,6 +397,9 @@ spf_status spf_value_download(const spf_value *value, void *host);
 /* blocks until the operation that produces `value` has run (returns at once for a valid value): SPF_OK, or the failure;
  * any thread, any number of times, whether or not the operation has a ticket.  Launches what is still deferred. */
 spf_status spf_value_wait(const spf_value *value);
+/* launches what has been pushed so far (the deferred table, see Deferred operands) without waiting for anything: a pusher that
+ * knows a long operation is complete — the conversions at the head of a circuit — lets it start while it pushes the rest */
+spf_status spf_pool_flush(spf_pool *pool);
 spf_status spf_value_retain(spf_value *value);
 void spf_value_release(spf_value *value);
 /* any of the out pointers may be NULL */

@@ -166,6 +166,7 @@ SYMBOLS = [
     ("spf_value_trivial", _I, [_P, _I, _I, _U64, C.POINTER(_P)]),
     ("spf_value_download", _I, [_P, _P]),
     ("spf_value_wait", _I, [_P]),
+    ("spf_pool_flush", _I, [_P]),
     ("spf_value_retain", _I, [_P]),
     ("spf_value_release", None, [_P]),
     ("spf_value_info", _I, [_P, C.POINTER(_I), C.POINTER(_SZ), C.POINTER(_I), C.POINTER(_I)]),
@@ -900,6 +901,10 @@ class Pool:
         h = C.c_void_p()
         self._ck(self._lib.spf_pool_submit_op_v(self._h, int(op), arr, len(inputs), int(param), C.byref(h), None), "spf_pool_submit_op_v")
         return Value(self, h)
+
+    def flush(self):
+        """`spf_pool_flush`: what has been pushed so far is launched (nothing is waited for)"""
+        self._ck(self._lib.spf_pool_flush(self._h), "spf_pool_flush")
 
     def run_v(self, op: int, inputs, param: int = 0) -> "Value":
         v, t = self.submit_v(op, inputs, param)

@@ -2421,6 +2421,18 @@ spf_status spf_value_wait(const spf_value* v)
     return v->home ? v->home->wait_value(v) : SPF_ERR_INVALID_ARGUMENT;
 }
 
+spf_status spf_pool_flush(spf_pool* p)
+{
+    if (!p) return SPF_ERR_INVALID_ARGUMENT;
+    auto one = [](spf_pool* q) {
+        std::lock_guard<spf_pool::Mutex> lk(q->mu);
+        q->flush_deferred();
+    };
+    if (p->members.empty()) one(p);
+    else for (spf_pool* q : p->members) one(q);
+    return SPF_OK;
+}
+
 spf_status spf_value_retain(spf_value* v)
 {
     if (!v) return SPF_ERR_INVALID_ARGUMENT;

@@ -40,7 +40,7 @@ def load():
     d.spf_pool_push_cmux_v.restype = C.c_long
     d.spf_pool_push_cmux_v.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_double, P, P, P, D]
     d.spf_circuit_push.restype = C.c_int
-    d.spf_circuit_push.argtypes = [P, P, P, P, C.c_uint32, P, P, P, P, P, P, P, C.c_uint32, P, C.c_uint32, D]
+    d.spf_circuit_push.argtypes = [P, P, P, P, P, C.c_uint32, P, P, P, P, P, P, P, C.c_uint32, P, C.c_uint32, D]
     d.spf_circuit_drive.restype = C.c_int
     d.spf_circuit_drive.argtypes = [P, P, P, P, C.c_int, C.c_uint32, P, P, P, P, P, P, D]
     _DRV = d
@@ -127,7 +127,7 @@ def run_circuit_by_handles(pool, rec, threads=64, member=-1, vals=None):
     return outs, el.value, t_up + el.value + t_down
 
 
-def push_circuit_by_handles(pool, rec, member=-1, order=None):
+def push_circuit_by_handles(pool, rec, member=-1, order=None, flush_conversions=True):
     """-> (outputs as arrays in rec.outputs order, seconds inside the pusher, seconds of upload + pusher + download).  ONE native
     thread submits every operation of the circuit without a ticket and without a wait, level by level (operands that are still
     pending: include/spf_hip.h "Deferred operands"), then waits for the output values only."""
@@ -151,7 +151,8 @@ def push_circuit_by_handles(pool, rec, member=-1, order=None):
     t_up = time.perf_counter() - t0
     table = (C.c_void_p * n)(*[(v._h if v is not None else None) for v in vals])
     el = C.c_double()
-    st = d.spf_circuit_push(pool._h, fn(lib, "spf_pool_submit_op_v"), fn(lib, "spf_value_wait"), fn(lib, "spf_value_release"), n,
+    st = d.spf_circuit_push(pool._h, fn(lib, "spf_pool_submit_op_v"), fn(lib, "spf_value_wait"), fn(lib, "spf_value_release"),
+                            fn(lib, "spf_pool_flush") if flush_conversions else None, n,
                             a["op"].ctypes.data, a["in"].ctypes.data, a["n_in"].ctypes.data, a["param"].ctypes.data, table,
                             a["keep"].ctypes.data, order.ctypes.data, len(order), outputs.ctypes.data, len(outputs), C.byref(el))
     for i, v in enumerate(vals):   # inputs the pusher released must not be released again by their wrappers

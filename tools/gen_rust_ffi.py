@@ -185,8 +185,8 @@ FAMILIES = [
     ("context and keys", r"spf_(default_params|create|destroy|last_error|version|load_|key_blob)"),
     ("hot path, host pointers (`_batch`)", r"spf_(?!group_|pool_).*_batch$"),
     ("hot path, device pointers (`_dev`) and device buffers", r"spf_((?!group_).*_dev$|device_)"),
-    ("call coalescing: the pool, host pointers", r"spf_pool_(?!.*_v$)(?!value_|trim|create_group)"),
-    ("device-resident values and the pool by handle", r"spf_(value_|pool_.*_v$|pool_value_stats|pool_trim)"),
+    ("call coalescing: the pool, host pointers", r"spf_pool_(?!.*_v$)(?!value_|trim|flush|create_group)"),
+    ("device-resident values and the pool by handle", r"spf_(value_|pool_.*_v$|pool_value_stats|pool_trim|pool_flush)"),
     ("gate graphs", r"spf_graph_"),
     ("device group (every GPU, one process)", r"spf_(group_|pool_create_group)"),
     ("measurement, LUT, wire formats, constants", r"spf_"),

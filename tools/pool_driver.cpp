@@ -364,7 +364,8 @@ int spf_circuit_drive(spf_pool* pool, submit_op_v_fn submit, wait_fn wait, relea
 // returned at once) — the operands of a task are results that are still pending, the pool orders and batches them by level
 // (spf_hip.h, "Deferred operands") — then waits for the `n_out` output values only.  Values nobody keeps are released right after
 // the last submit that takes them (the pool holds its own references while they are needed).
-int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_wait, release_fn release, uint32_t n_nodes,
+typedef spf_status (*flush_fn)(spf_pool*);
+int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_wait, release_fn release, flush_fn flush, uint32_t n_nodes,
                      const int32_t* op, const uint32_t* in, const uint32_t* n_in, const uint64_t* param, spf_value** values,
                      const uint8_t* keep, const uint32_t* order, uint32_t n_order, const uint32_t* outputs, uint32_t n_out,
                      double* elapsed_s)
@@ -387,6 +388,9 @@ int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_
             const uint32_t src = in[3 * node + k];
             if (--users[src] == 0 && !keep[src] && values[src]) { release(values[src]); values[src] = nullptr; }
         }
+        // (flush, may be null: the last of a run of circuit bootstraps has been pushed — the conversions at the head of a circuit
+        // are complete and milliseconds long: they start now, under the rest of the push)
+        if (flush && op[node] == SPF_OP_CIRCUIT_BOOTSTRAP && (j + 1 == n_order || op[order[j + 1]] != SPF_OP_CIRCUIT_BOOTSTRAP)) (void)flush(pool);
     }
     const auto t_pushed = std::chrono::steady_clock::now();
     for (uint32_t j = 0; j < n_out && !error; j++) {
