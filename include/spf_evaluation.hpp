@@ -311,6 +311,9 @@ class PooledEvaluation {
     PooledEvaluation& operator=(const PooledEvaluation&) = delete;
     ~PooledEvaluation() { spf_pool_destroy(pool_); }
     spf_pool* raw() const { return pool_; }
+    // pushed mode: what has been pushed so far is launched now (e.g. once the conversions at the head of a circuit are in: they
+    // run under the rest of the push); nothing is waited for
+    void flush() const { check(spf_pool_flush(pool_)); }
 
     // `encrypt` / `trivial_*` land here: host words -> a device ciphertext on the calling thread's member
     template <class C> C upload(const void* host) const
