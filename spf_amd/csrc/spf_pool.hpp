@@ -446,7 +446,7 @@ struct spf_pool {
     {
         return spf_pool_impl::cmux_family(op) ? 4 * cap * (op == spf_pool_impl::OP_GLEV_CMUX ? prm.cbs_radix_count : 1) + 3 * cap : 3 * cap;
     }
-    bool prepare_set(spf_pool_impl::Staging& s, int op, size_t cap, bool by_handle)
+    bool prepare_set(spf_pool_impl::Staging& s, int op, size_t cap, bool by_handle, bool table_set = false)
     {
         size_t in[3], out;
         in_out_sizes(op, in, out);
@@ -469,7 +469,9 @@ struct spf_pool {
         }
         if (op == spf_pool_impl::OP_GATE_CBS && !grow_dev(s.d_mid, s.cap_mid, cap * lwe0_bytes())) return false;
         if ((op == spf_pool_impl::OP_KEYSWITCH || op == spf_pool_impl::OP_CBS || op == spf_pool_impl::OP_GATE_CBS) && s.scr_cap < cap) {
-            if (scratch_reserve(ctx, s.scr, cap, true, true) != SPF_OK) return false; // (both: the set serves any kind later)
+            // (both: a staging set serves any kind later; a table set only ever sees the keyswitch — no 160 KB of circuit-bootstrap
+            // intermediates per slot for it)
+            if (scratch_reserve(ctx, s.scr, cap, true, !table_set) != SPF_OK) return false;
             s.scr_cap = cap;
         }
         return true;
@@ -1426,7 +1428,7 @@ struct spf_pool {
                 auto t_b = clock::now(), t_c = t_b;
 #endif
                 try {
-                    if (st == SPF_OK && b->deferred && !prepare_set(staging_of(*b), b->op, b->cap, true)) st = SPF_ERR_HIP;
+                    if (st == SPF_OK && b->deferred && !prepare_set(staging_of(*b), b->op, b->cap, true, table_batch(*b))) st = SPF_ERR_HIP;
 #ifdef SPF_POOL_TRACE
                     t_c = clock::now();
 #endif
