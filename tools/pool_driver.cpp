@@ -390,7 +390,11 @@ int spf_circuit_push(spf_pool* pool, submit_op_v_fn submit, value_wait_fn value_
         }
         // (flush, may be null: the last of a run of circuit bootstraps has been pushed — the conversions at the head of a circuit
         // are complete and milliseconds long: they start now, under the rest of the push)
-        if (flush && op[node] == SPF_OP_CIRCUIT_BOOTSTRAP && (j + 1 == n_order || op[order[j + 1]] != SPF_OP_CIRCUIT_BOOTSTRAP)) (void)flush(pool);
+        // (once: conversions in the middle of a circuit are better left to gather — the pool runs all of one rank as one batch)
+        if (flush && op[node] == SPF_OP_CIRCUIT_BOOTSTRAP && (j + 1 == n_order || op[order[j + 1]] != SPF_OP_CIRCUIT_BOOTSTRAP)) {
+            (void)flush(pool);
+            flush = nullptr;
+        }
     }
     const auto t_pushed = std::chrono::steady_clock::now();
     for (uint32_t j = 0; j < n_out && !error; j++) {
