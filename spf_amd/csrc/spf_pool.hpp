@@ -731,7 +731,8 @@ struct spf_pool {
             t_last_deferred = b->t_last;
             // (launching what has gathered every N operations, so that the GPU works while a long push goes on, was measured and
             // loses: it cuts the merged conversion batches into pieces — a pushed 32 x 32 multiplication 75-81 ms at 4 096 / 16 384
-            // operations per flush, 64 at 65 536, 60-65 with none)
+            // operations per flush, 64 at 65 536, 60-65 with none; launching only the CHEAP batches every 2 048 / 8 192 / 32 768
+            // operations: 60-62 ms against 51-54 — the launcher then works the pool's mutex while the pusher pushes)
             if (b->n == b->cap) {
                 // full: the next batch of this key is twice as big; this one waits with the rest (launching it now would take every
                 // shallower batch with it, half filled: a level of 1 024 gates pushed into a fresh pool is a few launches, once)
