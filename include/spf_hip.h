@@ -395,7 +395,8 @@ spf_status spf_value_trivial(spf_pool *pool, int member, spf_value_kind kind, ui
 /* HBM -> host (blocking); `host` has room for the kind's words */
 spf_status spf_value_download(const spf_value *value, void *host);
 /* blocks until the operation that produces `value` has run (returns at once for a valid value): SPF_OK, or the failure;
- * any thread, any number of times, whether or not the operation has a ticket.  Launches what is still deferred. */
+ * any thread, any number of times, whether or not the operation has a ticket.  Launches what the value needs: the deferred table,
+ * or the open batch the operation sits in (spf_pool_wait leaves such a batch open for other callers to join). */
 spf_status spf_value_wait(const spf_value *value);
 /* launches what has been pushed so far (the deferred table, see Deferred operands) without waiting for anything: a pusher that
  * knows a long operation is complete — the conversions at the head of a circuit — lets it start while it pushes the rest */

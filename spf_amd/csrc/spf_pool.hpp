@@ -1050,6 +1050,9 @@ struct spf_pool {
                 std::lock_guard<Mutex> lk(mu);
                 b = v->producer;
                 if (b && b->deferred && !b->closed) flush_deferred();
+                // (an operation with valid operands sits in an ordinary lane: whoever waits for its VALUE wants it now — the lane is
+                // closed instead of sitting out the quiet time; spf_pool_wait, the blocking callers' way, leaves it to gather)
+                else if (b && !b->deferred && !b->closed && filling[b->lane] == b) close_batch(b->lane);
             }
             if (b) {
                 const size_t g = v->slot / Batch::kTreeGroup;
